@@ -1,0 +1,462 @@
+"""TEST INFRASTRUCTURE — ctypes bindings for the CPU oracle.
+
+Two back ends with the same Python surface (mirroring the reference classes):
+
+* ``port`` — oracle/libhcv_oracle.so, the plain-C restatement (hcv_oracle.c).  Travels in-tree.
+* ``ref``  — oracle/_ref/libhisstools_ref.so, the *unmodified* reference compiled from
+  /root/reference by oracle/Makefile.  Exists wherever it was prebuilt (it is git-ignored but
+  travels to the GPU box with the snapshot).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (hisstools_library_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_PATH = os.path.join(_HERE, "libhcv_oracle.so")
+REF_PATH = os.path.join(_HERE, "_ref", "libhisstools_ref.so")
+REF_ROOT = "/root/reference"
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_sz = C.c_size_t
+_ip = C.c_ssize_t
+
+
+def build(ref: bool = True) -> None:
+    """Compile the oracle (and the reference build where /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+    if ref and os.path.isdir(REF_ROOT):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_PATH)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(_f64p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+_libs: dict = {}
+
+
+def _decl(lib, name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+def lib(backend: str):
+    if backend in _libs:
+        return _libs[backend]
+    if backend == "port":
+        if not os.path.exists(PORT_PATH):
+            build(ref=False)
+        L = C.CDLL(PORT_PATH)
+        s = "_f32"
+        n = {k: "hcvo_" + k + s for k in (
+            "part_new part_delete part_set_fft_size part_set_length part_set_offset part_set_reset_offset "
+            "part_set part_reset part_process td_new td_delete td_set_length td_set_offset td_set td_reset "
+            "td_process mono_new mono_new_custom mono_delete mono_set_reset_offset mono_resize mono_set "
+            "mono_reset mono_process n2m_new n2m_delete n2m_resize n2m_set n2m_reset n2m_process conv_new "
+            "conv_new_parallel conv_delete conv_clear conv_clear_chan conv_reset conv_reset_chan conv_resize "
+            "conv_stream").split()}
+        n.update(conv_set_f32="hcvo_conv_set_f32", conv_set_f64="hcvo_conv_set_f64",
+                 conv_process_f32="hcvo_conv_process_f32", conv_process_f64="hcvo_conv_process_f64",
+                 rfft="hcvo_rfft_f32", rifft="hcvo_rifft_f32", fft="hcvo_fft_f32")
+    elif backend == "ref":
+        if not os.path.exists(REF_PATH):
+            if os.path.isdir(REF_ROOT):
+                build(ref=True)
+            else:
+                raise FileNotFoundError(REF_PATH + " (reference build) is not available here")
+        L = C.CDLL(REF_PATH)
+        n = {k: "ref_" + k for k in (
+            "part_new part_delete part_set_fft_size part_set_length part_set_offset part_set_reset_offset "
+            "part_set part_reset part_process td_new td_delete td_set_length td_set_offset td_set td_reset "
+            "td_process mono_new mono_new_custom mono_delete mono_set_reset_offset mono_resize mono_set "
+            "mono_reset mono_process n2m_new n2m_delete n2m_resize n2m_set n2m_reset n2m_process conv_new "
+            "conv_new_parallel conv_delete conv_clear conv_clear_chan conv_reset conv_reset_chan conv_resize "
+            "conv_set_f32 conv_set_f64 conv_process_f32 conv_process_f64").split()}
+        n.update(conv_stream="ref_conv_stream_f32", rfft="ref_rfft_f32", rifft="ref_rifft_f32", fft="ref_fft_f32")
+    else:
+        raise ValueError(backend)
+
+    vp = C.c_void_p
+    f = {}
+    f["part_new"] = _decl(L, n["part_new"], vp, _sz, _sz, _sz, _sz)
+    f["part_delete"] = _decl(L, n["part_delete"], None, vp)
+    f["part_set_fft_size"] = _decl(L, n["part_set_fft_size"], C.c_int, vp, _sz)
+    f["part_set_length"] = _decl(L, n["part_set_length"], C.c_int, vp, _sz)
+    f["part_set_offset"] = _decl(L, n["part_set_offset"], None, vp, _sz)
+    f["part_set_reset_offset"] = _decl(L, n["part_set_reset_offset"], None, vp, _ip)
+    f["part_set"] = _decl(L, n["part_set"], C.c_int, vp, _f32p, _sz)
+    f["part_reset"] = _decl(L, n["part_reset"], None, vp)
+    f["part_process"] = _decl(L, n["part_process"], C.c_int, vp, _f32p, _f32p, _sz)
+    f["td_new"] = _decl(L, n["td_new"], vp, _sz, _sz)
+    f["td_delete"] = _decl(L, n["td_delete"], None, vp)
+    f["td_set_length"] = _decl(L, n["td_set_length"], C.c_int, vp, _sz)
+    f["td_set_offset"] = _decl(L, n["td_set_offset"], None, vp, _sz)
+    f["td_set"] = _decl(L, n["td_set"], C.c_int, vp, _f32p, _sz)
+    f["td_reset"] = _decl(L, n["td_reset"], None, vp)
+    f["td_process"] = _decl(L, n["td_process"], C.c_int, vp, _f32p, _f32p, _sz)
+    f["mono_new"] = _decl(L, n["mono_new"], vp, _sz, C.c_int)
+    if backend == "port":
+        f["mono_new_custom"] = _decl(L, n["mono_new_custom"], vp, _sz, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p))
+    else:
+        f["mono_new_custom"] = _decl(L, n["mono_new_custom"], vp, _sz, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, _sz)
+    f["mono_delete"] = _decl(L, n["mono_delete"], None, vp)
+    f["mono_set_reset_offset"] = _decl(L, n["mono_set_reset_offset"], None, vp, _ip)
+    f["mono_resize"] = _decl(L, n["mono_resize"], C.c_int, vp, _sz)
+    f["mono_set"] = _decl(L, n["mono_set"], C.c_int, vp, _f32p, _sz, C.c_int)
+    f["mono_reset"] = _decl(L, n["mono_reset"], C.c_int, vp)
+    f["mono_process"] = _decl(L, n["mono_process"], None, vp, _f32p, _f32p, _f32p, _sz, C.c_int)
+    f["n2m_new"] = _decl(L, n["n2m_new"], vp, C.c_uint32, _sz, C.c_int)
+    f["n2m_delete"] = _decl(L, n["n2m_delete"], None, vp)
+    f["n2m_resize"] = _decl(L, n["n2m_resize"], C.c_int, vp, C.c_uint32, _sz)
+    f["n2m_set"] = _decl(L, n["n2m_set"], C.c_int, vp, C.c_uint32, _f32p, _sz, C.c_int)
+    f["n2m_reset"] = _decl(L, n["n2m_reset"], C.c_int, vp, C.c_uint32)
+    f["n2m_process"] = _decl(L, n["n2m_process"], None, vp, C.POINTER(_f32p), _f32p, _f32p, _sz, _sz)
+    f["conv_new"] = _decl(L, n["conv_new"], vp, C.c_uint32, C.c_uint32, C.c_int)
+    f["conv_new_parallel"] = _decl(L, n["conv_new_parallel"], vp, C.c_uint32, C.c_int)
+    f["conv_delete"] = _decl(L, n["conv_delete"], None, vp)
+    f["conv_clear"] = _decl(L, n["conv_clear"], None, vp, C.c_int)
+    f["conv_clear_chan"] = _decl(L, n["conv_clear_chan"], None, vp, C.c_uint32, C.c_uint32, C.c_int)
+    f["conv_reset"] = _decl(L, n["conv_reset"], None, vp)
+    f["conv_reset_chan"] = _decl(L, n["conv_reset_chan"], C.c_int, vp, C.c_uint32, C.c_uint32)
+    f["conv_resize"] = _decl(L, n["conv_resize"], C.c_int, vp, C.c_uint32, C.c_uint32, _sz)
+    f["conv_set_f32"] = _decl(L, n["conv_set_f32"], C.c_int, vp, C.c_uint32, C.c_uint32, _f32p, _sz, C.c_int)
+    f["conv_set_f64"] = _decl(L, n["conv_set_f64"], C.c_int, vp, C.c_uint32, C.c_uint32, _f64p, _sz, C.c_int)
+    f["conv_process_f32"] = _decl(L, n["conv_process_f32"], None, vp, C.POINTER(_f32p), C.POINTER(_f32p), _sz, _sz, _sz)
+    f["conv_process_f64"] = _decl(L, n["conv_process_f64"], None, vp, C.POINTER(_f64p), C.POINTER(_f64p), _sz, _sz, _sz)
+    f["conv_stream"] = _decl(L, n["conv_stream"], C.c_double, vp, _f32p, _f32p, _sz, _sz, _sz, _sz)
+    if backend == "port":
+        f["rfft"] = _decl(L, n["rfft"], None, _f32p, _sz, C.c_uint, _f32p, _f32p)
+        f["rifft"] = _decl(L, n["rifft"], None, _f32p, _f32p, C.c_uint, _f32p)
+        f["fft"] = _decl(L, n["fft"], None, _f32p, _f32p, C.c_uint, C.c_int)
+        f["synth_audio"] = _decl(L, "hcvo_synth_audio_f32", None, C.c_uint32, _f32p, _sz)
+        f["synth_ir"] = _decl(L, "hcvo_synth_ir_f32", None, C.c_uint32, C.c_uint32, _f32p, _sz)
+        f["conv_set_reset_offset"] = _decl(L, "hcvo_conv_set_reset_offset_f32", None, vp, _ip)
+        f["n2m_set_reset_offset"] = _decl(L, "hcvo_n2m_set_reset_offset_f32", None, vp, _ip)
+        f["rfft_f64"] = _decl(L, "hcvo_rfft_f64", None, _f64p, _sz, C.c_uint, _f64p, _f64p)
+        f["rifft_f64"] = _decl(L, "hcvo_rifft_f64", None, _f64p, _f64p, C.c_uint, _f64p)
+    else:
+        f["rfft"] = _decl(L, n["rfft"], None, _f32p, _sz, _sz, _f32p, _f32p)
+        f["rifft"] = _decl(L, n["rifft"], None, _f32p, _f32p, _sz, _f32p)
+        f["fft"] = _decl(L, n["fft"], None, _f32p, _f32p, _sz, C.c_int)
+        f["part_stream"] = _decl(L, "ref_part_stream_f32", C.c_double, vp, _f32p, _f32p, _sz, _sz)
+        f["mono_stream"] = _decl(L, "ref_mono_stream_f32", C.c_double, vp, _f32p, _f32p, _sz, _sz)
+        f["unzip"] = _decl(L, "ref_unzip_f32", None, _f32p, _f32p, _f32p, _sz)
+        f["zip"] = _decl(L, "ref_zip_f32", None, _f32p, _f32p, _f32p, _sz)
+        f["unzip_zero"] = _decl(L, "ref_unzip_zero_f32", None, _f32p, _f32p, _f32p, _sz, _sz)
+    ns = type("OracleLib", (), f)
+    ns.backend = backend
+    ns.cdll = L
+    _libs[backend] = ns
+    return ns
+
+
+# --------------------------------------------------------------------------------------- FFT
+
+def rfft(x, log2n: int, backend: str = "port"):
+    """hisstools_rfft 5-arg: returns (realp, imagp) of length 2^(log2n-1)."""
+    L = lib(backend)
+    x = _f32(x)
+    half = 1 << (log2n - 1)
+    re = np.zeros(half, np.float32)
+    im = np.zeros(half, np.float32)
+    L.rfft(_fp(x), x.size, log2n, _fp(re), _fp(im))
+    return re, im
+
+
+def rifft(re, im, log2n: int, backend: str = "port"):
+    """hisstools_rifft 4-arg: returns 2^log2n real samples (unnormalised)."""
+    L = lib(backend)
+    re, im = _f32(re).copy(), _f32(im).copy()
+    out = np.zeros(1 << log2n, np.float32)
+    L.rifft(_fp(re), _fp(im), log2n, _fp(out))
+    return out
+
+
+def fft(re, im, log2n: int, inverse: bool = False, backend: str = "port"):
+    L = lib(backend)
+    re, im = _f32(re).copy(), _f32(im).copy()
+    L.fft(_fp(re), _fp(im), log2n, int(inverse))
+    return re, im
+
+
+# --------------------------------------------------------------------------------------- synthetic data
+
+def synth_audio(ch: int, n: int) -> np.ndarray:
+    x = np.zeros(n, np.float32)
+    lib("port").synth_audio(ch, _fp(x), n)
+    return x
+
+
+def synth_ir(i: int, o: int, length: int) -> np.ndarray:
+    h = np.zeros(length, np.float32)
+    lib("port").synth_ir(i, o, _fp(h), length)
+    return h
+
+
+# --------------------------------------------------------------------------------------- classes
+
+def _blocks(total: int, block):
+    """Yield (pos, n) for a fixed block size or a cyclic list of ragged sizes."""
+    pos, k = 0, 0
+    sizes = [block] if isinstance(block, int) else list(block)
+    while pos < total:
+        n = min(sizes[k % len(sizes)], total - pos)
+        yield pos, n
+        pos += n
+        k += 1
+
+
+class PartitionedConvolve:
+    def __init__(self, maxFFTSize, maxLength, offset, length, backend="port"):
+        self.L = lib(backend)
+        self.h = self.L.part_new(maxFFTSize, maxLength, offset, length)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.part_delete(self.h)
+            self.h = None
+
+    def setFFTSize(self, n): return self.L.part_set_fft_size(self.h, n)
+    def setLength(self, n): return self.L.part_set_length(self.h, n)
+    def setOffset(self, n): self.L.part_set_offset(self.h, n)
+    def setResetOffset(self, n=-1): self.L.part_set_reset_offset(self.h, n)
+    def reset(self): self.L.part_reset(self.h)
+
+    def set(self, ir, length=None):
+        if ir is None:
+            return self.L.part_set(self.h, None, 0 if length is None else length)
+        ir = _f32(ir)
+        return self.L.part_set(self.h, _fp(ir), ir.size if length is None else length)
+
+    def process(self, x, out=None):
+        x = _f32(x)
+        if out is None:
+            out = np.full(x.size, np.nan, np.float32)
+        wrote = self.L.part_process(self.h, _fp(x), _fp(out), x.size)
+        return bool(wrote), out
+
+    def run(self, x, block=512):
+        x = _f32(x)
+        y = np.zeros_like(x)
+        for pos, n in _blocks(x.size, block):
+            self.L.part_process(self.h, _fp(x[pos:pos + n]), _fp(y[pos:pos + n]), n)
+        return y
+
+
+class TimeDomainConvolve:
+    def __init__(self, offset, length, backend="port"):
+        self.L = lib(backend)
+        self.h = self.L.td_new(offset, length)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.td_delete(self.h)
+            self.h = None
+
+    def setLength(self, n): return self.L.td_set_length(self.h, n)
+    def setOffset(self, n): self.L.td_set_offset(self.h, n)
+    def reset(self): self.L.td_reset(self.h)
+
+    def set(self, ir, length=None):
+        if ir is None:
+            return self.L.td_set(self.h, None, 0 if length is None else length)
+        ir = _f32(ir)
+        return self.L.td_set(self.h, _fp(ir), ir.size if length is None else length)
+
+    def process(self, x, out=None):
+        x = _f32(x)
+        if out is None:
+            out = np.full(x.size, np.nan, np.float32)
+        wrote = self.L.td_process(self.h, _fp(x), _fp(out), x.size)
+        return bool(wrote), out
+
+    def run(self, x, block=512):
+        x = _f32(x)
+        y = np.zeros_like(x)
+        for pos, n in _blocks(x.size, block):
+            self.L.td_process(self.h, _fp(x[pos:pos + n]), _fp(y[pos:pos + n]), n)
+        return y
+
+
+class MonoConvolve:
+    def __init__(self, maxLength, latency=None, zeroLatency=None, A=0, B=0, C_=0, D=0, backend="port"):
+        self.L = lib(backend)
+        self.error = None
+        if latency is not None:
+            self.h = self.L.mono_new(maxLength, int(latency))
+        elif backend == "port":
+            err = C.c_char_p()
+            self.h = self.L.mono_new_custom(maxLength, int(bool(zeroLatency)), A, B, C_, D, C.byref(err))
+            if not self.h:
+                self.error = err.value.decode()
+        else:
+            buf = C.create_string_buffer(128)
+            self.h = self.L.mono_new_custom(maxLength, int(bool(zeroLatency)), A, B, C_, D, buf, 128)
+            if not self.h:
+                self.error = buf.value.decode()
+        if not self.h:
+            raise RuntimeError(self.error or "construction failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.mono_delete(self.h)
+            self.h = None
+
+    def setResetOffset(self, n=-1): self.L.mono_set_reset_offset(self.h, n)
+    def resize(self, n): return self.L.mono_resize(self.h, n)
+    def reset(self): return self.L.mono_reset(self.h)
+
+    def set(self, ir, requestResize, length=None):
+        if ir is None:
+            return self.L.mono_set(self.h, None, 0 if length is None else length, int(requestResize))
+        ir = _f32(ir)
+        return self.L.mono_set(self.h, _fp(ir), ir.size if length is None else length, int(requestResize))
+
+    def process(self, x, out=None, accumulate=False):
+        x = _f32(x)
+        if out is None:
+            out = np.full(x.size, np.nan, np.float32)
+        temp = np.zeros(x.size, np.float32)
+        self.L.mono_process(self.h, _fp(x), _fp(temp), _fp(out), x.size, int(accumulate))
+        return out
+
+    def run(self, x, block=512):
+        x = _f32(x)
+        y = np.zeros_like(x)
+        temp = np.zeros(x.size, np.float32)
+        for pos, n in _blocks(x.size, block):
+            self.L.mono_process(self.h, _fp(x[pos:pos + n]), _fp(temp), _fp(y[pos:pos + n]), n, 0)
+        return y
+
+
+def _ptr_array(rows, ptr_t):
+    arr = (ptr_t * len(rows))()
+    for i, r in enumerate(rows):
+        arr[i] = r.ctypes.data_as(ptr_t)
+    return arr
+
+
+class NToMonoConvolve:
+    def __init__(self, inChans, maxLength, latency, backend="port"):
+        self.L = lib(backend)
+        self.h = self.L.n2m_new(inChans, maxLength, int(latency))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.n2m_delete(self.h)
+            self.h = None
+
+    def resize(self, inChan, n): return self.L.n2m_resize(self.h, inChan, n)
+    def reset(self, inChan): return self.L.n2m_reset(self.h, inChan)
+
+    def setResetOffset(self, n):          # port only
+        self.L.n2m_set_reset_offset(self.h, n)
+
+    def set(self, inChan, ir, resize, length=None):
+        if ir is None:
+            return self.L.n2m_set(self.h, inChan, None, 0 if length is None else length, int(resize))
+        ir = _f32(ir)
+        return self.L.n2m_set(self.h, inChan, _fp(ir), ir.size if length is None else length, int(resize))
+
+    def run(self, ins, block=512, activeIns=None):
+        ins = _f32(ins)
+        nin, total = ins.shape
+        y = np.zeros(total, np.float32)
+        temp = np.zeros(total, np.float32)
+        act = nin if activeIns is None else activeIns
+        for pos, n in _blocks(total, block):
+            rows = [ins[i, pos:pos + n] for i in range(nin)]
+            self.L.n2m_process(self.h, _ptr_array(rows, _f32p), _fp(y[pos:pos + n]), _fp(temp), n, act)
+        return y
+
+
+class Convolver:
+    def __init__(self, numIns, numOuts=None, latency=0, backend="port"):
+        self.L = lib(backend)
+        if numOuts is None:
+            self.h = self.L.conv_new_parallel(numIns, int(latency))
+        else:
+            self.h = self.L.conv_new(numIns, numOuts, int(latency))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.conv_delete(self.h)
+            self.h = None
+
+    def clear(self, *args):
+        if len(args) == 1:
+            self.L.conv_clear(self.h, int(args[0]))
+        else:
+            self.L.conv_clear_chan(self.h, args[0], args[1], int(args[2]))
+
+    def reset(self, *args):
+        if not args:
+            self.L.conv_reset(self.h)
+            return None
+        return self.L.conv_reset_chan(self.h, args[0] & 0xFFFFFFFF, args[1] & 0xFFFFFFFF)
+
+    def resize(self, inChan, outChan, n): return self.L.conv_resize(self.h, inChan & 0xFFFFFFFF, outChan & 0xFFFFFFFF, n)
+
+    def setResetOffset(self, n):          # port only
+        self.L.conv_set_reset_offset(self.h, n)
+
+    def set(self, inChan, outChan, ir, resize, length=None):
+        if ir is None:
+            return self.L.conv_set_f32(self.h, inChan, outChan, None, 0 if length is None else length, int(resize))
+        ir = np.ascontiguousarray(ir)
+        if ir.dtype == np.float64:
+            return self.L.conv_set_f64(self.h, inChan, outChan, _dp(ir), ir.size if length is None else length, int(resize))
+        ir = _f32(ir)
+        return self.L.conv_set_f32(self.h, inChan, outChan, _fp(ir), ir.size if length is None else length, int(resize))
+
+    def process(self, ins, outs, numIns=None, numOuts=None):
+        """ins: [numIns][n], outs: [numOuts][n] (written in place); dtype float32 or float64."""
+        n = ins.shape[1]
+        ni = ins.shape[0] if numIns is None else numIns
+        no = outs.shape[0] if numOuts is None else numOuts
+        if ins.dtype == np.float64:
+            self.L.conv_process_f64(self.h, _ptr_array(list(ins), _f64p), _ptr_array(list(outs), _f64p), ni, no, n)
+        else:
+            self.L.conv_process_f32(self.h, _ptr_array(list(ins), _f32p), _ptr_array(list(outs), _f32p), ni, no, n)
+
+    def run(self, ins, numOuts, block=512):
+        ins = np.ascontiguousarray(ins)
+        nin, total = ins.shape
+        outs = np.zeros((numOuts, total), ins.dtype)
+        for pos, n in _blocks(total, block):
+            i_rows = [ins[i, pos:pos + n] for i in range(nin)]
+            o_rows = [outs[o, pos:pos + n] for o in range(numOuts)]
+            pt = _f64p if ins.dtype == np.float64 else _f32p
+            fn = self.L.conv_process_f64 if ins.dtype == np.float64 else self.L.conv_process_f32
+            fn(self.h, _ptr_array(i_rows, pt), _ptr_array(o_rows, pt), nin, numOuts, n)
+        return outs
+
+    def stream_timed(self, ins, numOuts, block=512):
+        """C-side streaming loop; returns (outs, seconds)."""
+        ins = _f32(ins)
+        nin, total = ins.shape
+        outs = np.zeros((numOuts, total), np.float32)
+        secs = self.L.conv_stream(self.h, _fp(ins), _fp(outs), nin, numOuts, total, block)
+        return outs, secs

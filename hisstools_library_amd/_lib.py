@@ -1,0 +1,115 @@
+"""ctypes loader for libhisstools_amd.so (the C ABI declared in include/hisstools_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C hisstools_library_amd/csrc``.
+There is no CPU fallback: if the shared object is missing this module raises ImportError, and if no
+GPU is usable every ``*_create`` returns NULL, which the wrappers turn into RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhisstools_amd.so")
+
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+vp = C.c_void_p
+usz = C.c_size_t
+uptr = C.c_size_t      # uintptr_t
+iptr = C.c_ssize_t     # intptr_t
+u32 = C.c_uint32
+
+
+class StageStats(C.Structure):
+    _fields_ = [("fft_size", u32), ("partitions", u32), ("num_ins", u32), ("num_outs", u32),
+                ("mac_launches", C.c_uint64), ("mac_hops", C.c_uint64), ("mac_ms", C.c_double),
+                ("ksplit", u32), ("out_tile", u32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/hisstools_amd.h declares
+SIGNATURES = {
+    "hcv_version": (C.c_char_p, []),
+    "hcv_device_count": (C.c_int, []),
+    "hcv_set_default_device": (C.c_int, [C.c_int]),
+    "hcv_get_default_device": (C.c_int, []),
+    "hcv_last_error": (C.c_char_p, []),
+    "hcv_rfft_f32": (C.c_int, [f32p, usz, usz, usz, C.c_uint, f32p, f32p]),
+    "hcv_rifft_f32": (C.c_int, [f32p, f32p, usz, C.c_uint, f32p]),
+    "hcv_partitioned_create": (vp, [uptr, uptr, uptr, uptr]),
+    "hcv_partitioned_destroy": (None, [vp]),
+    "hcv_partitioned_set_fft_size": (C.c_int, [vp, uptr]),
+    "hcv_partitioned_set_length": (C.c_int, [vp, uptr]),
+    "hcv_partitioned_set_offset": (None, [vp, uptr]),
+    "hcv_partitioned_set_reset_offset": (None, [vp, iptr]),
+    "hcv_partitioned_set": (C.c_int, [vp, f32p, uptr]),
+    "hcv_partitioned_reset": (None, [vp]),
+    "hcv_partitioned_process": (C.c_int, [vp, f32p, f32p, uptr]),
+    "hcv_timedomain_create": (vp, [uptr, uptr]),
+    "hcv_timedomain_destroy": (None, [vp]),
+    "hcv_timedomain_set_length": (C.c_int, [vp, uptr]),
+    "hcv_timedomain_set_offset": (None, [vp, uptr]),
+    "hcv_timedomain_set": (C.c_int, [vp, f32p, uptr]),
+    "hcv_timedomain_reset": (None, [vp]),
+    "hcv_timedomain_process": (C.c_int, [vp, f32p, f32p, uptr]),
+    "hcv_mono_create": (vp, [uptr, C.c_int]),
+    "hcv_mono_create_custom": (vp, [uptr, C.c_int, u32, u32, u32, u32, C.c_char_p, usz]),
+    "hcv_mono_destroy": (None, [vp]),
+    "hcv_mono_set_reset_offset": (None, [vp, iptr]),
+    "hcv_mono_resize": (C.c_int, [vp, uptr]),
+    "hcv_mono_set": (C.c_int, [vp, f32p, uptr, C.c_int]),
+    "hcv_mono_reset": (C.c_int, [vp]),
+    "hcv_mono_process": (C.c_int, [vp, f32p, f32p, f32p, uptr, C.c_int]),
+    "hcv_ntomono_create": (vp, [u32, uptr, C.c_int]),
+    "hcv_ntomono_destroy": (None, [vp]),
+    "hcv_ntomono_resize": (C.c_int, [vp, u32, uptr]),
+    "hcv_ntomono_set": (C.c_int, [vp, u32, f32p, uptr, C.c_int]),
+    "hcv_ntomono_reset": (C.c_int, [vp, u32]),
+    "hcv_ntomono_process": (C.c_int, [vp, C.POINTER(f32p), f32p, f32p, usz, usz]),
+    "hcv_convolver_create": (vp, [u32, u32, C.c_int]),
+    "hcv_convolver_create_parallel": (vp, [u32, C.c_int]),
+    "hcv_convolver_destroy": (None, [vp]),
+    "hcv_convolver_clear": (None, [vp, C.c_int]),
+    "hcv_convolver_clear_chan": (None, [vp, u32, u32, C.c_int]),
+    "hcv_convolver_reset": (None, [vp]),
+    "hcv_convolver_reset_chan": (C.c_int, [vp, u32, u32]),
+    "hcv_convolver_resize": (C.c_int, [vp, u32, u32, uptr]),
+    "hcv_convolver_set_f32": (C.c_int, [vp, u32, u32, f32p, uptr, C.c_int]),
+    "hcv_convolver_set_f64": (C.c_int, [vp, u32, u32, f64p, uptr, C.c_int]),
+    "hcv_convolver_process_f32": (C.c_int, [vp, C.POINTER(f32p), C.POINTER(f32p), usz, usz, usz]),
+    "hcv_convolver_process_f64": (C.c_int, [vp, C.POINTER(f64p), C.POINTER(f64p), usz, usz, usz]),
+    "hcv_convolver_create_on": (vp, [u32, u32, C.c_int, C.c_int, u32]),
+    "hcv_convolver_create_custom": (vp, [u32, u32, C.c_int, uptr, C.c_int, u32, u32, u32, u32, C.c_int, u32]),
+    "hcv_convolver_set_f32_dev": (C.c_int, [vp, u32, u32, vp, uptr, C.c_int]),
+    "hcv_convolver_process_f32_dev": (C.c_int, [vp, vp, usz, vp, usz, usz, usz, usz, C.c_int]),
+    "hcv_convolver_synchronize": (C.c_int, [vp]),
+    "hcv_convolver_device": (C.c_int, [vp]),
+    "hcv_convolver_set_profiling": (None, [vp, C.c_int]),
+    "hcv_convolver_num_stages": (C.c_int, [vp]),
+    "hcv_convolver_stage_stats": (C.c_int, [vp, C.c_int, C.POINTER(StageStats)]),
+    "hcv_convolver_clear_stats": (None, [vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol.  Raises ImportError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C hisstools_library_amd/csrc).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().hcv_last_error() or b"").decode()

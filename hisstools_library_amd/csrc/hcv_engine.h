@@ -1,0 +1,149 @@
+// Device-resident N x M multi-stage convolution engine (internal).
+//
+// One Engine replaces a whole tree of reference objects:
+//     Convolver -> NToMonoConvolve[out] -> MonoConvolve[in] -> {TimeDomainConvolve, PartitionedConvolve x <=4}
+// (Convolver.cpp:17-18, NToMonoConvolve.cpp:7-8, MonoConvolve.cpp:235-252).  Where the reference keeps one
+// input-spectrum ring, one forward FFT and one inverse FFT PER (in,out) PAIR PER STAGE, the engine keeps one
+// input ring and one forward FFT per INPUT and one inverse FFT per OUTPUT per stage, and accumulates over
+// inputs and partitions in the frequency domain.
+//
+// HBM layout per FFT stage s (N = fft size, M = N/2 bins, float2 = interleaved complex bin):
+//     Hs [nout][nin_alloc][Pcap][M] float2      IR partition spectra, bin-contiguous (streamed by spectral_mac)
+//     X  [nin][R][M]               float2      ring of the last R input spectra per input (R >= Pcap + Tmax)
+//     Y  [ksplit][T][nout][M]      float2      split-K partial sums of one process call
+//     hv [nout][nin_alloc]         int64       first hop each pair may see (per-pair reset)
+// plus per engine:
+//     hist     [nin][RH]  float                input history ring (overlap-save frames + FIR history)
+//     timeline [nout][OR] float                output timeline ring; every stage ADDS its hop results at their
+//                                              emission time, emit() reads and clears the current block
+//     taps     [nout][nin_alloc][2048] float   time-domain head taps, zero padded
+#pragma once
+
+#include "hcv_kernels.h"
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace hcv
+{
+    struct StageCfg
+    {
+        uint32_t fft_size = 0;      // power of two, 2^5 .. 2^20
+        uint64_t offset = 0;        // first IR sample of this stage's segment
+        uint64_t length = 0;        // segment length limit, 0 = "to the end of the IR"
+        uint64_t capacity = 0;      // IR samples this stage can hold (rounded up to a multiple of fft_size/2)
+    };
+
+    struct EngineCfg
+    {
+        uint32_t nin = 1, nout = 1;
+        bool diag = false;          // parallel mode: output o is fed by input o only (Convolver.cpp:24-41)
+        bool has_td = false;
+        uint64_t td_offset = 0, td_length = 0;   // td_length 0 = up to 2044 taps (TimeDomainConvolve.cpp:62-87)
+        std::vector<StageCfg> stages;
+        int device = -1;            // -1 = current default (HCV_DEVICE env or 0)
+        uint32_t max_block = 0;     // 0 = default (HCV_MAX_BLOCK env or 32768)
+    };
+
+    struct StageStats
+    {
+        uint32_t fft_size, partitions, nin, nout;
+        uint64_t mac_launches, mac_hops;
+        double mac_ms;              // summed HIP-event time of this stage's spectral_mac launches (profiling on)
+        uint32_t ksplit, out_tile;
+    };
+
+    class Engine
+    {
+    public:
+        static Engine *create(const EngineCfg &cfg, std::string *err);
+        ~Engine();
+
+        uint32_t nin() const { return mCfg.nin; }
+        uint32_t nout() const { return mCfg.nout; }
+        bool diag() const { return mCfg.diag; }
+        size_t num_stages() const { return mStages.size(); }
+        uint64_t stage_capacity(size_t s) const;
+        uint32_t stage_partitions(size_t s, uint32_t in, uint32_t out) const;
+        uint32_t td_taps(uint32_t in, uint32_t out) const;
+
+        // change the IR window a stage / the head takes at the NEXT set_ir (PartitionedConvolve::setOffset/setLength)
+        void set_stage_window(size_t s, uint64_t offset, uint64_t length);
+        void set_td_window(uint64_t offset, uint64_t length);
+
+        // grow the (last) stage so it can hold `capacity` IR samples; false on allocation failure
+        bool ensure_stage_capacity(size_t s, uint64_t capacity);
+
+        // load / clear one pair's IR in every stage (ir == nullptr or len == 0 clears).  Blocks until the device has
+        // consumed `ir`.  device_ptr: ir is device memory on this engine's GPU.
+        bool set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bool device_ptr);
+
+        void reset_pair(uint32_t in, uint32_t out);     // consumed at the next process (MonoConvolve.cpp:148-152,185-193)
+        void reset_all();
+
+        // host-pointer streaming call.  outs[o] is overwritten (accumulate=false) or added to.
+        bool process(const float *const *ins, float *const *outs, uint32_t nin_act, uint32_t nout_act, uint64_t n, bool accumulate);
+        // device-resident call: ins/outs are [rows][stride] float on this GPU.  Asynchronous unless sync=true.
+        bool process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
+                         bool sync);
+        bool synchronize();
+
+        void set_profiling(bool on);
+        bool stage_stats(size_t s, StageStats *out);
+        void clear_stats();
+
+        const std::string &last_error() const { return mErr; }
+        int device() const { return mDevice; }
+        uint32_t max_block() const { return mMaxBlock; }
+
+    private:
+        struct Stage;
+        struct EventPair;
+        Engine() = default;
+        bool init(const EngineCfg &cfg);
+        bool fail(const char *what, hipError_t e);
+        bool alloc_stage(Stage &st);
+        void free_stage(Stage &st);
+        bool global_reset();
+        bool apply_pending_resets();
+        bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
+        size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }
+        void collect_events();
+
+        EngineCfg mCfg;
+        int mDevice = 0;
+        uint32_t mMaxBlock = 0, mNinAlloc = 1;
+        std::vector<Stage *> mStages;
+        std::mutex mMutex;          // host-side engine state + enqueue order
+        std::mutex mSetMutex;       // serialises set_ir (shared IR staging buffer)
+        std::string mErr;
+
+        hipStream_t mStream = nullptr, mTdStream = nullptr;
+        hipEvent_t mEvInput = nullptr, mEvTd = nullptr;
+
+        // rings and staging
+        float *mHist = nullptr;     long long mHistLen = 0;
+        float *mTimeline = nullptr; long long mTlLen = 0;
+        float *mTdOut = nullptr;
+        float *mDevIn = nullptr, *mDevOut = nullptr;
+        float *mPinIn = nullptr, *mPinOut = nullptr;
+        float *mIrBuf = nullptr;    uint64_t mIrCap = 0;
+
+        // time-domain head
+        float *mTaps = nullptr;
+        long long *mTdValid = nullptr;
+        std::vector<uint32_t> mTdCount;     // taps per pair
+        uint32_t mTdLpad = 0;
+        long long mTdMaxValid = 0;
+
+        // per pair
+        std::vector<uint8_t> mPending, mLoaded;
+        long long mN = 0;                   // samples since the last global reset
+        bool mProfiling = false;
+        std::vector<EventPair *> mEvents;
+    };
+
+    const float2 *twiddles(int device, int log2n, std::string *err);   // cached per (device, size)
+}

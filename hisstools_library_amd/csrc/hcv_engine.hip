@@ -1,0 +1,703 @@
+// Device-resident N x M multi-stage convolution engine: host-side orchestration of the gfx950 kernels.
+// See hcv_engine.h for the HBM layout.
+
+#include "hcv_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+namespace hcv
+{
+
+#define HCV_TRY(expr)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return fail(#expr, e_);                                                                  \
+    } while (0)
+
+static long long pow2ceil(long long v)
+{
+    long long p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static int ilog2(uint64_t v)
+{
+    int l = 0;
+    while ((uint64_t(1) << l) < v) l++;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// twiddle tables: N-th roots of unity exp(-2 pi i m / N), m < N/2, computed in double and rounded once
+// (the reference builds its tables the same way, HISSTools_FFT_Core.h:414-448); one table per (device, N)
+// shared by every engine instead of one setup per PartitionedConvolve (PartitionedConvolve.cpp:101).
+// ------------------------------------------------------------------------------------------------
+
+static std::mutex gTwMutex;
+static std::map<std::pair<int, int>, float2 *> gTwTables;
+
+const float2 *twiddles(int device, int log2n, std::string *err)
+{
+    std::lock_guard<std::mutex> g(gTwMutex);
+    auto key = std::make_pair(device, log2n);
+    auto it = gTwTables.find(key);
+    if (it != gTwTables.end()) return it->second;
+
+    const size_t half = size_t(1) << (log2n - 1);
+    std::vector<float2> host(half);
+    const double pi = 3.14159265358979323846264338327950288;
+    for (size_t m = 0; m < half; m++)
+    {
+        double angle = -(double) m * pi / (double) half;
+        host[m] = make_float2((float) std::cos(angle), (float) std::sin(angle));
+    }
+    float2 *dev = nullptr;
+    hipError_t e = hipMalloc(&dev, half * sizeof(float2));
+    if (e == hipSuccess) e = hipMemcpy(dev, host.data(), half * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        if (err) *err = std::string("twiddle table upload failed: ") + hipGetErrorString(e);
+        if (dev) (void) hipFree(dev);
+        return nullptr;
+    }
+    gTwTables[key] = dev;
+    return dev;
+}
+
+// ------------------------------------------------------------------------------------------------
+
+struct Engine::Stage
+{
+    StageCfg cfg;
+    int log2n = 0;
+    uint32_t N = 0, M = 0;
+    uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
+    float2 *Hs = nullptr, *X = nullptr, *Y = nullptr;
+    size_t y_elems = 0;
+    long long *hv = nullptr;
+    long long max_hv = 0;
+    std::vector<uint32_t> pact;
+    const float2 *tw = nullptr;
+    // stats
+    uint64_t launches = 0, hops = 0;
+    double ms = 0.0;
+    uint32_t last_ksplit = 0, last_ot = 0;
+};
+
+struct Engine::EventPair
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    size_t stage = 0;
+    bool live = false;
+};
+
+bool Engine::fail(const char *what, hipError_t e)
+{
+    mErr = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+Engine *Engine::create(const EngineCfg &cfg, std::string *err)
+{
+    Engine *e = new Engine();
+    if (!e->init(cfg))
+    {
+        if (err) *err = e->mErr;
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+
+bool Engine::init(const EngineCfg &cfg)
+{
+    mCfg = cfg;
+    if (mCfg.nin < 1) mCfg.nin = 1;
+    if (mCfg.nout < 1)
+    {
+        mErr = "engine needs at least one output";
+        return false;
+    }
+    if (mCfg.diag) mCfg.nin = mCfg.nout;
+    mNinAlloc = mCfg.diag ? 1 : mCfg.nin;
+
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+    {
+        mErr = "no HIP device available (the convolution engine has no CPU fallback)";
+        if (e != hipSuccess) mErr += std::string(": ") + hipGetErrorString(e);
+        return false;
+    }
+    if (cfg.device >= 0)
+        mDevice = cfg.device;
+    else if (const char *env = std::getenv("HCV_DEVICE"))
+        mDevice = std::atoi(env);
+    else
+        HCV_TRY(hipGetDevice(&mDevice));
+    if (mDevice < 0 || mDevice >= count)
+    {
+        mErr = "HIP device index out of range";
+        return false;
+    }
+    HCV_TRY(hipSetDevice(mDevice));
+
+    mMaxBlock = cfg.max_block;
+    if (!mMaxBlock)
+    {
+        const char *env = std::getenv("HCV_MAX_BLOCK");
+        mMaxBlock = env ? (uint32_t) std::atoi(env) : 32768u;
+    }
+    if (mMaxBlock < 16) mMaxBlock = 16;
+
+    uint32_t nmax = 0;
+    for (const StageCfg &sc : mCfg.stages)
+    {
+        int l2 = ilog2(sc.fft_size);
+        if ((uint64_t(1) << l2) != sc.fft_size || l2 < kMinFFTLog2 || l2 > kMaxFFTLog2)
+        {
+            mErr = "invalid FFT size";
+            return false;
+        }
+        if (l2 > kMaxLdsFFTLog2)
+        {
+            mErr = "FFT sizes above 32768 are not supported by this build";
+            return false;
+        }
+        nmax = std::max(nmax, sc.fft_size);
+    }
+
+    HCV_TRY(hipStreamCreateWithFlags(&mStream, hipStreamNonBlocking));
+    HCV_TRY(hipStreamCreateWithFlags(&mTdStream, hipStreamNonBlocking));
+    HCV_TRY(hipEventCreateWithFlags(&mEvInput, hipEventDisableTiming));
+    HCV_TRY(hipEventCreateWithFlags(&mEvTd, hipEventDisableTiming));
+
+    mHistLen = pow2ceil((long long) mMaxBlock + std::max<long long>(nmax, 4096));
+    mTlLen = pow2ceil((long long) mMaxBlock + std::max<long long>(nmax / 2, 16));
+    const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
+
+    HCV_TRY(hipMalloc(&mHist, sizeof(float) * mCfg.nin * mHistLen));
+    HCV_TRY(hipMemset(mHist, 0, sizeof(float) * mCfg.nin * mHistLen));
+    HCV_TRY(hipMalloc(&mTimeline, sizeof(float) * mCfg.nout * mTlLen));
+    HCV_TRY(hipMemset(mTimeline, 0, sizeof(float) * mCfg.nout * mTlLen));
+    HCV_TRY(hipMalloc(&mDevIn, sizeof(float) * mCfg.nin * mMaxBlock));
+    HCV_TRY(hipMalloc(&mDevOut, sizeof(float) * mCfg.nout * mMaxBlock));
+    HCV_TRY(hipHostMalloc(&mPinIn, sizeof(float) * mCfg.nin * mMaxBlock, hipHostMallocDefault));
+    HCV_TRY(hipHostMalloc(&mPinOut, sizeof(float) * mCfg.nout * mMaxBlock, hipHostMallocDefault));
+    if (mCfg.has_td)
+    {
+        HCV_TRY(hipMalloc(&mTdOut, sizeof(float) * mCfg.nout * mMaxBlock));
+        HCV_TRY(hipMalloc(&mTaps, sizeof(float) * pairs * 2048));
+        HCV_TRY(hipMemset(mTaps, 0, sizeof(float) * pairs * 2048));
+        HCV_TRY(hipMalloc(&mTdValid, sizeof(long long) * pairs));
+        HCV_TRY(hipMemset(mTdValid, 0, sizeof(long long) * pairs));
+        mTdCount.assign(pairs, 0);
+    }
+    mPending.assign(pairs, 0);
+    mLoaded.assign(pairs, 0);
+
+    for (const StageCfg &sc : mCfg.stages)
+    {
+        Stage *st = new Stage();
+        st->cfg = sc;
+        st->log2n = ilog2(sc.fft_size);
+        st->N = sc.fft_size;
+        st->M = sc.fft_size / 2;
+        st->pact.assign(pairs, 0);
+        mStages.push_back(st);
+        st->tw = twiddles(mDevice, st->log2n, &mErr);
+        if (!st->tw) return false;
+        if (!alloc_stage(*st)) return false;
+    }
+    HCV_TRY(hipDeviceSynchronize());
+    return true;
+}
+
+bool Engine::alloc_stage(Stage &st)
+{
+    const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
+    uint64_t cap = st.cfg.capacity ? st.cfg.capacity : st.M;
+    st.Pcap = (uint32_t) std::max<uint64_t>(1, (cap + st.M - 1) / st.M);
+    st.Tmax = mMaxBlock / st.M + 1;
+    st.R = st.Pcap + st.Tmax;
+    const size_t hs_elems = pairs * st.Pcap * st.M;
+    const size_t x_elems = (size_t) mCfg.nin * st.R * st.M;
+    st.y_elems = (size_t) std::max<uint32_t>(st.Tmax, 64u) * mCfg.nout * st.M;
+    HCV_TRY(hipMalloc(&st.Hs, sizeof(float2) * hs_elems));
+    HCV_TRY(hipMemset(st.Hs, 0, sizeof(float2) * hs_elems));
+    HCV_TRY(hipMalloc(&st.X, sizeof(float2) * x_elems));
+    HCV_TRY(hipMemset(st.X, 0, sizeof(float2) * x_elems));
+    HCV_TRY(hipMalloc(&st.Y, sizeof(float2) * st.y_elems));
+    HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
+    HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
+    return true;
+}
+
+void Engine::free_stage(Stage &st)
+{
+    if (st.Hs) (void) hipFree(st.Hs);
+    if (st.X) (void) hipFree(st.X);
+    if (st.Y) (void) hipFree(st.Y);
+    if (st.hv) (void) hipFree(st.hv);
+    st.Hs = st.X = st.Y = nullptr;
+    st.hv = nullptr;
+}
+
+Engine::~Engine()
+{
+    (void) hipSetDevice(mDevice);
+    if (mStream) (void) hipStreamSynchronize(mStream);
+    if (mTdStream) (void) hipStreamSynchronize(mTdStream);
+    for (Stage *st : mStages)
+    {
+        free_stage(*st);
+        delete st;
+    }
+    for (EventPair *ev : mEvents)
+    {
+        if (ev->a) (void) hipEventDestroy(ev->a);
+        if (ev->b) (void) hipEventDestroy(ev->b);
+        delete ev;
+    }
+    if (mHist) (void) hipFree(mHist);
+    if (mTimeline) (void) hipFree(mTimeline);
+    if (mTdOut) (void) hipFree(mTdOut);
+    if (mDevIn) (void) hipFree(mDevIn);
+    if (mDevOut) (void) hipFree(mDevOut);
+    if (mPinIn) (void) hipHostFree(mPinIn);
+    if (mPinOut) (void) hipHostFree(mPinOut);
+    if (mIrBuf) (void) hipFree(mIrBuf);
+    if (mTaps) (void) hipFree(mTaps);
+    if (mTdValid) (void) hipFree(mTdValid);
+    if (mEvInput) (void) hipEventDestroy(mEvInput);
+    if (mEvTd) (void) hipEventDestroy(mEvTd);
+    if (mStream) (void) hipStreamDestroy(mStream);
+    if (mTdStream) (void) hipStreamDestroy(mTdStream);
+}
+
+uint64_t Engine::stage_capacity(size_t s) const
+{
+    return s < mStages.size() ? (uint64_t) mStages[s]->Pcap * mStages[s]->M : 0;
+}
+
+uint32_t Engine::stage_partitions(size_t s, uint32_t in, uint32_t out) const
+{
+    if (s >= mStages.size() || out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return 0;
+    return mStages[s]->pact[pair_index(in, out)];
+}
+
+uint32_t Engine::td_taps(uint32_t in, uint32_t out) const
+{
+    if (!mCfg.has_td || out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return 0;
+    return mTdCount[pair_index(in, out)];
+}
+
+void Engine::set_stage_window(size_t s, uint64_t offset, uint64_t length)
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    if (s < mStages.size())
+    {
+        mStages[s]->cfg.offset = offset;
+        mStages[s]->cfg.length = length;
+    }
+}
+
+void Engine::set_td_window(uint64_t offset, uint64_t length)
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    mCfg.td_offset = offset;
+    mCfg.td_length = length;
+}
+
+// Capacity growth of a stage (MonoConvolve::resize / set(..., requestResize) reallocate the tail partition,
+// MonoConvolve.cpp:101-110,123; here all pairs of a stage share one allocation, so growing re-strides it).
+bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    if (s >= mStages.size()) return false;
+    (void) hipSetDevice(mDevice);
+    Stage &st = *mStages[s];
+    const uint32_t newP = (uint32_t) std::max<uint64_t>(1, (capacity + st.M - 1) / st.M);
+    if (newP <= st.Pcap) return true;
+
+    const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
+    const uint32_t newR = newP + st.Tmax;
+    float2 *nHs = nullptr, *nX = nullptr;
+    const size_t hs_bytes = sizeof(float2) * pairs * newP * st.M;
+    const size_t x_bytes = sizeof(float2) * (size_t) mCfg.nin * newR * st.M;
+    if (hipMalloc(&nHs, hs_bytes) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        return false;
+    }
+    if (hipMalloc(&nX, x_bytes) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        (void) hipFree(nHs);
+        return false;
+    }
+    bool ok = hipMemsetAsync(nHs, 0, hs_bytes, mStream) == hipSuccess && hipMemsetAsync(nX, 0, x_bytes, mStream) == hipSuccess;
+    if (ok && st.P > 0)
+    {
+        ok = launch_regrow_spectra(st.Hs, nHs, (long long) pairs, (int) st.Pcap, (int) newP, (int) st.M, mStream) == hipSuccess;
+        const long long h_done = mN / st.M;                // hops completed so far: indices 0 .. h_done-1
+        const int live = (int) std::min<long long>(st.P, h_done);
+        if (ok && live > 0)
+            ok = launch_regrow_ring(st.X, nX, (int) mCfg.nin, (int) st.R, (int) newR, (int) st.M, h_done - 1, live, mStream) == hipSuccess;
+    }
+    ok = ok && hipStreamSynchronize(mStream) == hipSuccess;
+    if (!ok)
+    {
+        (void) hipFree(nHs);
+        (void) hipFree(nX);
+        mErr = "stage regrow failed";
+        return false;
+    }
+    (void) hipFree(st.Hs);
+    (void) hipFree(st.X);
+    st.Hs = nHs;
+    st.X = nX;
+    st.Pcap = newP;
+    st.R = newR;
+    return true;
+}
+
+bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bool device_ptr)
+{
+    if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return false;
+    std::lock_guard<std::mutex> gs(mSetMutex);
+    HCV_TRY(hipSetDevice(mDevice));
+    if (!ir) len = 0;
+
+    const float *dsrc = nullptr;
+    if (len)
+    {
+        if (device_ptr)
+            dsrc = ir;
+        else
+        {
+            if (len > mIrCap)
+            {
+                HCV_TRY(hipStreamSynchronize(mStream));
+                if (mIrBuf) (void) hipFree(mIrBuf);
+                mIrBuf = nullptr;
+                mIrCap = 0;
+                uint64_t want = std::max<uint64_t>(len, 65536);
+                HCV_TRY(hipMalloc(&mIrBuf, sizeof(float) * want));
+                mIrCap = want;
+            }
+            dsrc = mIrBuf;
+        }
+    }
+
+    {
+        std::lock_guard<std::mutex> g(mMutex);
+        if (len && !device_ptr) HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mStream));
+        const size_t pair = pair_index(in, out);
+        bool any = false;
+        for (Stage *sp : mStages)
+        {
+            Stage &st = *sp;
+            uint64_t seg = len > st.cfg.offset ? len - st.cfg.offset : 0;          // PartitionedConvolve.cpp:192-193
+            if (st.cfg.length && st.cfg.length < seg) seg = st.cfg.length;
+            const uint64_t cap = (uint64_t) st.Pcap * st.M;
+            if (seg > cap) seg = cap;                                               // :195-199 (caller reports the error)
+            const uint32_t newP = (uint32_t) ((seg + st.M - 1) / st.M);
+            const uint32_t oldP = st.pact[pair];
+            const uint32_t wr = std::max(newP, oldP);
+            if (wr)
+            {
+                const float *src = seg ? dsrc + st.cfg.offset : mHist;              // never dereferenced when seg == 0
+                HCV_TRY(launch_rfft_ir(st.log2n, src, (long long) seg, (int) wr, st.Hs + pair * (size_t) st.Pcap * st.M, st.tw, mStream));
+            }
+            st.pact[pair] = newP;
+            st.P = *std::max_element(st.pact.begin(), st.pact.end());
+            any = any || newP;
+        }
+        if (mCfg.has_td)
+        {
+            const uint64_t lim = mCfg.td_length ? mCfg.td_length : 2044;            // TimeDomainConvolve.cpp:77
+            uint64_t taps = len > mCfg.td_offset ? std::min<uint64_t>(len - mCfg.td_offset, lim) : 0;
+            if (taps > 2044) taps = 2044;
+            float *dst = mTaps + pair * 2048;
+            if (taps) HCV_TRY(hipMemcpyAsync(dst, dsrc + mCfg.td_offset, sizeof(float) * taps, hipMemcpyDeviceToDevice, mStream));
+            HCV_TRY(hipMemsetAsync(dst + taps, 0, sizeof(float) * (2048 - taps), mStream));
+            mTdCount[pair] = (uint32_t) taps;
+            uint32_t mx = *std::max_element(mTdCount.begin(), mTdCount.end());
+            mTdLpad = ((mx + 15) / 16) * 16;
+            any = any || taps;
+        }
+        mLoaded[pair] = any ? 1 : 0;
+        mPending[pair] = 1;                                                         // set() always ends in reset()
+    }
+    HCV_TRY(hipStreamSynchronize(mStream));
+    return true;
+}
+
+void Engine::reset_pair(uint32_t in, uint32_t out)
+{
+    if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return;
+    std::lock_guard<std::mutex> g(mMutex);
+    mPending[pair_index(in, out)] = 1;
+}
+
+void Engine::reset_all()
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    std::fill(mPending.begin(), mPending.end(), 1);
+}
+
+// Every loaded pair restarts: clear the rings and restart the hop clock.  The input-spectrum rings are not
+// cleared — like the reference (PartitionedConvolve.cpp:271 clears only the frame/accum buffers) stale slots are
+// fenced off by the valid-partition bound instead (mValidPartitions there, h - hv here).
+bool Engine::global_reset()
+{
+    mN = 0;
+    HCV_TRY(hipMemsetAsync(mHist, 0, sizeof(float) * mCfg.nin * mHistLen, mStream));
+    HCV_TRY(hipMemsetAsync(mTimeline, 0, sizeof(float) * mCfg.nout * mTlLen, mStream));
+    const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
+    for (Stage *st : mStages)
+    {
+        HCV_TRY(hipMemsetAsync(st->hv, 0, sizeof(long long) * pairs, mStream));
+        st->max_hv = 0;
+    }
+    if (mTdValid) HCV_TRY(hipMemsetAsync(mTdValid, 0, sizeof(long long) * pairs, mStream));
+    mTdMaxValid = 0;
+    return true;
+}
+
+bool Engine::apply_pending_resets()
+{
+    bool any = false, all = true;
+    for (size_t p = 0; p < mPending.size(); p++)
+    {
+        any = any || mPending[p];
+        if (mLoaded[p] && !mPending[p]) all = false;
+    }
+    if (!any) return true;
+    if (all)
+    {
+        if (!global_reset()) return false;
+    }
+    else
+    {
+        // A single pair restarts while others keep running.  The pair must ignore input older than "now"; with one
+        // shared input ring per input this is enforced at hop granularity for the FFT stages (the hop in progress is
+        // still visible to the pair) and exactly for the time-domain head.  See DESIGN.md "per-pair reset".
+        for (size_t p = 0; p < mPending.size(); p++)
+        {
+            if (!mPending[p]) continue;
+            for (Stage *st : mStages)
+            {
+                const long long hvv = mN / st->M;
+                HCV_TRY(launch_fill_i64(st->hv + p, 1, hvv, mStream));
+                st->max_hv = std::max(st->max_hv, hvv);
+            }
+            if (mTdValid)
+            {
+                HCV_TRY(launch_fill_i64(mTdValid + p, 1, mN, mStream));
+                mTdMaxValid = std::max(mTdMaxValid, mN);
+            }
+        }
+    }
+    std::fill(mPending.begin(), mPending.end(), 0);
+    return true;
+}
+
+// One block of at most max_block samples, everything device side.  Caller holds mMutex.
+bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B)
+{
+    const long long n0 = mN;
+    const long long hmask = mHistLen - 1, tmask = mTlLen - 1;
+    const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+
+    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, mStream));
+
+    const bool td = mCfg.has_td && mTdLpad > 0;
+    if (td)
+    {
+        // the short head runs on its own stream, concurrently with the (HBM-bound) FFT stages
+        HCV_TRY(hipEventRecord(mEvInput, mStream));
+        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput, 0));
+        const bool check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
+        HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
+                                n0, (int) B, mTdValid, check, mTdOut, mMaxBlock, mTdStream));
+        HCV_TRY(hipEventRecord(mEvTd, mTdStream));
+    }
+
+    bool any_stage = false;
+    for (size_t si = 0; si < mStages.size(); si++)
+    {
+        Stage &st = *mStages[si];
+        any_stage = true;                                   // the timeline may still hold earlier hops
+        if (!st.P) continue;
+        const long long h_first = n0 / st.M;
+        const int T = (int) ((n0 + B) / st.M - h_first);
+        if (T <= 0) continue;
+
+        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, mStream));
+
+        MacShape sh;
+        sh.M = (int) st.M;
+        sh.R = (int) st.R;
+        sh.P = (int) st.P;
+        sh.Pcap = (int) st.Pcap;
+        sh.nin = (int) nin_act;
+        sh.nin_alloc = (int) mNinAlloc;
+        sh.nout = (int) nout_act;
+        sh.diag = mCfg.diag ? 1 : 0;
+        sh.T = T;
+        sh.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M));
+        MacPlan pl;
+        mac_plan(sh, pl);
+        const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
+
+        EventPair *ev = nullptr;
+        if (mProfiling)
+        {
+            for (EventPair *c : mEvents)
+                if (!c->live) { ev = c; break; }
+            if (!ev)
+            {
+                ev = new EventPair();
+                HCV_TRY(hipEventCreate(&ev->a));
+                HCV_TRY(hipEventCreate(&ev->b));
+                mEvents.push_back(ev);
+            }
+            ev->stage = si;
+            ev->live = true;
+            HCV_TRY(hipEventRecord(ev->a, mStream));
+        }
+        HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, mStream));
+        if (ev) HCV_TRY(hipEventRecord(ev->b, mStream));
+        st.launches++;
+        st.hops += (uint64_t) T;
+        st.last_ksplit = (uint32_t) pl.ksplit;
+        st.last_ot = (uint32_t) pl.ot;
+
+        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, pl.ksplit, (long long) T * nout_act * st.M, h_first, T, (int) nout_act, mTimeline, mTlLen,
+                                         tmask, st.tw, mStream));
+    }
+
+    if (td) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd, 0));
+    HCV_TRY(launch_emit(mTimeline, mTlLen, tmask, n0, (int) B, (int) nout_act, td ? mTdOut : nullptr, mMaxBlock, dout, out_stride, any_stage ? 1 : 0,
+                        mStream));
+    mN += B;
+    return true;
+}
+
+bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_act, uint32_t nout_act, uint64_t n, bool accumulate)
+{
+    HCV_TRY(hipSetDevice(mDevice));
+    nout_act = std::min(nout_act, mCfg.nout);
+    nin_act = std::min(nin_act, mCfg.nin);
+    if (!nout_act || !n) return true;
+    const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+
+    for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
+    {
+        const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
+        for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i] + pos, sizeof(float) * B);
+        {
+            std::lock_guard<std::mutex> g(mMutex);
+            if (!apply_pending_resets()) return false;
+            if (rows_in) HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
+            if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
+            HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
+        }
+        HCV_TRY(hipStreamSynchronize(mStream));
+        for (uint32_t o = 0; o < nout_act; o++)
+        {
+            float *dst = outs[o] + pos;
+            const float *src = mPinOut + (size_t) o * B;
+            if (accumulate)
+                for (uint32_t j = 0; j < B; j++) dst[j] += src[j];
+            else
+                std::memcpy(dst, src, sizeof(float) * B);
+        }
+    }
+    if (mProfiling) collect_events();
+    return true;
+}
+
+bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
+                         bool sync)
+{
+    HCV_TRY(hipSetDevice(mDevice));
+    nout_act = std::min(nout_act, mCfg.nout);
+    nin_act = std::min(nin_act, mCfg.nin);
+    if (!nout_act || !n) return true;
+    {
+        std::lock_guard<std::mutex> g(mMutex);
+        if (!apply_pending_resets()) return false;
+        for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
+        {
+            const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
+            if (!enqueue_chunk(ins + pos, in_stride, outs + pos, out_stride, nin_act, nout_act, B)) return false;
+        }
+    }
+    if (sync) return synchronize();
+    return true;
+}
+
+bool Engine::synchronize()
+{
+    HCV_TRY(hipSetDevice(mDevice));
+    HCV_TRY(hipStreamSynchronize(mStream));
+    if (mProfiling) collect_events();
+    return true;
+}
+
+void Engine::set_profiling(bool on)
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    mProfiling = on;
+}
+
+void Engine::collect_events()
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    for (EventPair *ev : mEvents)
+    {
+        if (!ev->live) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev->a, ev->b) == hipSuccess && ev->stage < mStages.size()) mStages[ev->stage]->ms += ms;
+        else (void) hipGetLastError();
+        ev->live = false;
+    }
+}
+
+bool Engine::stage_stats(size_t s, StageStats *out)
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    if (s >= mStages.size() || !out) return false;
+    const Stage &st = *mStages[s];
+    out->fft_size = st.N;
+    out->partitions = st.P;
+    out->nin = mCfg.diag ? 1 : mCfg.nin;
+    out->nout = mCfg.nout;
+    out->mac_launches = st.launches;
+    out->mac_hops = st.hops;
+    out->mac_ms = st.ms;
+    out->ksplit = st.last_ksplit;
+    out->out_tile = st.last_ot;
+    return true;
+}
+
+void Engine::clear_stats()
+{
+    std::lock_guard<std::mutex> g(mMutex);
+    for (Stage *st : mStages)
+    {
+        st->launches = st->hops = 0;
+        st->ms = 0.0;
+    }
+}
+
+} // namespace hcv

@@ -1,0 +1,56 @@
+// Launch interface of the gfx950 kernels (hcv_kernels.hip).  Internal to the library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace hcv
+{
+    constexpr int kMinFFTLog2 = 5;        // PartitionedConvolve.h:18
+    constexpr int kMaxFFTLog2 = 20;       // PartitionedConvolve.h:19
+    constexpr int kMaxLdsFFTLog2 = 15;    // N = 32768 -> 16384 complex points = 128 KiB of the CU's 160 KiB LDS
+
+    // ---- FFT family (tw = N-th roots of unity, N/2 entries) ----
+    hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin,
+                                  float2 *X, int R, const float2 *tw, hipStream_t st);
+    hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, hipStream_t st);
+    hipError_t launch_rfft_rows(int log2n, const float *src, long long src_stride, long long in_len, int batch, float2 *dst, const float2 *tw,
+                                hipStream_t st);
+    hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, hipStream_t st);
+    hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long long ks_stride, long long h_first, int T, int nout,
+                                        float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, hipStream_t st);
+
+    // ---- spectral multiply-accumulate ----
+    struct MacShape
+    {
+        int M;              // bins per spectrum (= N/2)
+        int R;              // input-spectrum ring slots
+        int P, Pcap;        // live partitions, allocated partitions per pair
+        int nin, nin_alloc; // live inputs, allocated inputs per output row
+        int nout;           // live outputs
+        int diag;           // parallel (diagonal) mode
+        int T;              // hops in this launch
+        int max_ksplit;     // 0 = unlimited (bounded by the Y partial buffer)
+    };
+    struct MacPlan
+    {
+        int ot, bx, by, binblocks, outtiles, ksplit, kper;
+    };
+    int mac_out_tile(int nout, int diag);
+    void mac_plan(const MacShape &s, MacPlan &pl);
+    hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
+                                   long long h_first, bool check, hipStream_t st);
+
+    // ---- time-domain head ----
+    hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
+                               int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
+                               long long out_stride, hipStream_t st);
+
+    // ---- ring bookkeeping ----
+    hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,
+                                    long long n0, hipStream_t st);
+    hipError_t launch_emit(float *timeline, long long tl_stride, long long tl_mask, long long n0, int B, int nout, const float *td,
+                           long long td_stride, float *out, long long out_stride, int use_timeline, hipStream_t st);
+    hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st);
+    hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st);
+    hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st);
+}

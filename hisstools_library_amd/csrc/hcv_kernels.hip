@@ -1,0 +1,975 @@
+// MI355X (gfx950 / CDNA4) kernels for the partitioned-convolution hot path.
+//
+//   K2/K9  rfft_frames / rfft_ir      real -> packed half spectrum, LDS Stockham, x2 scale
+//   K1     spectral_mac               Y[t][o] = sum_i sum_p X[i][h-p] * H[o][i][p]   (the HBM roofline kernel)
+//   K3/K4  rifft_overlap_add          packed spectrum -> time, 1/(4N) scale, valid half added to the output timeline
+//   K5     fir_head                   direct-form FIR head (time-domain stage)
+//   K7     scatter_input / emit       ring bookkeeping on device
+//
+// Spectrum format (identical to the reference's vDSP-compatible packing, HISSTools_FFT_Core.h:934-988,
+// but stored INTERLEAVED as float2 per bin so one dwordx4 load carries two bins):
+//   bin 0      = (2*X[0], 2*X[N/2])          DC and Nyquist packed
+//   bin k>0    = (2*Re X[k], 2*Im X[k])      k < N/2
+//
+// Everything here is written for wave64 / gfx950 only.
+
+#include "hcv_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+namespace hcv
+{
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// tw holds the N-th roots of unity exp(-2*pi*i*m/N) for m in [0, N/2); the second half of the circle
+// is the negated first half.
+template <int LOG2M>
+__device__ __forceinline__ float2 root(const float2 *__restrict__ tw, int m)
+{
+    constexpr int M = 1 << LOG2M;                    // N/2 table entries
+    float2 w = tw[m & (M - 1)];
+    return (m & M) ? make_float2(-w.x, -w.y) : w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-LDS complex FFT of M = 2^LOG2M points, forward sign, unnormalised, natural order in and out.
+// Stockham autosort, radix-4 passes plus one radix-2 pass when LOG2M is odd.  TG threads cooperate on one
+// transform; every pass is "read my butterflies into registers / barrier / write results / barrier", so a
+// single M-point LDS buffer suffices (64 KiB at N = 16384).
+// ------------------------------------------------------------------------------------------------
+
+template <int LOG2M, int TG>
+struct LdsFFT
+{
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int NB4 = M / 4;
+    static constexpr int BPT4 = (NB4 + TG - 1) / TG;
+    static constexpr int NB2 = M / 2;
+    static constexpr int BPT2 = (NB2 + TG - 1) / TG;
+
+    __device__ static __forceinline__ void run(float2 *s, int tid, const float2 *__restrict__ tw)
+    {
+        int p = 1;
+#pragma unroll 1
+        for (int pass = 0; pass < LOG2M / 2; pass++, p <<= 2)
+        {
+            float2 u[BPT4][4];
+#pragma unroll
+            for (int b = 0; b < BPT4; b++)
+            {
+                int i = tid + b * TG;
+                if (NB4 % TG == 0 || i < NB4)
+                {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) u[b][r] = s[i + r * NB4];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < BPT4; b++)
+            {
+                int i = tid + b * TG;
+                if (NB4 % TG == 0 || i < NB4)
+                {
+                    int k = i & (p - 1);
+                    int j = ((i - k) << 2) + k;
+                    // twiddle exp(-2 pi i k r / (4p)) = root(k * r * (2M / 4p))
+                    int step = k * ((2 * M) / (4 * p));
+                    float2 u0 = u[b][0];
+                    float2 u1 = cmul(u[b][1], root<LOG2M>(tw, step));
+                    float2 u2 = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
+                    float2 u3 = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
+                    float2 a = make_float2(u0.x + u2.x, u0.y + u2.y);
+                    float2 c = make_float2(u0.x - u2.x, u0.y - u2.y);
+                    float2 e = make_float2(u1.x + u3.x, u1.y + u3.y);
+                    float2 d = make_float2(u1.y - u3.y, u3.x - u1.x);     // -i * (u1 - u3)
+                    s[j] = make_float2(a.x + e.x, a.y + e.y);
+                    s[j + p] = make_float2(c.x + d.x, c.y + d.y);
+                    s[j + 2 * p] = make_float2(a.x - e.x, a.y - e.y);
+                    s[j + 3 * p] = make_float2(c.x - d.x, c.y - d.y);
+                }
+            }
+            __syncthreads();
+        }
+        if (LOG2M & 1)
+        {
+            float2 u[BPT2][2];
+#pragma unroll
+            for (int b = 0; b < BPT2; b++)
+            {
+                int i = tid + b * TG;
+                if (NB2 % TG == 0 || i < NB2)
+                {
+                    u[b][0] = s[i];
+                    u[b][1] = s[i + NB2];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < BPT2; b++)
+            {
+                int i = tid + b * TG;
+                if (NB2 % TG == 0 || i < NB2)
+                {
+                    int k = i & (p - 1);
+                    int j = ((i - k) << 1) + k;
+                    float2 u0 = u[b][0];
+                    float2 u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
+                    s[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+                    s[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+                }
+            }
+            __syncthreads();
+        }
+    }
+};
+
+// threads cooperating on one transform and transforms per 256-thread workgroup
+template <int LOG2M> struct FFTGeom
+{
+    static constexpr int M = 1 << LOG2M;
+    static constexpr int TG = (M / 4) < 256 ? (M / 4) : 256;
+    static constexpr int G = 256 / TG;
+    static constexpr int THREADS = TG * G;
+};
+
+// Real post-pass of the forward transform (the maths of pass_real_trig_table<false>,
+// HISSTools_FFT_Core.h:934-988): s holds Z = FFT_M(x_even + i x_odd); writes the packed, doubled half
+// spectrum to dst[0..M).
+template <int LOG2M, int TG>
+__device__ __forceinline__ void real_post_store(const float2 *s, int tid, const float2 *__restrict__ tw, float2 *__restrict__ dst)
+{
+    constexpr int M = 1 << LOG2M;
+    for (int k = tid; k <= M / 2; k += TG)
+    {
+        if (k == 0)
+        {
+            float2 z = s[0];
+            float t1 = z.x + z.y, t2 = z.x - z.y;
+            dst[0] = make_float2(t1 + t1, t2 + t2);
+        }
+        else
+        {
+            int m = M - k;
+            float2 w = tw[k];                            // exp(-i pi k / M)
+            float2 z1 = s[k], z2 = s[m];
+            float r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+            float u1 = (w.x * i3) + (w.y * r4);
+            float u2 = (w.y * i3) - (w.x * r4);
+            dst[k] = make_float2(r3 + u1, u2 + i4);
+            dst[m] = make_float2(r3 - u1, u2 - i4);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: forward real FFT of overlap-save frames straight out of the input history ring.
+//   transform q = (t, i): frame = hist[i][(h-1)*H .. (h+1)*H), h = h_first + t   (natural [older | newer] order:
+//   the valid half of the matching inverse is the SECOND one).
+//   out: X[(i * R + (h mod R)) * M + k]
+// ------------------------------------------------------------------------------------------------
+
+template <int LOG2M>
+__global__ __launch_bounds__(256) void rfft_frames_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
+                                                          long long h_first, int T, int nin, float2 *__restrict__ X, int R,
+                                                          const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int q = blockIdx.x * G + g;
+    const bool live = q < T * nin;
+    const int t = live ? q / nin : 0, i = live ? q % nin : 0;
+    const long long h = h_first + t;
+    float2 *s = lds + g * M;
+
+    const float *row = hist + (long long) i * hist_stride;
+    const long long base = (h - 1) * (long long) M;      // hop = M samples, frame = 2M samples = M float2
+    for (int k = tid; k < M; k += TG)
+    {
+        long long pos = (base + 2LL * k) & hist_mask;     // even, so the float2 never straddles the wrap
+        s[k] = *reinterpret_cast<const float2 *>(row + pos);
+    }
+    __syncthreads();
+    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    if (live)
+    {
+        int slot = (int) (h % R);
+        real_post_store<LOG2M, TG>(s, tid, tw, X + ((long long) i * R + slot) * M);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: IR partition FFT.  Partition p of one (in,out) pair: ir[p*M .. p*M + M) zero-padded to 2M samples.
+//   src points at the first sample of the stage's IR segment, `count` samples are valid.
+//   dst = H spectra of that pair, [P][M] float2.  Partitions past the IR are written as zeros.
+// ------------------------------------------------------------------------------------------------
+
+template <int LOG2M>
+__global__ __launch_bounds__(256) void rfft_ir_kernel(const float *__restrict__ src, long long count, int P, float2 *__restrict__ dst,
+                                                      const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int p = blockIdx.x * G + g;
+    const bool live = p < P;
+    float2 *s = lds + g * M;
+
+    const long long first = (long long) p * M;           // first sample of this partition
+    for (int k = tid; k < M; k += TG)
+    {
+        // samples 2k, 2k+1 of the zero-padded partition; only the first M samples can be non-zero
+        long long a = first + 2LL * k;
+        float x0 = (live && 2 * k < M && a < count) ? src[a] : 0.f;
+        float x1 = (live && 2 * k + 1 < M && a + 1 < count) ? src[a + 1] : 0.f;
+        s[k] = make_float2(x0, x1);
+    }
+    __syncthreads();
+    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    if (live) real_post_store<LOG2M, TG>(s, tid, tw, dst + (long long) p * M);
+}
+
+// Generic real FFT of `batch` independent rows (plumbing for the hisstools_rfft surface): row b has
+// in_len valid samples at src + b * src_stride, zero padded to 2M; dst row stride M float2.
+template <int LOG2M>
+__global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict__ src, long long src_stride, long long in_len, int batch,
+                                                        float2 *__restrict__ dst, const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int b = blockIdx.x * G + g;
+    const bool live = b < batch;
+    float2 *s = lds + g * M;
+    const float *row = src + (long long) (live ? b : 0) * src_stride;
+    for (int k = tid; k < M; k += TG)
+    {
+        float x0 = (live && 2LL * k < in_len) ? row[2 * k] : 0.f;
+        float x1 = (live && 2LL * k + 1 < in_len) ? row[2 * k + 1] : 0.f;
+        s[k] = make_float2(x0, x1);
+    }
+    __syncthreads();
+    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    if (live) real_post_store<LOG2M, TG>(s, tid, tw, dst + (long long) b * M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse real FFT core: packed spectrum in LDS (s[0..M)) -> 2M real samples left in LDS as
+// s[k] = (x[2k+1], x[2k])  (note the swap: the inverse complex FFT is run on exchanged re/im, the
+// trick of HISSTools_FFT_Core.h:1341-1346).  Unnormalised, as hisstools_rifft.
+// ------------------------------------------------------------------------------------------------
+
+template <int LOG2M, int TG>
+__device__ __forceinline__ void real_pre_inverse(float2 *s, int tid, const float2 *__restrict__ tw)
+{
+    constexpr int M = 1 << LOG2M;
+    // every thread reads its pairs, barrier, then writes (k and M-k are owned by the same thread)
+    for (int k = tid; k <= M / 2; k += TG)
+    {
+        if (k == 0)
+        {
+            float2 z = s[0];
+            s[0] = make_float2(z.x - z.y, z.x + z.y);    // stored swapped (im, re): re = t1 = x+y, im = t2 = x-y
+        }
+        else
+        {
+            int m = M - k;
+            float2 w = tw[k];
+            float c = -w.x, sn = w.y;
+            float2 z1 = s[k], z2 = s[m];
+            float r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+            float u1 = (c * i3) + (sn * r4);
+            float u2 = (sn * i3) - (c * r4);
+            s[k] = make_float2(u2 + i4, r3 + u1);         // (im, re)
+            s[m] = make_float2(u2 - i4, r3 - u1);
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 + K4 + K6: inverse FFT of the accumulated spectra, scale by 1/(4N), and ADD the valid half-frame into
+// the per-output timeline ring at the hop's emission time ((h+1)*H .. (h+2)*H) — latency N/2, as the reference).
+//   Y: [ksplit][T][nout][M] float2 partial sums (summed here)
+// ------------------------------------------------------------------------------------------------
+
+template <int LOG2M>
+__global__ __launch_bounds__(256) void rifft_overlap_add_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, long long h_first,
+                                                                int T, int nout, float *__restrict__ timeline, long long tl_stride,
+                                                                long long tl_mask, const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int q = blockIdx.x * G + g;
+    const bool live = q < T * nout;
+    const int t = live ? q / nout : 0, o = live ? q % nout : 0;
+    float2 *s = lds + g * M;
+
+    const float2 *src = Y + ((long long) t * nout + o) * M;
+    for (int k = tid; k < M; k += TG)
+    {
+        float2 a = src[k];
+        for (int ks = 1; ks < ksplit; ks++)
+        {
+            float2 b = src[ks * ks_stride + k];
+            a.x += b.x;
+            a.y += b.y;
+        }
+        s[k] = a;
+    }
+    __syncthreads();
+    real_pre_inverse<LOG2M, TG>(s, tid, tw);
+    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+
+    if (live)
+    {
+        const float scale = 1.f / (float) (8 * M);        // 1 / (4N), N = 2M  (scaleStore, PartitionedConvolve.cpp:232-241)
+        const long long h = h_first + t;
+        float *row = timeline + (long long) o * tl_stride;
+        const long long base = (h + 1) * (long long) M;
+        // valid samples are e in [M, 2M): float2 index k in [M/2, M)
+        for (int k = M / 2 + tid; k < M; k += TG)
+        {
+            float2 v = s[k];                               // (x[2k+1], x[2k])
+            long long pos = (base + 2LL * k - M) & tl_mask;
+            float2 *d = reinterpret_cast<float2 *>(row + pos);
+            float2 cur = *d;
+            cur.x += v.y * scale;
+            cur.y += v.x * scale;
+            *d = cur;
+        }
+    }
+}
+
+// plain inverse for the hisstools_rifft plumbing surface: src rows of M float2 -> dst rows of 2M floats
+template <int LOG2M>
+__global__ __launch_bounds__(256) void rifft_rows_kernel(const float2 *__restrict__ src, int batch, float *__restrict__ dst,
+                                                         const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int b = blockIdx.x * G + g;
+    const bool live = b < batch;
+    float2 *s = lds + g * M;
+    const float2 *row = src + (long long) (live ? b : 0) * M;
+    for (int k = tid; k < M; k += TG) s[k] = row[k];
+    __syncthreads();
+    real_pre_inverse<LOG2M, TG>(s, tid, tw);
+    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    if (live)
+    {
+        float2 *d = reinterpret_cast<float2 *>(dst + (long long) b * 2 * M);
+        for (int k = tid; k < M; k += TG)
+        {
+            float2 v = s[k];
+            d[k] = make_float2(v.y, v.x);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: spectral multiply-accumulate — the HBM-bound roofline kernel.
+//
+//   Y[ks][t][o][b] = sum over k = (i, p) in this block's k-slice of  X[i][(h - p) mod R][b] * H[o][i][p][b]
+//
+// Thread = two bins (one dwordx4 of X, OT dwordx4 of H per k), OT outputs share the X value in registers, so X
+// traffic is 1/OT of H traffic.  H is streamed exactly once per hop with 16-byte coalesced loads; the reduction
+// over (i, p) stays in registers; large reductions are split over blockIdx (split-K) and summed by the inverse
+// FFT kernel's prologue.  For short FFTs (few bins) the spare threads of the workgroup take k-sub-slices
+// (blockDim.y) and are reduced through LDS.
+//
+// bin 0 carries (DC, Nyquist) and needs two real products instead of a complex one
+// (PartitionedConvolve.cpp:398-406, 424-425): the one lane that owns bin 0 tracks the Nyquist products in a
+// side accumulator and repairs its bin after the loop.
+//
+// hv[o][i] is the first hop whose input a pair may see (per-pair reset); CHECK=false is the steady state
+// where every pair sees all P partitions.
+// ------------------------------------------------------------------------------------------------
+
+struct MacParams
+{
+    const float4 *X;        // [nin][R][M/2] float4
+    const float4 *H;        // [nout][nin_alloc][Pcap][M/2] float4
+    float4 *Y;              // [ksplit][T][nout][M/2] float4
+    const long long *hv;    // [nout][nin_alloc]
+    long long h_first;
+    int M2;                 // float4 per spectrum = M/2
+    int R, P, Pcap;
+    int nin, nin_alloc, nout;
+    int diag;               // parallel mode: output o reads input o only (nin == 1 logically)
+    int ksplit, kper;       // k-slices over blockIdx.x and their length
+    int binblocks;
+    long long ks_stride4;   // float4 stride between k-slices of Y
+};
+
+template <int OT, bool CHECK>
+__global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 red[];
+
+    const int bb = blockIdx.x % a.binblocks;
+    const int ks = blockIdx.x / a.binblocks;
+    const int o0 = blockIdx.y * OT;
+    const int t = blockIdx.z;
+    const long long h = a.h_first + t;
+    const int hmod = (int) (h % a.R);
+
+    const int b4 = bb * blockDim.x + threadIdx.x;       // float4 index inside the spectrum
+    const bool binlive = b4 < a.M2;
+    const int b4c = binlive ? b4 : 0;
+    const bool owns_bin0 = (b4 == 0);
+
+    // this block's k-slice [kb0, kb1) of the flattened (i, p) reduction
+    const int K = a.nin * a.P;
+    const int kb0 = ks * a.kper;
+    const int kb1 = min(K, kb0 + a.kper);
+
+    float4 acc[OT];
+    float ny[OT];                                       // bin 0 only: sum of the Nyquist products x.y * h.y
+#pragma unroll
+    for (int j = 0; j < OT; j++)
+    {
+        acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ny[j] = 0.f;
+    }
+
+    const long long pair_stride4 = (long long) a.Pcap * a.M2;
+    const long long out_stride4 = (long long) a.nin_alloc * pair_stride4;
+
+    // per-output base pointers (clamped: dead outputs of a ragged last tile re-read the last live one)
+    const float4 *hbase[OT];
+#pragma unroll
+    for (int j = 0; j < OT; j++) hbase[j] = a.H + (long long) min(o0 + j, a.nout - 1) * out_stride4 + b4c;
+
+    if (kb0 < kb1)
+    {
+        const int i_first = kb0 / a.P, i_last = (kb1 - 1) / a.P;
+        for (int i = i_first; i <= i_last; i++)
+        {
+            const int pa = (i == i_first) ? kb0 - i_first * a.P : 0;
+            const int pb = (i == i_last) ? kb1 - i_last * a.P : a.P;
+
+            int lim[OT];
+            if (CHECK)
+            {
+#pragma unroll
+                for (int j = 0; j < OT; j++)
+                {
+                    long long d = h - a.hv[(long long) min(o0 + j, a.nout - 1) * a.nin_alloc + i];
+                    lim[j] = d > 0x3fffffff ? 0x3fffffff : (d < -1 ? -1 : (int) d);
+                }
+            }
+
+            const float4 *xrow = a.X + (long long) (a.diag ? 0 : i) * a.R * a.M2 + b4c;
+            const long long hoff_i = (long long) i * pair_stride4;
+
+#pragma unroll 2
+            for (int p = pa + (int) threadIdx.y; p < pb; p += (int) blockDim.y)
+            {
+                int slot = hmod - p;
+                if (slot < 0) slot += a.R;
+
+                float4 hval[OT];
+                const long long hoff = hoff_i + (long long) p * a.M2;
+#pragma unroll
+                for (int j = 0; j < OT; j++) hval[j] = hbase[j][hoff];
+
+                float4 x;
+                if (!a.diag) x = xrow[(long long) slot * a.M2];
+
+#pragma unroll
+                for (int j = 0; j < OT; j++)
+                {
+                    if (a.diag) x = xrow[((long long) min(o0 + j, a.nout - 1) * a.R + slot) * a.M2];
+                    bool ok = true;
+                    if (CHECK) ok = p <= lim[j];
+                    if (ok)
+                    {
+                        const float4 hh = hval[j];
+                        acc[j].x += x.x * hh.x - x.y * hh.y;
+                        acc[j].y += x.x * hh.y + x.y * hh.x;
+                        acc[j].z += x.z * hh.z - x.w * hh.w;
+                        acc[j].w += x.z * hh.w + x.w * hh.z;
+                        if (owns_bin0) ny[j] += x.y * hh.y;
+                    }
+                }
+            }
+        }
+    }
+
+    if (owns_bin0)
+    {
+#pragma unroll
+        for (int j = 0; j < OT; j++)
+        {
+            acc[j].x += ny[j];                          // sum(x.x*h.x - x.y*h.y) + sum(x.y*h.y) = DC products
+            acc[j].y = ny[j];                           // Nyquist products
+        }
+    }
+
+    // reduce the k-lanes (threadIdx.y) through LDS
+    if (blockDim.y > 1)
+    {
+        const int nx = blockDim.x;
+#pragma unroll
+        for (int j = 0; j < OT; j++)
+        {
+            __syncthreads();
+            red[threadIdx.y * nx + threadIdx.x] = acc[j];
+            __syncthreads();
+            if (threadIdx.y == 0)
+            {
+                float4 s = red[threadIdx.x];
+                for (int y = 1; y < (int) blockDim.y; y++)
+                {
+                    float4 v = red[y * nx + threadIdx.x];
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                acc[j] = s;
+            }
+        }
+    }
+
+    if (threadIdx.y == 0 && binlive)
+    {
+        float4 *y = a.Y + (long long) ks * a.ks_stride4 + ((long long) t * a.nout) * a.M2 + b4;
+#pragma unroll
+        for (int j = 0; j < OT; j++)
+            if (o0 + j < a.nout) y[(long long) (o0 + j) * a.M2] = acc[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: direct-form FIR head.  out[o][n] = sum_i sum_k taps[o][i][k] * x[i][n - k],  k < L (L padded to x4, <= 2048).
+// Block = 256 threads = 1024 output samples x OTD outputs; the input window and the taps are staged in LDS;
+// each thread keeps a 4-sample x OTD-output register tile and walks the taps four at a time (aligned float4 LDS reads).
+// ------------------------------------------------------------------------------------------------
+
+constexpr int FIR_SPB = 1024;      // samples per block
+constexpr int FIR_OTD = 4;         // outputs per block
+
+template <bool CHECK>
+__global__ __launch_bounds__(256) void fir_head_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
+                                                       const float *__restrict__ taps, int Lpad, int tap_stride, int nin, int nin_alloc,
+                                                       int nout, int diag, long long n0, int B, const long long *__restrict__ valid_from,
+                                                       float *__restrict__ out, long long out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float fir_lds[];
+    float *xs = fir_lds;                                   // Lpad + FIR_SPB floats: x[n_blk - Lpad .. n_blk + SPB)
+    float *hs = fir_lds + (Lpad + FIR_SPB);                // FIR_OTD * Lpad taps
+
+    const int tid = threadIdx.x;
+    const int nb = blockIdx.x * FIR_SPB;                   // first sample of this block inside the call
+    const int o0 = blockIdx.y * FIR_OTD;
+    const long long nabs = n0 + nb;                        // absolute sample index of the block start
+
+    float acc[FIR_OTD][4];
+#pragma unroll
+    for (int j = 0; j < FIR_OTD; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[j][q] = 0.f;
+
+    const int ni = diag ? 1 : nin;
+    for (int ii = 0; ii < ni; ii++)
+    {
+        __syncthreads();
+        if (!diag)
+        {
+            const float *row = hist + (long long) ii * hist_stride;
+            for (int e = tid; e < Lpad + FIR_SPB; e += 256)
+                xs[e] = row[(nabs - Lpad + e) & hist_mask];
+        }
+        for (int e = tid; e < FIR_OTD * Lpad; e += 256)
+        {
+            int j = e / Lpad, k = e - j * Lpad;
+            int o = min(o0 + j, nout - 1);
+            int i = diag ? 0 : ii;
+            hs[e] = taps[((long long) o * nin_alloc + i) * tap_stride + k];
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int j = 0; j < FIR_OTD; j++)
+        {
+            int o = min(o0 + j, nout - 1);
+            if (diag)
+            {
+                // each output has its own input row: restage x for this output
+                __syncthreads();
+                const float *row = hist + (long long) o * hist_stride;
+                for (int e = tid; e < Lpad + FIR_SPB; e += 256)
+                    xs[e] = row[(nabs - Lpad + e) & hist_mask];
+                __syncthreads();
+            }
+            long long vf = 0;
+            if (CHECK) vf = valid_from[(long long) o * nin_alloc + (diag ? 0 : ii)];
+            // thread's four samples: n = nb + 4*tid + q ; x[n - k] lives at xs[Lpad + 4*tid + q - k]
+            const float *hj = hs + j * Lpad;
+            const int c = Lpad + 4 * tid;
+            float4 hi4 = *reinterpret_cast<const float4 *>(xs + c);       // x[n0..n0+3] for k = 0..3 window top
+            for (int k = 0; k < Lpad; k += 4)
+            {
+                float4 lo4 = *reinterpret_cast<const float4 *>(xs + c - k - 4);
+                float4 h4 = *reinterpret_cast<const float4 *>(hj + k);
+                float w[8] = { lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w };   // x at offsets -4..+3 relative to (c - k)
+                if (CHECK)
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        if (nabs + 4 * tid - k - 4 + e < vf) w[e] = 0.f;
+                }
+                const float hk[4] = { h4.x, h4.y, h4.z, h4.w };
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++)
+                        acc[j][q] += hk[kk] * w[4 + q - kk];
+                hi4 = lo4;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < FIR_OTD; j++)
+    {
+        int o = o0 + j;
+        if (o < nout)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                int n = nb + 4 * tid + q;
+                if (n < B) out[(long long) o * out_stride + n] = acc[j][q];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: ring bookkeeping
+// ------------------------------------------------------------------------------------------------
+
+// hist[i][(n0 + j) & mask] = in[i][j]
+__global__ void scatter_input_kernel(const float *__restrict__ in, long long in_stride, int B, float *__restrict__ hist,
+                                     long long hist_stride, long long hist_mask, long long n0)
+{
+    int i = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B; j += gridDim.x * blockDim.x)
+        hist[(long long) i * hist_stride + ((n0 + j) & hist_mask)] = in[(long long) i * in_stride + j];
+}
+
+// out[o][j] (+)= timeline[o][(n0 + j) & mask] + td[o][j]; the consumed timeline span is zeroed for reuse
+__global__ void emit_kernel(float *__restrict__ timeline, long long tl_stride, long long tl_mask, long long n0, int B,
+                            const float *__restrict__ td, long long td_stride, float *__restrict__ out, long long out_stride,
+                            int use_timeline)
+{
+    int o = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B; j += gridDim.x * blockDim.x)
+    {
+        float v = 0.f;
+        if (use_timeline)
+        {
+            float *p = timeline + (long long) o * tl_stride + ((n0 + j) & tl_mask);
+            v = *p;
+            *p = 0.f;
+        }
+        if (td) v += td[(long long) o * td_stride + j];
+        out[(long long) o * out_stride + j] = v;
+    }
+}
+
+__global__ void fill_i64_kernel(long long *p, long long n, long long v)
+{
+    for (long long j = blockIdx.x * (long long) blockDim.x + threadIdx.x; j < n; j += (long long) gridDim.x * blockDim.x) p[j] = v;
+}
+
+// copy spectra [pairs][Pold][M] -> [pairs][Pnew][M] (capacity growth of a stage), float4 granularity
+__global__ void regrow_spectra_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, long long pairs, int Pold, int Pnew, int M2)
+{
+    long long per = (long long) Pold * M2;
+    long long total = pairs * per;
+    for (long long e = blockIdx.x * (long long) blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x)
+    {
+        long long pair = e / per, r = e - pair * per;
+        dst[pair * (long long) Pnew * M2 + r] = src[e];
+    }
+}
+
+// move the live hops of an input-spectrum ring to a ring with a different slot count
+__global__ void regrow_ring_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int nin, int Rold, int Rnew, int M2,
+                                   long long h_last, int live)
+{
+    // blockIdx.y = input, blockIdx.z = age (0 = newest hop h_last)
+    int i = blockIdx.y, age = blockIdx.z;
+    if (age >= live) return;
+    long long h = h_last - age;
+    if (h < 0) return;
+    const float4 *s = src + ((long long) i * Rold + (h % Rold)) * M2;
+    float4 *d = dst + ((long long) i * Rnew + (h % Rnew)) * M2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M2; e += gridDim.x * blockDim.x) d[e] = s[e];
+}
+
+// ================================================================================================
+// launchers
+// ================================================================================================
+
+#define HCV_FFT_DISPATCH(LOG2M_EXPR, CALL)                                                                             \
+    switch (LOG2M_EXPR)                                                                                                \
+    {                                                                                                                  \
+        case 4: { constexpr int L = 4; CALL; } break;                                                                  \
+        case 5: { constexpr int L = 5; CALL; } break;                                                                  \
+        case 6: { constexpr int L = 6; CALL; } break;                                                                  \
+        case 7: { constexpr int L = 7; CALL; } break;                                                                  \
+        case 8: { constexpr int L = 8; CALL; } break;                                                                  \
+        case 9: { constexpr int L = 9; CALL; } break;                                                                  \
+        case 10: { constexpr int L = 10; CALL; } break;                                                                \
+        case 11: { constexpr int L = 11; CALL; } break;                                                                \
+        case 12: { constexpr int L = 12; CALL; } break;                                                                \
+        case 13: { constexpr int L = 13; CALL; } break;                                                                \
+        case 14: { constexpr int L = 14; CALL; } break;                                                                \
+        default: return hipErrorInvalidValue;                                                                          \
+    }
+
+template <int L> static inline size_t fft_lds_bytes() { return sizeof(float2) * FFTGeom<L>::M * FFTGeom<L>::G; }
+
+template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    return hipSuccess;
+}
+
+hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin,
+                              float2 *X, int R, const float2 *tw, hipStream_t st)
+{
+    if (T <= 0 || nin <= 0) return hipSuccess;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rfft_frames_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (T * nin + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rfft_frames_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, hist, hist_stride, hist_mask, h_first, T, nin, X, R, tw);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, hipStream_t st)
+{
+    if (P <= 0) return hipSuccess;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rfft_ir_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (P + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rfft_ir_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, src, count, P, dst, tw);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_rfft_rows(int log2n, const float *src, long long src_stride, long long in_len, int batch, float2 *dst, const float2 *tw,
+                            hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rfft_rows_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (batch + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rfft_rows_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, src, src_stride, in_len, batch, dst, tw);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, hipStream_t st)
+{
+    if (batch <= 0) return hipSuccess;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rifft_rows_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (batch + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rifft_rows_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, src, batch, dst, tw);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long long ks_stride, long long h_first, int T, int nout,
+                                    float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, hipStream_t st)
+{
+    if (T <= 0 || nout <= 0) return hipSuccess;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rifft_overlap_add_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (T * nout + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rifft_overlap_add_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, Y, ksplit, ks_stride, h_first, T, nout, timeline,
+                           tl_stride, tl_mask, tw);
+    });
+    return hipGetLastError();
+}
+
+// choose OT: largest tile not exceeding the live outputs (diag mode cannot share X between outputs)
+int mac_out_tile(int nout, int diag)
+{
+    if (diag) return 1;
+    if (nout >= 16) return 16;
+    if (nout >= 8) return 8;
+    if (nout >= 4) return 4;
+    if (nout >= 2) return 2;
+    return 1;
+}
+
+void mac_plan(const MacShape &s, MacPlan &pl)
+{
+    const int M2 = s.M / 2;
+    pl.ot = mac_out_tile(s.nout, s.diag);
+    pl.bx = M2 < 256 ? M2 : 256;
+    pl.by = 256 / pl.bx;
+    pl.binblocks = (M2 + pl.bx - 1) / pl.bx;
+    pl.outtiles = (s.nout + pl.ot - 1) / pl.ot;
+    const long long K = (long long) (s.diag ? 1 : s.nin) * s.P;
+    long long base = (long long) pl.binblocks * pl.outtiles * s.T;
+    // aim for >= ~8 workgroups per CU across the chip, but keep every k-slice at least 8*by long
+    long long want = (2048 + base - 1) / base;
+    long long maxsplit = K / (8LL * pl.by);
+    if (maxsplit < 1) maxsplit = 1;
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    if (s.max_ksplit > 0 && want > s.max_ksplit) want = s.max_ksplit;
+    pl.kper = (int) ((K + want - 1) / want);
+    pl.ksplit = (int) ((K + pl.kper - 1) / pl.kper);
+    if (pl.ksplit < 1) pl.ksplit = 1;
+}
+
+template <int OT>
+static hipError_t launch_mac_ot(const MacParams &a, const MacPlan &pl, int T, bool check, hipStream_t st)
+{
+    dim3 grid(pl.binblocks * pl.ksplit, pl.outtiles, T);
+    dim3 block(pl.bx, pl.by);
+    size_t lds = pl.by > 1 ? sizeof(float4) * 256 : 0;
+    if (check)
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, true>), grid, block, lds, st, a);
+    else
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, false>), grid, block, lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
+                               long long h_first, bool check, hipStream_t st)
+{
+    if (s.T <= 0 || s.nout <= 0) return hipSuccess;
+    MacParams a;
+    a.X = reinterpret_cast<const float4 *>(X);
+    a.H = reinterpret_cast<const float4 *>(H);
+    a.Y = reinterpret_cast<float4 *>(Y);
+    a.hv = hv;
+    a.h_first = h_first;
+    a.M2 = s.M / 2;
+    a.R = s.R;
+    a.P = s.P;
+    a.Pcap = s.Pcap;
+    a.nin = s.diag ? 1 : s.nin;
+    a.nin_alloc = s.nin_alloc;
+    a.nout = s.nout;
+    a.diag = s.diag;
+    a.ksplit = pl.ksplit;
+    a.kper = pl.kper;
+    a.binblocks = pl.binblocks;
+    a.ks_stride4 = (long long) s.T * s.nout * (s.M / 2);
+    switch (pl.ot)
+    {
+        case 16: return launch_mac_ot<16>(a, pl, s.T, check, st);
+        case 8: return launch_mac_ot<8>(a, pl, s.T, check, st);
+        case 4: return launch_mac_ot<4>(a, pl, s.T, check, st);
+        case 2: return launch_mac_ot<2>(a, pl, s.T, check, st);
+        default: return launch_mac_ot<1>(a, pl, s.T, check, st);
+    }
+}
+
+hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
+                           int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
+                           long long out_stride, hipStream_t st)
+{
+    if (B <= 0 || nout <= 0) return hipSuccess;
+    dim3 grid((B + FIR_SPB - 1) / FIR_SPB, (nout + FIR_OTD - 1) / FIR_OTD);
+    size_t lds = sizeof(float) * ((size_t) Lpad + FIR_SPB + (size_t) FIR_OTD * Lpad);
+    if (check)
+        hipLaunchKernelGGL(fir_head_kernel<true>, grid, dim3(256), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout,
+                           diag, n0, B, valid_from, out, out_stride);
+    else
+        hipLaunchKernelGGL(fir_head_kernel<false>, grid, dim3(256), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout,
+                           diag, n0, B, valid_from, out, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,
+                                long long n0, hipStream_t st)
+{
+    if (B <= 0 || nin <= 0) return hipSuccess;
+    dim3 grid(std::min((B + 255) / 256, 64), nin);
+    hipLaunchKernelGGL(scatter_input_kernel, grid, dim3(256), 0, st, in, in_stride, B, hist, hist_stride, hist_mask, n0);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit(float *timeline, long long tl_stride, long long tl_mask, long long n0, int B, int nout, const float *td, long long td_stride,
+                       float *out, long long out_stride, int use_timeline, hipStream_t st)
+{
+    if (B <= 0 || nout <= 0) return hipSuccess;
+    dim3 grid(std::min((B + 255) / 256, 64), nout);
+    hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, timeline, tl_stride, tl_mask, n0, B, td, td_stride, out, out_stride, use_timeline);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    int grid = (int) std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(grid), dim3(256), 0, st, p, n, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st)
+{
+    if (pairs <= 0 || Pold <= 0) return hipSuccess;
+    hipLaunchKernelGGL(regrow_spectra_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), pairs,
+                       Pold, Pnew, M / 2);
+    return hipGetLastError();
+}
+
+hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st)
+{
+    if (nin <= 0 || live <= 0) return hipSuccess;
+    int M2 = M / 2;
+    dim3 grid(std::min((M2 + 255) / 256, 16), nin, live);
+    hipLaunchKernelGGL(regrow_ring_kernel, grid, dim3(256), 0, st, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), nin, Rold, Rnew,
+                       M2, h_last, live);
+    return hipGetLastError();
+}
+
+} // namespace hcv

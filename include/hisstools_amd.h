@@ -1,0 +1,164 @@
+/* hisstools_amd.h — C ABI of the MI355X-native partitioned-convolution engine.
+ *
+ * This is the drop-in boundary for the HISSTools_Library hot path
+ *     Convolver -> NToMonoConvolve -> MonoConvolve -> {PartitionedConvolve, TimeDomainConvolve} -> HISSTools_FFT
+ * The reference has no FFI of its own: hosts compile its C++ headers.  Every entry point below
+ * therefore replaces exactly one public method of one reference class (cited as file:line relative to the
+ * reference tree); the header-only C++ classes in include/hisstools_amd/ *.h re-create the reference's class
+ * names and signatures on top of this ABI, so callers recompile unchanged.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; handles are opaque; no C++ or torch types cross the boundary
+ *   - int return values named "error" are ConvolveError codes (ConvolveErrors.h:4-19), reproduced below
+ *   - all audio / IR data is IEEE float32 (double overloads convert, as Convolver.cpp:126-134,156-183)
+ *   - *_dev variants take pointers to memory on the engine's GPU and never touch host memory (HBM-resident use)
+ *   - a NULL handle from a *_create means no usable GPU / out of memory; hcv_last_error() says why.  There is no
+ *     CPU fallback.
+ */
+#ifndef HISSTOOLS_AMD_H
+#define HISSTOOLS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HCV_API __attribute__((visibility("default")))
+
+/* ConvolveErrors.h:4-19 */
+enum
+{
+    HCV_ERR_NONE = 0,
+    HCV_ERR_IN_CHAN_OUT_OF_RANGE = 1,
+    HCV_ERR_OUT_CHAN_OUT_OF_RANGE = 2,
+    HCV_ERR_MEM_UNAVAILABLE = 3,
+    HCV_ERR_MEM_ALLOC_TOO_SMALL = 4,
+    HCV_ERR_TIME_IMPULSE_TOO_LONG = 5,
+    HCV_ERR_TIME_LENGTH_OUT_OF_RANGE = 6,
+    HCV_ERR_PARTITION_LENGTH_TOO_LARGE = 7,
+    HCV_ERR_FFT_SIZE_MAX_TOO_SMALL = 8,
+    HCV_ERR_FFT_SIZE_MAX_TOO_LARGE = 9,
+    HCV_ERR_FFT_SIZE_MAX_NON_POWER_OF_TWO = 10,
+    HCV_ERR_FFT_SIZE_OUT_OF_RANGE = 11,
+    HCV_ERR_FFT_SIZE_NON_POWER_OF_TWO = 12
+};
+
+/* LatencyMode, MonoConvolve.h:14-19 */
+enum { HCV_LATENCY_ZERO = 0, HCV_LATENCY_SHORT = 1, HCV_LATENCY_MEDIUM = 2 };
+
+typedef struct hcv_partitioned hcv_partitioned;   /* HISSTools::PartitionedConvolve */
+typedef struct hcv_timedomain hcv_timedomain;     /* HISSTools::TimeDomainConvolve  */
+typedef struct hcv_mono hcv_mono;                 /* HISSTools::MonoConvolve        */
+typedef struct hcv_ntomono hcv_ntomono;           /* HISSTools::NToMonoConvolve     */
+typedef struct hcv_convolver hcv_convolver;       /* HISSTools::Convolver           */
+
+/* ---------------------------------------------------------------- library / device */
+
+HCV_API const char *hcv_version(void);
+HCV_API int hcv_device_count(void);                       /* number of HIP devices, 0 if none / no runtime */
+HCV_API int hcv_set_default_device(int device);           /* device used by subsequently created objects */
+HCV_API int hcv_get_default_device(void);
+HCV_API const char *hcv_last_error(void);                 /* thread-local text of the last failure */
+
+/* ---------------------------------------------------------------- HISSTools_FFT (float real transforms on the path)
+ * hisstools_rfft 5-arg  HISSTools_FFT.cpp:226-230   (zero-padding unzip + real FFT, output x2, vDSP packing)
+ * hisstools_rifft 4-arg HISSTools_FFT.cpp:244-248   (unnormalised; the input spectrum is NOT modified here)
+ * Batched: `batch` rows, input row stride in_stride floats, spectra rows of 2^(log2n-1) floats each.
+ * Returns 0 on success, -1 on failure (hcv_last_error). */
+HCV_API int hcv_rfft_f32(const float *in, size_t in_length, size_t in_stride, size_t batch, unsigned log2n, float *realp, float *imagp);
+HCV_API int hcv_rifft_f32(const float *realp, const float *imagp, size_t batch, unsigned log2n, float *out);
+
+/* ---------------------------------------------------------------- PartitionedConvolve (PartitionedConvolve.h:23-41) */
+
+HCV_API hcv_partitioned *hcv_partitioned_create(uintptr_t maxFFTSize, uintptr_t maxLength, uintptr_t offset, uintptr_t length); /* .cpp:52-102 */
+HCV_API void hcv_partitioned_destroy(hcv_partitioned *h);                                   /* .cpp:104-112 */
+HCV_API int hcv_partitioned_set_fft_size(hcv_partitioned *h, uintptr_t FFTSize);             /* .cpp:131-154 error */
+HCV_API int hcv_partitioned_set_length(hcv_partitioned *h, uintptr_t length);                /* .cpp:156-161 error */
+HCV_API void hcv_partitioned_set_offset(hcv_partitioned *h, uintptr_t offset);               /* .cpp:163-166 */
+HCV_API void hcv_partitioned_set_reset_offset(hcv_partitioned *h, intptr_t offset);          /* .cpp:168-171 (phase hint) */
+HCV_API int hcv_partitioned_set(hcv_partitioned *h, const float *input, uintptr_t length);   /* .cpp:173-225 error */
+HCV_API void hcv_partitioned_reset(hcv_partitioned *h);                                      /* .cpp:227-230 */
+HCV_API int hcv_partitioned_process(hcv_partitioned *h, const float *in, float *out, uintptr_t numSamples); /* .cpp:243-385; 1 = out written, 0 = untouched, -1 = device failure */
+
+/* ---------------------------------------------------------------- TimeDomainConvolve (TimeDomainConvolve.h:15-31) */
+
+HCV_API hcv_timedomain *hcv_timedomain_create(uintptr_t offset, uintptr_t length);           /* .cpp:33-50 */
+HCV_API void hcv_timedomain_destroy(hcv_timedomain *h);
+HCV_API int hcv_timedomain_set_length(hcv_timedomain *h, uintptr_t length);                  /* .cpp:62-67 error */
+HCV_API void hcv_timedomain_set_offset(hcv_timedomain *h, uintptr_t offset);                 /* .cpp:57-60 */
+HCV_API int hcv_timedomain_set(hcv_timedomain *h, const float *input, uintptr_t length);     /* .cpp:69-87 error */
+HCV_API void hcv_timedomain_reset(hcv_timedomain *h);                                        /* .cpp:89-92 */
+HCV_API int hcv_timedomain_process(hcv_timedomain *h, const float *in, float *out, uintptr_t numSamples); /* .cpp:128-163; returns "has taps" */
+
+/* ---------------------------------------------------------------- MonoConvolve (MonoConvolve.h:30-48) */
+
+HCV_API hcv_mono *hcv_mono_create(uintptr_t maxLength, int latency);                         /* .cpp:18-32 */
+/* custom partitioning, .cpp:36-45; where the reference throws std::runtime_error this returns NULL and copies the
+ * message ("invalid FFT size or order" / "no valid FFT sizes given") into err */
+HCV_API hcv_mono *hcv_mono_create_custom(uintptr_t maxLength, int zeroLatency, uint32_t A, uint32_t B, uint32_t C, uint32_t D, char *err, size_t errlen);
+HCV_API void hcv_mono_destroy(hcv_mono *h);
+HCV_API void hcv_mono_set_reset_offset(hcv_mono *h, intptr_t offset);                        /* .cpp:80-99 */
+HCV_API int hcv_mono_resize(hcv_mono *h, uintptr_t length);                                  /* .cpp:101-110 error */
+HCV_API int hcv_mono_set(hcv_mono *h, const float *input, uintptr_t length, int requestResize); /* .cpp:118-140 error */
+HCV_API int hcv_mono_reset(hcv_mono *h);                                                     /* .cpp:148-152 error */
+HCV_API int hcv_mono_process(hcv_mono *h, const float *in, float *temp, float *out, uintptr_t numSamples, int accumulate); /* .cpp:179-201; 1 = out written/added, 0 = untouched, -1 failure */
+
+/* ---------------------------------------------------------------- NToMonoConvolve (NToMonoConvolve.h:18-24) */
+
+HCV_API hcv_ntomono *hcv_ntomono_create(uint32_t inChans, uintptr_t maxLength, int latency); /* .cpp:4-9 */
+HCV_API void hcv_ntomono_destroy(hcv_ntomono *h);
+HCV_API int hcv_ntomono_resize(hcv_ntomono *h, uint32_t inChan, uintptr_t length);           /* .cpp:20-23 error */
+HCV_API int hcv_ntomono_set(hcv_ntomono *h, uint32_t inChan, const float *input, uintptr_t length, int resize); /* .cpp:25-28 error */
+HCV_API int hcv_ntomono_reset(hcv_ntomono *h, uint32_t inChan);                              /* .cpp:30-33 error */
+HCV_API int hcv_ntomono_process(hcv_ntomono *h, const float *const *ins, float *out, float *temp, size_t numSamples, size_t activeInChans); /* .cpp:35-43; 0 ok, -1 failure */
+
+/* ---------------------------------------------------------------- Convolver (Convolver.h:23-50) */
+
+HCV_API hcv_convolver *hcv_convolver_create(uint32_t numIns, uint32_t numOuts, int latency); /* Convolver.cpp:5-22 */
+HCV_API hcv_convolver *hcv_convolver_create_parallel(uint32_t numIO, int latency);           /* Convolver.cpp:24-41 */
+HCV_API void hcv_convolver_destroy(hcv_convolver *h);                                        /* Convolver.cpp:43-47 */
+HCV_API void hcv_convolver_clear(hcv_convolver *h, int resize);                              /* :51-64 */
+HCV_API void hcv_convolver_clear_chan(hcv_convolver *h, uint32_t inChan, uint32_t outChan, int resize); /* :66-69 */
+HCV_API void hcv_convolver_reset(hcv_convolver *h);                                          /* :73-86 */
+HCV_API int hcv_convolver_reset_chan(hcv_convolver *h, uint32_t inChan, uint32_t outChan);   /* :88-98 error */
+HCV_API int hcv_convolver_resize(hcv_convolver *h, uint32_t inChan, uint32_t outChan, uintptr_t length); /* :100-110 error */
+HCV_API int hcv_convolver_set_f32(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const float *input, uintptr_t length, int resize);  /* :114-124 error */
+HCV_API int hcv_convolver_set_f64(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const double *input, uintptr_t length, int resize); /* :126-134 error */
+HCV_API int hcv_convolver_process_f32(hcv_convolver *h, const float *const *ins, float **outs, size_t numIns, size_t numOuts, size_t numSamples);   /* :138-154; 0 ok, -1 failure */
+HCV_API int hcv_convolver_process_f64(hcv_convolver *h, const double *const *ins, double **outs, size_t numIns, size_t numOuts, size_t numSamples); /* :156-183 */
+
+/* ---------------------------------------------------------------- MI355X extensions of the Convolver (no reference analogue)
+ * Multi-GPU: one object per GPU, each owning a block of output rows (no collective on the data path); see
+ * hisstools_library_amd/sharded.py.  `device` < 0 = default device. */
+HCV_API hcv_convolver *hcv_convolver_create_on(uint32_t numIns, uint32_t numOuts, int latency, int device, uint32_t maxBlock);
+HCV_API hcv_convolver *hcv_convolver_create_custom(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency,
+                                                   uint32_t A, uint32_t B, uint32_t C, uint32_t D, int device, uint32_t maxBlock);
+/* IR already in HBM on the object's device */
+HCV_API int hcv_convolver_set_f32_dev(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const float *input_dev, uintptr_t length, int resize);
+/* ins_dev: [numIns][in_stride] floats, outs_dev: [numOuts][out_stride] floats, both in HBM.  Asynchronous on the object's
+ * stream unless sync != 0.  Returns 0 ok, -1 failure. */
+HCV_API int hcv_convolver_process_f32_dev(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride,
+                                          size_t numIns, size_t numOuts, size_t numSamples, int sync);
+HCV_API int hcv_convolver_synchronize(hcv_convolver *h);
+HCV_API int hcv_convolver_device(hcv_convolver *h);
+
+/* per-stage measurements of the spectral multiply-accumulate kernel (HIP events on the launch stream) */
+typedef struct hcv_stage_stats
+{
+    uint32_t fft_size, partitions, num_ins, num_outs;
+    uint64_t mac_launches, mac_hops;
+    double mac_ms;
+    uint32_t ksplit, out_tile;
+} hcv_stage_stats;
+HCV_API void hcv_convolver_set_profiling(hcv_convolver *h, int on);
+HCV_API int hcv_convolver_num_stages(hcv_convolver *h);
+HCV_API int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_stats *out);
+HCV_API void hcv_convolver_clear_stats(hcv_convolver *h);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HISSTOOLS_AMD_H */

@@ -1,0 +1,430 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, the golden vectors produced by the
+unmodified reference, and float64 ground truth.  Needs a real MI355X:  pytest -m gpu
+
+Stated tolerance: per output channel  max|y - y_ref| <= TOL * max|y_ref|
+    TOL = 2e-6  for IRs up to 2 s (what the reference itself achieves against float64 is ~3e-7)
+    TOL = 1e-5  for many-input sums and the long-IR stress shapes
+The GPU path shares one forward FFT per input and one inverse FFT per output and reduces (input, partition)
+products in a different order than the reference, so results agree to rounding, not bitwise.
+"""
+import functools
+import os
+import types
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-6
+TOL_SUM = 1e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hisstools_library_amd as H
+    assert H.load().hcv_device_count() > 0, "no GPU visible: the HIP path cannot run (and there is no fallback)"
+    return H
+
+
+def truth_conv(x, h, latency=0):
+    from scipy.signal import fftconvolve
+    y = fftconvolve(np.asarray(x, np.float64), np.asarray(h, np.float64))[: len(x)]
+    return np.concatenate([np.zeros(latency), y])[: len(x)]
+
+
+# ------------------------------------------------------------------------------------------- FFT (K2/K3)
+
+@pytest.mark.parametrize("l2", list(range(5, 16)))
+def test_rfft_rifft_vs_oracle(H, oracle, l2):
+    n = 1 << l2
+    x = np.stack([oracle.synth_audio(40 + b, n) for b in range(3)])
+    re, im = H.hisstools_rfft(x, l2)
+    for b in range(3):
+        ore, oim = oracle.rfft(x[b], l2)
+        scale = max(np.abs(ore).max(), np.abs(oim).max())
+        assert np.abs(re[b] - ore).max() / scale < 1e-6 and np.abs(im[b] - oim).max() / scale < 1e-6
+        # vDSP packing against numpy in float64
+        X = np.fft.rfft(x[b].astype(np.float64)) * 2
+        assert abs(re[b][0] - X.real[0]) / scale < 1e-6 and abs(im[b][0] - X.real[n // 2]) / scale < 1e-6
+    inv = H.hisstools_rifft(re, im, l2)
+    for b in range(3):
+        assert np.abs(inv[b] / (2 * n) - x[b]).max() < 2e-6          # rifft(rfft(x)) = 2N x
+        assert rel_err(inv[b], oracle.rifft(re[b], im[b], l2)) < 1e-6
+
+
+def test_rfft_zero_padding_and_odd_length(H, oracle, golden):
+    re, im = H.hisstools_rfft(golden["fft8_odd_x"], 8)
+    scale = np.abs(golden["fft8_odd_re"]).max()
+    assert np.abs(re - golden["fft8_odd_re"]).max() / scale < 1e-6
+    assert np.abs(im - golden["fft8_odd_im"]).max() / scale < 1e-6
+
+
+@pytest.mark.parametrize("l2", [5, 8, 10, 12, 14])
+def test_fft_golden_vectors(H, golden, l2):
+    re, im = H.hisstools_rfft(golden[f"fft{l2}_x"], l2)
+    scale = max(np.abs(golden[f"fft{l2}_re"]).max(), np.abs(golden[f"fft{l2}_im"]).max())
+    assert np.abs(re - golden[f"fft{l2}_re"]).max() / scale < 1e-6
+    assert np.abs(im - golden[f"fft{l2}_im"]).max() / scale < 1e-6
+    assert rel_err(H.hisstools_rifft(golden[f"fft{l2}_re"], golden[f"fft{l2}_im"], l2), golden[f"fft{l2}_inv"]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- golden vectors end to end
+
+@pytest.mark.parametrize("name,N,blocks", [("part256", 256, 512), ("part1024", 1024, [1, 7, 333, 2000, 64])])
+def test_golden_partitioned(H, golden, name, N, blocks):
+    p = H.PartitionedConvolve(N, golden[f"{name}_ir"].size, 0, 0)
+    assert p.set(golden[f"{name}_ir"]) == 0
+    assert rel_err(p.run(golden[f"{name}_x"], blocks), golden[f"{name}_y"]) < TOL
+
+
+def test_golden_partitioned_window(H, golden):
+    p = H.PartitionedConvolve(256, 1024, 300, 500)
+    assert p.set(golden["partwin_ir"]) == 0
+    assert rel_err(p.run(golden["partwin_x"], 256), golden["partwin_y"]) < TOL
+
+
+@pytest.mark.parametrize("Lh", [1, 16, 128, 2044])
+def test_golden_time_domain(H, golden, Lh):
+    t = H.TimeDomainConvolve(0, Lh)
+    t.set(golden["td_ir"])
+    assert rel_err(t.run(golden["td_x"], 512), golden[f"td{Lh}_y"]) < TOL
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_golden_mono(H, golden, mode):
+    m = H.MonoConvolve(16384, latency=mode)
+    assert m.set(golden["mono_ir"], True) == 0
+    assert rel_err(m.run(golden["mono_x"], 512), golden[f"mono{mode}_y"]) < TOL
+
+
+def test_golden_mono_custom(H, golden):
+    m = H.MonoConvolve(11000, zeroLatency=False, A=512, B=2048)
+    assert m.set(golden["mono_ir"], False) == 0
+    assert rel_err(m.run(golden["mono_x"], [100, 900, 2048]), golden["monoc_y"]) < TOL
+
+
+def test_golden_ntomono(H, golden):
+    c = H.NToMonoConvolve(3, 16384, 0)
+    for i in range(3):
+        assert c.set(i, golden["n2m_irs"][i], True) == 0
+    assert rel_err(c.run(golden["n2m_x"], 512), golden["n2m_y"]) < TOL_SUM
+
+
+def test_golden_convolver(H, golden):
+    irs = golden["conv_irs"]
+    c = H.Convolver(2, 3, 0)
+    for o in range(3):
+        for i in range(2):
+            assert c.set(i, o, irs[o, i], True) == 0
+    y = c.run(golden["conv_x"], 3, 512)
+    for o in range(3):
+        assert rel_err(y[o], golden["conv_y"][o]) < TOL_SUM
+    c = H.Convolver(3, None, 1)
+    for o in range(3):
+        assert c.set(o, o, golden["par_irs"][o], True) == 0
+    y = c.run(golden["par_x"], 3, 256)
+    for o in range(3):
+        assert rel_err(y[o], golden["par_y"][o]) < TOL_SUM
+
+
+# ------------------------------------------------------------------------------------------- HIP vs oracle on seeded inputs
+
+@pytest.mark.parametrize("N,L,S,block", [
+    (32, 200, 1500, 64), (64, 1000, 3000, [5, 300, 17]), (256, 5000, 12000, 512), (1024, 20000, 30000, 2048),
+    (4096, 48000, 40000, 4096), (16384, 48000, 70000, 8192), (32768, 70000, 100000, 5000)])
+def test_partitioned_vs_oracle(H, oracle, N, L, S, block):
+    h, x = oracle.synth_ir(1, 2, L), oracle.synth_audio(3, S)
+    ref = oracle.PartitionedConvolve(N, L, 0, 0)
+    ref.setResetOffset(0)
+    assert ref.set(h) == 0
+    gpu = H.PartitionedConvolve(N, L, 0, 0)
+    assert gpu.set(h) == 0
+    y_ref, y = ref.run(x, 2048 if not isinstance(block, int) or block > 2048 else block), gpu.run(x, block)
+    assert rel_err(y, y_ref) < TOL
+    assert rel_err(y, truth_conv(x, h, N // 2)) < TOL
+    assert (y[: N // 2] == 0).all()                              # latency exactly N/2
+
+
+def test_partitioned_block_size_independence(H, oracle):
+    h, x = oracle.synth_ir(5, 5, 6000), oracle.synth_audio(6, 20000)
+    outs = []
+    for block in (64, 512, [1, 7, 333, 5000, 4096], 20000):
+        p = H.PartitionedConvolve(1024, 6000, 0, 0)
+        p.set(h)
+        outs.append(p.run(x, block))
+    for y in outs[1:]:
+        assert rel_err(y, outs[0]) < 1e-6                        # same maths, reduction split may differ with batch size
+
+
+def test_partitioned_fft_size_change_and_reload(H, oracle):
+    h, x = oracle.synth_ir(7, 0, 3000), oracle.synth_audio(7, 9000)
+    p = H.PartitionedConvolve(4096, 4096, 0, 0)
+    assert p.set(h) == 0
+    y1 = p.run(x, 512)
+    assert rel_err(y1, truth_conv(x, h, 2048)) < TOL
+    assert p.setFFTSize(512) == 0
+    assert p.process(x[:100])[0] is False                         # no partitions until the next set (.cpp:131-154)
+    assert p.set(h) == 0
+    assert rel_err(p.run(x, 512), truth_conv(x, h, 256)) < TOL
+
+
+@pytest.mark.parametrize("Lh,block", [(1, 512), (16, 64), (128, 512), (128, 5000), (2044, 4096), (777, [3, 1000, 4099])])
+def test_time_domain_vs_oracle(H, oracle, Lh, block):
+    h, x = oracle.synth_ir(2, 1, 2044), oracle.synth_audio(9, 15000)
+    ref = oracle.TimeDomainConvolve(0, Lh)
+    ref.set(h)
+    gpu = H.TimeDomainConvolve(0, Lh)
+    gpu.set(h)
+    y = gpu.run(x, block)
+    assert rel_err(y, ref.run(x, 512)) < TOL
+    assert rel_err(y, truth_conv(x, h[:Lh])) < TOL               # plain causal FIR for any call size (no ring-wrap defect)
+
+
+@pytest.mark.parametrize("mode,lat", [(0, 0), (1, 128), (2, 512)])
+def test_mono_modes_vs_oracle_and_truth(H, oracle, mode, lat):
+    h, x = oracle.synth_ir(0, 0, 48000), oracle.synth_audio(0, 60000)      # config-1 shape: 1 s @ 48 kHz
+    ref = oracle.MonoConvolve(48000, latency=mode)
+    ref.setResetOffset(0)
+    assert ref.set(h, True) == 0
+    gpu = H.MonoConvolve(48000, latency=mode)
+    assert gpu.set(h, True) == 0
+    y, y_ref = gpu.run(x, 512), ref.run(x, 512)
+    assert rel_err(y, y_ref) < TOL
+    assert rel_err(y, truth_conv(x, h, lat)) < TOL
+
+
+def test_mono_single_stage_config1(H, oracle):
+    # BASELINE config 1: MonoConvolve 1x1, one 16384-point stage, 1 s @ 48 kHz IR
+    h, x = oracle.synth_ir(0, 0, 48000), oracle.synth_audio(0, 80000)
+    ref = oracle.MonoConvolve(48000, zeroLatency=False, A=16384)
+    ref.setResetOffset(0)
+    ref.set(h, False)
+    gpu = H.MonoConvolve(48000, zeroLatency=False, A=16384)
+    assert gpu.set(h, False) == 0
+    assert rel_err(gpu.run(x, 2048), ref.run(x, 2048)) < TOL
+
+
+def test_mono_impulse_is_exact(H):
+    # delta in -> the IR comes out sample-exact in the zero-latency chain
+    h = np.zeros(40000, np.float32)
+    for k, v in ((0, 0.5), (5, -0.25), (130, 0.75), (600, 0.3), (9000, -0.6), (30000, 0.9)):
+        h[k] = v
+    m = H.MonoConvolve(40000, latency=0)
+    assert m.set(h, True) == 0
+    x = np.zeros(45000, np.float32)
+    x[0] = 1.0
+    y = m.run(x, 512)
+    assert np.abs(y[:40000] - h).max() < 2e-7
+
+
+def test_mono_accumulate(H, oracle):
+    h, x = oracle.synth_ir(1, 1, 300), oracle.synth_audio(2, 2000)
+    m = H.MonoConvolve(16384, latency=0)
+    m.set(h, False)
+    y = m.process(x)
+    m.reset()
+    ya = m.process(x, out=np.full(x.size, 2.0, np.float32), accumulate=True)
+    assert np.abs(ya - (y + 2.0)).max() < 1e-6
+
+
+def test_ntomono_vs_oracle(H, oracle):
+    nin, L, S = 8, 24000, 30000                                   # config-3 shape at 1/10 length
+    irs = [oracle.synth_ir(i, 0, L) for i in range(nin)]
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    ref = oracle.NToMonoConvolve(nin, 16384, 0)
+    ref.setResetOffset(0)
+    gpu = H.NToMonoConvolve(nin, 16384, 0)
+    for i in range(nin):
+        assert ref.set(i, irs[i], True) == 0 and gpu.set(i, irs[i], True) == 0
+    y = gpu.run(xs, 1024)
+    assert rel_err(y, ref.run(xs, 1024)) < TOL_SUM
+    truth = sum(truth_conv(xs[i], irs[i]) for i in range(nin))
+    assert rel_err(y, truth) < TOL_SUM
+    # activeIns < numIns uses only the leading inputs (NToMonoConvolve.cpp:41)
+    gpu.reset(0)
+    for i in range(nin):
+        gpu.reset(i)
+    y3 = gpu.run(xs, 1024, activeIns=3)
+    assert rel_err(y3, sum(truth_conv(xs[i], irs[i]) for i in range(3))) < TOL_SUM
+
+
+def test_convolver_matrix_vs_oracle(H, oracle):
+    nin, nout, L, S = 5, 3, 12000, 20000                          # ragged: not a multiple of any output tile
+    irs = {(i, o): oracle.synth_ir(i, o, L - 100 * i - 10 * o) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    ref = oracle.Convolver(nin, nout, 1)
+    ref.setResetOffset(0)
+    gpu = H.Convolver(nin, nout, 1)
+    for (i, o), h in irs.items():
+        assert ref.set(i, o, h, True) == 0 and gpu.set(i, o, h, True) == 0
+    y, y_ref = gpu.run(xs, nout, 512), ref.run(xs, nout, 512)
+    for o in range(nout):
+        assert rel_err(y[o], y_ref[o]) < TOL_SUM
+        truth = sum(truth_conv(xs[i], irs[(i, o)], 128) for i in range(nin))
+        assert rel_err(y[o], truth) < TOL_SUM
+
+
+def test_convolver_double_api_and_parallel(H, oracle):
+    n, L, S = 4, 5000, 9000
+    irs = [oracle.synth_ir(o, o, L).astype(np.float64) for o in range(n)]
+    xs = np.stack([oracle.synth_audio(50 + o, S) for o in range(n)]).astype(np.float64)
+    gpu = H.Convolver(n, None, 0)
+    ref = oracle.Convolver(n, None, 0)
+    ref.setResetOffset(0)
+    for o in range(n):
+        assert gpu.set(o, o, irs[o], True) == 0 and ref.set(o, o, irs[o], True) == 0
+    y = gpu.run(xs, n, 256)
+    assert y.dtype == np.float64
+    y_ref = ref.run(xs, n, 256)
+    for o in range(n):
+        assert rel_err(y[o], y_ref[o]) < TOL
+        assert rel_err(y[o], truth_conv(xs[o], irs[o])) < TOL
+
+
+def test_silent_and_cleared_pairs(H, oracle):
+    xs = np.stack([oracle.synth_audio(i, 4000) for i in range(2)])
+    h = oracle.synth_ir(0, 0, 2000)
+    c = H.Convolver(2, 2, 0)
+    assert c.set(0, 1, h, True) == 0
+    y = c.run(xs, 2, 512)
+    assert (y[0] == 0).all()                                      # no IR on output 0: zeros (NToMonoConvolve.cpp:39)
+    assert rel_err(y[1], truth_conv(xs[0], h)) < TOL
+    c.clear(0, 1, False)
+    assert (c.run(xs, 2, 512) == 0).all()
+    assert c.set(0, 1, oracle.synth_ir(0, 0, 20000), False) == 4  # too long without resize: silent (MonoConvolve.cpp:139,183)
+    assert (c.run(xs, 2, 512) == 0).all()
+
+
+def test_reset_restarts_history(H, oracle):
+    h, x = oracle.synth_ir(3, 3, 9000), oracle.synth_audio(8, 12000)
+    c = H.Convolver(1, 1, 0)
+    c.set(0, 0, h, True)
+    y1 = c.run(x[None, :], 1, 512)[0]
+    c.reset()
+    y2 = c.run(x[None, :], 1, 512)[0]
+    assert rel_err(y2, y1) < 1e-6                                 # same input after reset() -> same output (no tail of run 1)
+    y3 = c.run(x[None, :], 1, 512)[0]
+    assert rel_err(y3, y1) > 1e-3                                 # without reset the previous tail rings on
+
+
+def test_capacity_growth_keeps_running_pairs(H, oracle):
+    # growing the tail for one pair (set(..., resize=True)) must not disturb another pair that is mid-stream
+    xs = np.stack([oracle.synth_audio(i, 40000) for i in range(2)])
+    xs[1, :20000] = 0.0                                           # input 1 is silent until its IR arrives
+    h0, h1 = oracle.synth_ir(0, 0, 16000), oracle.synth_ir(1, 0, 60000)
+    c = H.Convolver(2, 1, 2)
+    assert c.set(0, 0, h0, True) == 0
+    y_a = c.run(xs[:, :20000], 1, 1000)[0]
+    assert c.set(1, 0, h1, True) == 0                             # re-strides the tail stage while input 0 is running
+    y_b = c.run(xs[:, 20000:], 1, 1000)[0]
+    y = np.concatenate([y_a, y_b])
+    truth = truth_conv(xs[0], h0, 512) + truth_conv(xs[1], h1, 512)
+    assert rel_err(y, truth) < TOL_SUM
+
+
+def test_api_behaviour_checklist(H):
+    from semantics import EXPECTED, checklist
+    ns = types.SimpleNamespace(PartitionedConvolve=H.PartitionedConvolve, TimeDomainConvolve=H.TimeDomainConvolve, MonoConvolve=H.MonoConvolve,
+                               NToMonoConvolve=H.NToMonoConvolve, Convolver=H.Convolver)
+    obs, (y, ya) = checklist(ns)
+    assert obs == EXPECTED
+    assert np.allclose(ya, y + 1.0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- full-size shapes by property
+
+def _sparse_matrix_case(H, nin, nout, L, S, block, latency, seed):
+    """IRs that are a single scaled, delayed impulse: the exact answer is a gain-weighted sum of delayed inputs,
+    which is cheap to compute in float64 at any size."""
+    rng = np.random.RandomState(seed)
+    delays = rng.randint(0, L, size=(nout, nin))
+    gains = rng.uniform(-1, 1, size=(nout, nin))
+    xs = rng.uniform(-1, 1, size=(nin, S)).astype(np.float32)
+    c = H.Convolver(nin, nout, latency)
+    h = np.zeros(L, np.float32)
+    for o in range(nout):
+        for i in range(nin):
+            h[delays[o, i]] = gains[o, i]
+            assert c.set(i, o, h, True) == 0
+            h[delays[o, i]] = 0.0
+    y = c.run(xs, nout, block)
+    lat = {0: 0, 1: 128, 2: 512}[latency]
+    for o in range(nout):
+        t = np.zeros(S)
+        for i in range(nin):
+            d = delays[o, i] + lat
+            if d < S:
+                t[d:] += gains[o, i] * xs[i, : S - d].astype(np.float64)
+        assert rel_err(y[o], t) < TOL_SUM, (o, rel_err(y[o], t))
+
+
+def test_config4_shape_64x64_2s_impulse_irs(H):
+    _sparse_matrix_case(H, 64, 64, 96000, 3 * 8192 + 100, 8192, 0, seed=4)
+
+
+def test_config3_shape_8to1_5s_impulse_irs(H):
+    _sparse_matrix_case(H, 8, 1, 240000, 250000, 4096, 0, seed=3)
+
+
+def test_config2_shape_partitioned_10s(H, oracle):
+    # PartitionedConvolve 1x1, 4096-point partitions, 10 s @ 48 kHz IR (P = 235): linearity + impulse at full size
+    L, N, S = 480000, 4096, 500000
+    h = oracle.synth_ir(0, 0, L)
+    p = H.PartitionedConvolve(N, L, 0, 0)
+    assert p.set(h) == 0
+    x = np.zeros(S, np.float32)
+    x[0], x[1000] = 1.0, -0.5
+    y = p.run(x, 8192)
+    t = np.zeros(S)
+    t[2048: 2048 + L] += h[: S - 2048]
+    t[3048: 3048 + L] -= 0.5 * h[: S - 3048]
+    assert np.abs(y - t).max() < 2e-6 * np.abs(h).max() * 10
+    # linearity on noise: conv(a x1 + b x2) == a conv(x1) + b conv(x2)
+    x1, x2 = oracle.synth_audio(1, 60000), oracle.synth_audio(2, 60000)
+    outs = []
+    for sig in (x1, x2, 0.5 * x1 - 2.0 * x2):
+        p.reset()
+        outs.append(p.run(sig.astype(np.float32), 4096).astype(np.float64))
+    assert rel_err(outs[2], 0.5 * outs[0] - 2.0 * outs[1]) < TOL_SUM
+
+
+def test_config5_shape_16x16_60s_device_resident(H):
+    """16x16, 60 s @ 96 kHz IRs (11.8 GB of spectra): impulse IRs built in HBM, audio resident in HBM."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    nin = nout = 16
+    L, S = 5760000, 4 * 8192
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(5)
+    delays = rng.randint(0, 3 * 8192, size=(nout, nin))            # keep the responses inside the streamed span
+    far = rng.randint(L - 100000, L, size=(nout, nin))             # plus one far tap per pair that must stay silent here
+    gains = rng.uniform(-1, 1, size=(nout, nin))
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=8192)
+    h = torch.zeros(L, dtype=torch.float32, device=dev)
+    for o in range(nout):
+        for i in range(nin):
+            h[int(delays[o, i])] = float(gains[o, i])
+            h[int(far[o, i])] = 1.0
+            torch.cuda.synchronize()
+            assert c.set_dev(i, o, h.data_ptr(), L, True) == 0
+            h[int(delays[o, i])] = 0.0
+            h[int(far[o, i])] = 0.0
+    xs = torch.from_numpy(rng.uniform(-1, 1, size=(nin, S)).astype(np.float32)).to(dev)
+    ys = torch.zeros((nout, S), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    for pos in range(0, S, 8192):
+        c.process_dev(xs.data_ptr() + 4 * pos, S, ys.data_ptr() + 4 * pos, S, nin, nout, 8192)
+    c.synchronize()
+    y, x = ys.cpu().numpy(), xs.cpu().numpy()
+    for o in range(nout):
+        t = np.zeros(S)
+        for i in range(nin):
+            d = delays[o, i]
+            t[d:] += gains[o, i] * x[i, : S - d].astype(np.float64)
+        assert rel_err(y[o], t) < TOL_SUM
+    st = c.stage_stats()
+    assert st[-1]["fft_size"] == 16384 and st[-1]["partitions"] == 703

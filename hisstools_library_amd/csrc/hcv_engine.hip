@@ -581,8 +581,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         st.last_ksplit = (uint32_t) pl.ksplit;
         st.last_ot = (uint32_t) pl.ot;
 
-        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, pl.ksplit, (long long) T * nout_act * st.M, h_first, T, (int) nout_act, mTimeline, mTlLen,
-                                         tmask, st.tw, mStream));
+        const long long y_elems = (long long) T * nout_act * st.M;
+        HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, mStream));
+        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, mTimeline, mTlLen, tmask, st.tw, mStream));
     }
 
     if (td) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd, 0));

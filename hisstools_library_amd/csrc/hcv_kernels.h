@@ -37,6 +37,7 @@ namespace hcv
     };
     int mac_out_tile(int nout, int diag);
     void mac_plan(const MacShape &s, MacPlan &pl);
+    hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st);
     hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
                                    long long h_first, bool check, hipStream_t st);
 

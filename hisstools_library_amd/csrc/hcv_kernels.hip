@@ -561,17 +561,45 @@ __global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
     }
 }
 
+// Split-K epilogue: Y[0][e] = sum_ks Y[ks][e].  One float4 per thread, the ksplit strided loads of a thread are
+// independent (issued back to back), neighbouring threads are contiguous: a plain coalesced streaming reduction.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict__ Y, int ksplit, long long ks_stride4, long long n4)
+{
+    const long long e = blockIdx.x * (long long) blockDim.x + threadIdx.x;
+    if (e >= n4) return;
+    float4 s = Y[e];
+    int ks = 1;
+    for (; ks + 3 < ksplit; ks += 4)
+    {
+        const float4 a = Y[(long long) ks * ks_stride4 + e];
+        const float4 b = Y[(long long) (ks + 1) * ks_stride4 + e];
+        const float4 c = Y[(long long) (ks + 2) * ks_stride4 + e];
+        const float4 d = Y[(long long) (ks + 3) * ks_stride4 + e];
+        s.x += (a.x + b.x) + (c.x + d.x);
+        s.y += (a.y + b.y) + (c.y + d.y);
+        s.z += (a.z + b.z) + (c.z + d.z);
+        s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; ks < ksplit; ks++)
+    {
+        const float4 a = Y[(long long) ks * ks_stride4 + e];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    Y[e] = s;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: direct-form FIR head.  out[o][n] = sum_i sum_k taps[o][i][k] * x[i][n - k],  k < L (L padded to x4, <= 2048).
-// Block = 256 threads = 1024 output samples x OTD outputs; the input window and the taps are staged in LDS;
+// Block = 128 threads = 512 output samples x OTD outputs; the input window and the taps are staged in LDS;
 // each thread keeps a 4-sample x OTD-output register tile and walks the taps four at a time (aligned float4 LDS reads).
+// OTD (1, 2 or 4) is chosen at launch so that small matrices still spread over the chip.
 // ------------------------------------------------------------------------------------------------
 
-constexpr int FIR_SPB = 1024;      // samples per block
-constexpr int FIR_OTD = 4;         // outputs per block
+constexpr int FIR_THREADS = 128;
+constexpr int FIR_SPB = 4 * FIR_THREADS;      // samples per block
 
-template <bool CHECK>
-__global__ __launch_bounds__(256) void fir_head_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
+template <int FIR_OTD, bool CHECK>
+__global__ __launch_bounds__(FIR_THREADS) void fir_head_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
                                                        const float *__restrict__ taps, int Lpad, int tap_stride, int nin, int nin_alloc,
                                                        int nout, int diag, long long n0, int B, const long long *__restrict__ valid_from,
                                                        float *__restrict__ out, long long out_stride)
@@ -598,10 +626,10 @@ __global__ __launch_bounds__(256) void fir_head_kernel(const float *__restrict__
         if (!diag)
         {
             const float *row = hist + (long long) ii * hist_stride;
-            for (int e = tid; e < Lpad + FIR_SPB; e += 256)
+            for (int e = tid; e < Lpad + FIR_SPB; e += FIR_THREADS)
                 xs[e] = row[(nabs - Lpad + e) & hist_mask];
         }
-        for (int e = tid; e < FIR_OTD * Lpad; e += 256)
+        for (int e = tid; e < FIR_OTD * Lpad; e += FIR_THREADS)
         {
             int j = e / Lpad, k = e - j * Lpad;
             int o = min(o0 + j, nout - 1);
@@ -619,7 +647,7 @@ __global__ __launch_bounds__(256) void fir_head_kernel(const float *__restrict__
                 // each output has its own input row: restage x for this output
                 __syncthreads();
                 const float *row = hist + (long long) o * hist_stride;
-                for (int e = tid; e < Lpad + FIR_SPB; e += 256)
+                for (int e = tid; e < Lpad + FIR_SPB; e += FIR_THREADS)
                     xs[e] = row[(nabs - Lpad + e) & hist_mask];
                 __syncthreads();
             }
@@ -912,20 +940,47 @@ hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float
     }
 }
 
+hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st)
+{
+    if (ksplit <= 1 || elems <= 0) return hipSuccess;
+    const long long n4 = elems / 2;
+    const int grid = (int) ((n4 + 255) / 256);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4 *>(Y), ksplit, ks_stride / 2, n4);
+    return hipGetLastError();
+}
+
+template <int OTD>
+static hipError_t launch_fir_otd(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
+                                 int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
+                                 long long out_stride, hipStream_t st)
+{
+    dim3 grid((B + FIR_SPB - 1) / FIR_SPB, (nout + OTD - 1) / OTD);
+    size_t lds = sizeof(float) * ((size_t) Lpad + FIR_SPB + (size_t) OTD * Lpad);
+    if (check)
+        hipLaunchKernelGGL((fir_head_kernel<OTD, true>), grid, dim3(FIR_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
+                           nin_alloc, nout, diag, n0, B, valid_from, out, out_stride);
+    else
+        hipLaunchKernelGGL((fir_head_kernel<OTD, false>), grid, dim3(FIR_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
+                           nin_alloc, nout, diag, n0, B, valid_from, out, out_stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                            int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
                            long long out_stride, hipStream_t st)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
-    dim3 grid((B + FIR_SPB - 1) / FIR_SPB, (nout + FIR_OTD - 1) / FIR_OTD);
-    size_t lds = sizeof(float) * ((size_t) Lpad + FIR_SPB + (size_t) FIR_OTD * Lpad);
-    if (check)
-        hipLaunchKernelGGL(fir_head_kernel<true>, grid, dim3(256), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout,
-                           diag, n0, B, valid_from, out, out_stride);
-    else
-        hipLaunchKernelGGL(fir_head_kernel<false>, grid, dim3(256), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout,
-                           diag, n0, B, valid_from, out, out_stride);
-    return hipGetLastError();
+    // widest output tile that still leaves >= 2 workgroups per CU
+    const long long sblocks = (B + FIR_SPB - 1) / FIR_SPB;
+    int otd = 4;
+    while (otd > 1 && sblocks * ((nout + otd - 1) / otd) < 512) otd >>= 1;
+    if (diag) otd = 1;
+    switch (otd)
+    {
+        case 4: return launch_fir_otd<4>(hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout, diag, n0, B, valid_from, check, out, out_stride, st);
+        case 2: return launch_fir_otd<2>(hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout, diag, n0, B, valid_from, check, out, out_stride, st);
+        default: return launch_fir_otd<1>(hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin, nin_alloc, nout, diag, n0, B, valid_from, check, out, out_stride, st);
+    }
 }
 
 hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+try:
+    # PyTorch-ROCm bundles its own libamdhip64; when torch shares a process with libhisstools_amd.so it has to be
+    # loaded FIRST so both resolve to one HIP runtime.
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for everything except the HBM-resident tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

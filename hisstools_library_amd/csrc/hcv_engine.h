@@ -14,8 +14,8 @@
 //     hv [nout][nin_alloc]         int64       first hop each pair may see (per-pair reset)
 // plus per engine:
 //     hist     [nin][RH]  float                input history ring (overlap-save frames + FIR history)
-//     timeline [nout][OR] float                output timeline ring; every stage ADDS its hop results at their
-//                                              emission time, emit() reads and clears the current block
+//     timeline [nout][OR] float (per stage)    output timeline ring; the stage ADDS its hop results at their
+//                                              emission time, emit() sums the stages' rings and clears the block
 //     taps     [nout][nin_alloc][2048] float   time-domain head taps, zero padded
 #pragma once
 
@@ -125,7 +125,6 @@ namespace hcv
 
         // rings and staging
         float *mHist = nullptr;     long long mHistLen = 0;
-        float *mTimeline = nullptr; long long mTlLen = 0;
         float *mTdOut = nullptr;
         float *mDevIn = nullptr, *mDevOut = nullptr;
         float *mPinIn = nullptr, *mPinOut = nullptr;

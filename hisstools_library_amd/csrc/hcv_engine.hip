@@ -80,6 +80,10 @@ struct Engine::Stage
     uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
     float2 *Hs = nullptr, *X = nullptr, *Y = nullptr;
     size_t y_elems = 0;
+    float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
+    long long tl_len = 0;
+    hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream
+    hipEvent_t done = nullptr;
     long long *hv = nullptr;
     long long max_hv = 0;
     std::vector<uint32_t> pact;
@@ -179,13 +183,10 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipEventCreateWithFlags(&mEvTd, hipEventDisableTiming));
 
     mHistLen = pow2ceil((long long) mMaxBlock + std::max<long long>(nmax, 4096));
-    mTlLen = pow2ceil((long long) mMaxBlock + std::max<long long>(nmax / 2, 16));
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
 
     HCV_TRY(hipMalloc(&mHist, sizeof(float) * mCfg.nin * mHistLen));
     HCV_TRY(hipMemset(mHist, 0, sizeof(float) * mCfg.nin * mHistLen));
-    HCV_TRY(hipMalloc(&mTimeline, sizeof(float) * mCfg.nout * mTlLen));
-    HCV_TRY(hipMemset(mTimeline, 0, sizeof(float) * mCfg.nout * mTlLen));
     HCV_TRY(hipMalloc(&mDevIn, sizeof(float) * mCfg.nin * mMaxBlock));
     HCV_TRY(hipMalloc(&mDevOut, sizeof(float) * mCfg.nout * mMaxBlock));
     HCV_TRY(hipHostMalloc(&mPinIn, sizeof(float) * mCfg.nin * mMaxBlock, hipHostMallocDefault));
@@ -236,6 +237,11 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMalloc(&st.Y, sizeof(float2) * st.y_elems));
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
+    st.tl_len = pow2ceil((long long) mMaxBlock + st.M);
+    HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
+    HCV_TRY(hipMemset(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len));
+    HCV_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    HCV_TRY(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
     return true;
 }
 
@@ -245,8 +251,14 @@ void Engine::free_stage(Stage &st)
     if (st.X) (void) hipFree(st.X);
     if (st.Y) (void) hipFree(st.Y);
     if (st.hv) (void) hipFree(st.hv);
+    if (st.timeline) (void) hipFree(st.timeline);
+    if (st.done) (void) hipEventDestroy(st.done);
+    if (st.stream) (void) hipStreamDestroy(st.stream);
     st.Hs = st.X = st.Y = nullptr;
     st.hv = nullptr;
+    st.timeline = nullptr;
+    st.done = nullptr;
+    st.stream = nullptr;
 }
 
 Engine::~Engine()
@@ -266,7 +278,6 @@ Engine::~Engine()
         delete ev;
     }
     if (mHist) (void) hipFree(mHist);
-    if (mTimeline) (void) hipFree(mTimeline);
     if (mTdOut) (void) hipFree(mTdOut);
     if (mDevIn) (void) hipFree(mDevIn);
     if (mDevOut) (void) hipFree(mDevOut);
@@ -460,10 +471,10 @@ bool Engine::global_reset()
 {
     mN = 0;
     HCV_TRY(hipMemsetAsync(mHist, 0, sizeof(float) * mCfg.nin * mHistLen, mStream));
-    HCV_TRY(hipMemsetAsync(mTimeline, 0, sizeof(float) * mCfg.nout * mTlLen, mStream));
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     for (Stage *st : mStages)
     {
+        HCV_TRY(hipMemsetAsync(st->timeline, 0, sizeof(float) * mCfg.nout * st->tl_len, mStream));
         HCV_TRY(hipMemsetAsync(st->hv, 0, sizeof(long long) * pairs, mStream));
         st->max_hv = 0;
     }
@@ -511,19 +522,23 @@ bool Engine::apply_pending_resets()
 }
 
 // One block of at most max_block samples, everything device side.  Caller holds mMutex.
+//
+// Stream plan:   main:   scatter ─┬────────────────────────────────────────────┬─ emit
+//                stage s:         └ rfft_frames → spectral_mac → reduce → rifft ┤      (one stream per FFT stage)
+//                head:            └ fir_head ───────────────────────────────────┘
+// The stages only meet in emit(), so the latency-bound short stages and the FIR head hide under the HBM-bound tail.
 bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B)
 {
     const long long n0 = mN;
-    const long long hmask = mHistLen - 1, tmask = mTlLen - 1;
+    const long long hmask = mHistLen - 1;
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
 
     HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, mStream));
+    HCV_TRY(hipEventRecord(mEvInput, mStream));
 
     const bool td = mCfg.has_td && mTdLpad > 0;
     if (td)
     {
-        // the short head runs on its own stream, concurrently with the (HBM-bound) FFT stages
-        HCV_TRY(hipEventRecord(mEvInput, mStream));
         HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput, 0));
         const bool check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
         HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
@@ -531,17 +546,23 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(hipEventRecord(mEvTd, mTdStream));
     }
 
-    bool any_stage = false;
+    EmitSources src;
+    src.count = 0;
     for (size_t si = 0; si < mStages.size(); si++)
     {
         Stage &st = *mStages[si];
-        any_stage = true;                                   // the timeline may still hold earlier hops
+        src.timeline[src.count] = st.timeline;              // the ring may still hold hops of earlier calls
+        src.stride[src.count] = st.tl_len;
+        src.mask[src.count] = st.tl_len - 1;
+        src.count++;
         if (!st.P) continue;
         const long long h_first = n0 / st.M;
         const int T = (int) ((n0 + B) / st.M - h_first);
         if (T <= 0) continue;
 
-        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, mStream));
+        hipStream_t ss = st.stream;
+        HCV_TRY(hipStreamWaitEvent(ss, mEvInput, 0));
+        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, ss));
 
         MacShape sh;
         sh.M = (int) st.M;
@@ -572,23 +593,24 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             }
             ev->stage = si;
             ev->live = true;
-            HCV_TRY(hipEventRecord(ev->a, mStream));
+            HCV_TRY(hipEventRecord(ev->a, ss));
         }
-        HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, mStream));
-        if (ev) HCV_TRY(hipEventRecord(ev->b, mStream));
+        HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, ss));
+        if (ev) HCV_TRY(hipEventRecord(ev->b, ss));
         st.launches++;
         st.hops += (uint64_t) T;
         st.last_ksplit = (uint32_t) pl.ksplit;
         st.last_ot = (uint32_t) pl.ot;
 
         const long long y_elems = (long long) T * nout_act * st.M;
-        HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, mStream));
-        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, mTimeline, mTlLen, tmask, st.tw, mStream));
+        HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, ss));
+        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, ss));
+        HCV_TRY(hipEventRecord(st.done, ss));
+        HCV_TRY(hipStreamWaitEvent(mStream, st.done, 0));
     }
 
     if (td) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd, 0));
-    HCV_TRY(launch_emit(mTimeline, mTlLen, tmask, n0, (int) B, (int) nout_act, td ? mTdOut : nullptr, mMaxBlock, dout, out_stride, any_stage ? 1 : 0,
-                        mStream));
+    HCV_TRY(launch_emit(src, n0, (int) B, (int) nout_act, td ? mTdOut : nullptr, mMaxBlock, dout, out_stride, mStream));
     mN += B;
     return true;
 }

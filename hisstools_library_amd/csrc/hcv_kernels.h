@@ -49,8 +49,16 @@ namespace hcv
     // ---- ring bookkeeping ----
     hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,
                                     long long n0, hipStream_t st);
-    hipError_t launch_emit(float *timeline, long long tl_stride, long long tl_mask, long long n0, int B, int nout, const float *td,
-                           long long td_stride, float *out, long long out_stride, int use_timeline, hipStream_t st);
+    constexpr int kMaxStages = 4;         // MonoConvolve builds at most 4 FFT stages (MonoConvolve.cpp:235-252)
+    struct EmitSources
+    {
+        float *timeline[kMaxStages];
+        long long stride[kMaxStages];
+        long long mask[kMaxStages];
+        int count;
+    };
+    hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, const float *td, long long td_stride, float *out,
+                           long long out_stride, hipStream_t st);
     hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st);
     hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st);
     hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st);

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace hcv
 {
@@ -29,6 +30,14 @@ namespace hcv
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// 16-byte streaming load that bypasses cache retention (global_load_dwordx4 ... nt)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_nt(const float4 *p)
+{
+    v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // tw holds the N-th roots of unity exp(-2*pi*i*m/N) for m in [0, N/2); the second half of the circle
@@ -424,7 +433,7 @@ struct MacParams
     long long ks_stride4;   // float4 stride between k-slices of Y
 };
 
-template <int OT, bool CHECK>
+template <int OT, bool CHECK, bool NT>
 __global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
 {
     extern __shared__ __attribute__((aligned(16))) float4 red[];
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
                 float4 hval[OT];
                 const long long hoff = hoff_i + (long long) p * a.M2;
 #pragma unroll
-                for (int j = 0; j < OT; j++) hval[j] = hbase[j][hoff];
+                for (int j = 0; j < OT; j++) hval[j] = NT ? load_nt(hbase[j] + hoff) : hbase[j][hoff];
 
                 float4 x;
                 if (!a.diag) x = xrow[(long long) slot * a.M2];
@@ -708,20 +717,24 @@ __global__ void scatter_input_kernel(const float *__restrict__ in, long long in_
         hist[(long long) i * hist_stride + ((n0 + j) & hist_mask)] = in[(long long) i * in_stride + j];
 }
 
-// out[o][j] (+)= timeline[o][(n0 + j) & mask] + td[o][j]; the consumed timeline span is zeroed for reuse
-__global__ void emit_kernel(float *__restrict__ timeline, long long tl_stride, long long tl_mask, long long n0, int B,
-                            const float *__restrict__ td, long long td_stride, float *__restrict__ out, long long out_stride,
-                            int use_timeline)
+// out[o][j] = sum_s timeline_s[o][(n0 + j) & mask_s] + td[o][j]; the consumed timeline spans are zeroed for reuse.
+// Every FFT stage owns a timeline ring (so the stages can run concurrently on their own streams).
+__global__ void emit_kernel(EmitSources src, long long n0, int B, const float *__restrict__ td, long long td_stride, float *__restrict__ out,
+                            long long out_stride)
 {
     int o = blockIdx.y;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B; j += gridDim.x * blockDim.x)
     {
         float v = 0.f;
-        if (use_timeline)
+#pragma unroll
+        for (int s = 0; s < kMaxStages; s++)
         {
-            float *p = timeline + (long long) o * tl_stride + ((n0 + j) & tl_mask);
-            v = *p;
-            *p = 0.f;
+            if (s < src.count)
+            {
+                float *p = src.timeline[s] + (long long) o * src.stride[s] + ((n0 + j) & src.mask[s]);
+                v += *p;
+                *p = 0.f;
+            }
         }
         if (td) v += td[(long long) o * td_stride + j];
         out[(long long) o * out_stride + j] = v;
@@ -873,10 +886,20 @@ int mac_out_tile(int nout, int diag)
     return 1;
 }
 
+static int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
 void mac_plan(const MacShape &s, MacPlan &pl)
 {
+    // tuning knobs (read once): HCV_MAC_BLOCKS = workgroups to aim for, HCV_MAC_OT = cap on the output tile
+    static const int target_blocks = env_int("HCV_MAC_BLOCKS", 512);
+    static const int ot_cap = env_int("HCV_MAC_OT", 8);
     const int M2 = s.M / 2;
     pl.ot = mac_out_tile(s.nout, s.diag);
+    while (pl.ot > ot_cap && pl.ot > 1) pl.ot >>= 1;
     pl.bx = M2 < 256 ? M2 : 256;
     pl.by = 256 / pl.bx;
     pl.binblocks = (M2 + pl.bx - 1) / pl.bx;
@@ -884,7 +907,7 @@ void mac_plan(const MacShape &s, MacPlan &pl)
     const long long K = (long long) (s.diag ? 1 : s.nin) * s.P;
     long long base = (long long) pl.binblocks * pl.outtiles * s.T;
     // aim for >= ~8 workgroups per CU across the chip, but keep every k-slice at least 8*by long
-    long long want = (2048 + base - 1) / base;
+    long long want = (target_blocks + base - 1) / base;
     long long maxsplit = K / (8LL * pl.by);
     if (maxsplit < 1) maxsplit = 1;
     if (want > maxsplit) want = maxsplit;
@@ -901,10 +924,15 @@ static hipError_t launch_mac_ot(const MacParams &a, const MacPlan &pl, int T, bo
     dim3 grid(pl.binblocks * pl.ksplit, pl.outtiles, T);
     dim3 block(pl.bx, pl.by);
     size_t lds = pl.by > 1 ? sizeof(float4) * 256 : 0;
+    // H is streamed exactly once per launch when there is a single hop: keep it out of the caches (X stays resident)
+    static const int nt_mode = env_int("HCV_MAC_NT", 2);
+    const bool nt = nt_mode == 1 || (nt_mode == 2 && T == 1);
     if (check)
-        hipLaunchKernelGGL((spectral_mac_kernel<OT, true>), grid, block, lds, st, a);
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, true, false>), grid, block, lds, st, a);
+    else if (nt)
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, false, true>), grid, block, lds, st, a);
     else
-        hipLaunchKernelGGL((spectral_mac_kernel<OT, false>), grid, block, lds, st, a);
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, false, false>), grid, block, lds, st, a);
     return hipGetLastError();
 }
 
@@ -992,12 +1020,12 @@ hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int
     return hipGetLastError();
 }
 
-hipError_t launch_emit(float *timeline, long long tl_stride, long long tl_mask, long long n0, int B, int nout, const float *td, long long td_stride,
-                       float *out, long long out_stride, int use_timeline, hipStream_t st)
+hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, const float *td, long long td_stride, float *out,
+                       long long out_stride, hipStream_t st)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
     dim3 grid(std::min((B + 255) / 256, 64), nout);
-    hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, timeline, tl_stride, tl_mask, n0, B, td, td_stride, out, out_stride, use_timeline);
+    hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, src, n0, B, td, td_stride, out, out_stride);
     return hipGetLastError();
 }
 

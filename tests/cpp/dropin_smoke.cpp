@@ -1,0 +1,57 @@
+// Compiles against the drop-in headers exactly as a caller of the reference would (same includes modulo the
+// directory, same class names and signatures) and, when a GPU is present, runs a tiny 2x2 zero-latency convolution
+// with impulse IRs whose exact answer is known.  Exit codes: 0 ok, 2 no GPU (compile/link check only), 1 wrong result.
+#include "hisstools_amd/Convolver.h"
+#include "hisstools_amd/PartitionedConvolve.h"
+#include "hisstools_amd/TimeDomainConvolve.h"
+#include "hisstools_amd/HISSTools_FFT.h"
+
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+int main()
+{
+    if (hcv_device_count() <= 0)
+    {
+        std::printf("no GPU: link check only\n");
+        return 2;
+    }
+    const uint32_t nin = 2, nout = 2;
+    const size_t L = 20000, S = 3 * 8192;
+    HISSTools::Convolver conv(nin, nout, kLatencyZero);
+    const size_t delay[2][2] = { { 0, 130 }, { 9000, 17000 } };
+    const float gain[2][2] = { { 0.5f, -0.25f }, { 0.75f, 0.6f } };
+    std::vector<float> ir(L, 0.f);
+    for (uint32_t o = 0; o < nout; o++)
+        for (uint32_t i = 0; i < nin; i++)
+        {
+            ir[delay[o][i]] = gain[o][i];
+            if (conv.set(i, o, ir.data(), L, true) != CONVOLVE_ERR_NONE) return 1;
+            ir[delay[o][i]] = 0.f;
+        }
+    if (conv.set(2, 0, ir.data(), L, true) != CONVOLVE_ERR_IN_CHAN_OUT_OF_RANGE) return 1;
+
+    std::vector<std::vector<float>> x(nin, std::vector<float>(S)), y(nout, std::vector<float>(S, 0.f));
+    unsigned s = 12345;
+    for (auto &row : x)
+        for (auto &v : row) { s = s * 1664525u + 1013904223u; v = (float) ((s >> 8) * (1.0 / 16777216.0) * 2.0 - 1.0); }
+
+    for (size_t pos = 0; pos < S; pos += 512)
+    {
+        const float *ins[2] = { x[0].data() + pos, x[1].data() + pos };
+        float *outs[2] = { y[0].data() + pos, y[1].data() + pos };
+        conv.process(ins, outs, nin, nout, 512);
+    }
+    double worst = 0.0;
+    for (uint32_t o = 0; o < nout; o++)
+        for (size_t n = 0; n < S; n++)
+        {
+            double t = 0.0;
+            for (uint32_t i = 0; i < nin; i++)
+                if (n >= delay[o][i]) t += (double) gain[o][i] * x[i][n - delay[o][i]];
+            worst = std::fmax(worst, std::fabs(t - y[o][n]));
+        }
+    std::printf("drop-in Convolver 2x2: max abs error %.3e\n", worst);
+    return worst < 5e-6 ? 0 : 1;
+}

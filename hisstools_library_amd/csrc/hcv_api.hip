@@ -739,13 +739,37 @@ extern "C" const char *hcv_last_error(void) { return tlsError.c_str(); }
 
 static bool fft_size_ok(unsigned log2n)
 {
-    if (log2n < 5 || log2n > (unsigned) hcv::kMaxLdsFFTLog2)
+    if (log2n < 5 || log2n > (unsigned) hcv::kMaxFFTLog2)
     {
-        set_error("hcv_rfft/rifft: log2n must be in [5, 15] in this build");
+        set_error("hcv_rfft/rifft: log2n must be in [5, 20]");
         return false;
     }
     return true;
 }
+
+// scratch + sub-transform tables for one-off transforms above the LDS limit
+struct ScopedBigWork
+{
+    hcv::BigFFTWork w;
+    bool ok = true;
+    ScopedBigWork(int dev, unsigned log2n, size_t batch)
+    {
+        if (!hcv::is_big_fft((int) log2n)) return;
+        int l1, l2;
+        hcv::big_fft_split((int) log2n, l1, l2);
+        std::string err;
+        w.tw1 = hcv::twiddles(dev, l1 + 1, &err);
+        w.tw2 = hcv::twiddles(dev, l2 + 1, &err);
+        w.elems = (size_t(1) << (log2n - 1)) * std::min<size_t>(batch, 16);
+        ok = w.tw1 && w.tw2 && hipMalloc(&w.a, sizeof(float2) * w.elems) == hipSuccess && hipMalloc(&w.b, sizeof(float2) * w.elems) == hipSuccess;
+        if (!ok) set_error(err.empty() ? "big FFT workspace allocation failed" : err);
+    }
+    ~ScopedBigWork()
+    {
+        if (w.a) (void) hipFree(w.a);
+        if (w.b) (void) hipFree(w.b);
+    }
+};
 
 #define HCV_API_TRY(expr)                                                                                              \
     do                                                                                                                 \
@@ -787,7 +811,9 @@ extern "C" int hcv_rfft_f32(const float *in, size_t in_length, size_t in_stride,
     HCV_API_TRY(hipMalloc(&din, sizeof(float) * std::max<size_t>(1, batch * take)));
     if (ok) HCV_API_TRY(hipMalloc(&dout, sizeof(float2) * batch * half));
     if (ok && take) HCV_API_TRY(hipMemcpy(din, packed.data(), sizeof(float) * batch * take, hipMemcpyHostToDevice));
-    if (ok) HCV_API_TRY(hcv::launch_rfft_rows((int) log2n, din, (long long) take, (long long) take, (int) batch, dout, tw, nullptr));
+    ScopedBigWork big(dev, log2n, batch);
+    ok = ok && big.ok;
+    if (ok) HCV_API_TRY(hcv::launch_rfft_rows((int) log2n, din, (long long) take, (long long) take, (int) batch, dout, tw, &big.w, nullptr));
     if (ok) HCV_API_TRY(hipMemcpy(spec.data(), dout, sizeof(float2) * batch * half, hipMemcpyDeviceToHost));
     if (din) (void) hipFree(din);
     if (dout) (void) hipFree(dout);
@@ -827,7 +853,9 @@ extern "C" int hcv_rifft_f32(const float *realp, const float *imagp, size_t batc
     HCV_API_TRY(hipMalloc(&din, sizeof(float2) * batch * half));
     if (ok) HCV_API_TRY(hipMalloc(&dout, sizeof(float) * batch * n));
     if (ok) HCV_API_TRY(hipMemcpy(din, spec.data(), sizeof(float2) * batch * half, hipMemcpyHostToDevice));
-    if (ok) HCV_API_TRY(hcv::launch_rifft_rows((int) log2n, din, (int) batch, dout, tw, nullptr));
+    ScopedBigWork big(dev, log2n, batch);
+    ok = ok && big.ok;
+    if (ok) HCV_API_TRY(hcv::launch_rifft_rows((int) log2n, din, (int) batch, dout, tw, &big.w, nullptr));
     if (ok) HCV_API_TRY(hipMemcpy(out, dout, sizeof(float) * batch * n, hipMemcpyDeviceToHost));
     if (din) (void) hipFree(din);
     if (dout) (void) hipFree(dout);

@@ -82,6 +82,7 @@ struct Engine::Stage
     size_t y_elems = 0;
     float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
     long long tl_len = 0;
+    BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream
     hipEvent_t done = nullptr;
     long long *hv = nullptr;
@@ -169,11 +170,6 @@ bool Engine::init(const EngineCfg &cfg)
             mErr = "invalid FFT size";
             return false;
         }
-        if (l2 > kMaxLdsFFTLog2)
-        {
-            mErr = "FFT sizes above 32768 are not supported by this build";
-            return false;
-        }
         nmax = std::max(nmax, sc.fft_size);
     }
 
@@ -229,7 +225,9 @@ bool Engine::alloc_stage(Stage &st)
     st.R = st.Pcap + st.Tmax;
     const size_t hs_elems = pairs * st.Pcap * st.M;
     const size_t x_elems = (size_t) mCfg.nin * st.R * st.M;
-    st.y_elems = (size_t) std::max<uint32_t>(st.Tmax, 64u) * mCfg.nout * st.M;
+    // room for split-K partials: up to 64 slices for short spectra, fewer as the bin axis alone fills the chip
+    const uint32_t split_cap = std::max<uint32_t>(1, std::min<uint32_t>(64, 2048u / std::max<uint32_t>(1, st.M / 512)));
+    st.y_elems = (size_t) std::max<uint32_t>(st.Tmax, split_cap) * mCfg.nout * st.M;
     HCV_TRY(hipMalloc(&st.Hs, sizeof(float2) * hs_elems));
     HCV_TRY(hipMemset(st.Hs, 0, sizeof(float2) * hs_elems));
     HCV_TRY(hipMalloc(&st.X, sizeof(float2) * x_elems));
@@ -237,6 +235,18 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMalloc(&st.Y, sizeof(float2) * st.y_elems));
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
+    if (is_big_fft(st.log2n))
+    {
+        int l1, l2;
+        big_fft_split(st.log2n, l1, l2);
+        st.big.tw1 = twiddles(mDevice, l1 + 1, &mErr);
+        st.big.tw2 = twiddles(mDevice, l2 + 1, &mErr);
+        if (!st.big.tw1 || !st.big.tw2) return false;
+        const size_t batch = std::min<size_t>(32, (size_t) st.Tmax * std::max(mCfg.nin, mCfg.nout));
+        st.big.elems = batch * st.M;
+        HCV_TRY(hipMalloc(&st.big.a, sizeof(float2) * st.big.elems));
+        HCV_TRY(hipMalloc(&st.big.b, sizeof(float2) * st.big.elems));
+    }
     st.tl_len = pow2ceil((long long) mMaxBlock + st.M);
     HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
     HCV_TRY(hipMemset(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len));
@@ -252,6 +262,9 @@ void Engine::free_stage(Stage &st)
     if (st.Y) (void) hipFree(st.Y);
     if (st.hv) (void) hipFree(st.hv);
     if (st.timeline) (void) hipFree(st.timeline);
+    if (st.big.a) (void) hipFree(st.big.a);
+    if (st.big.b) (void) hipFree(st.big.b);
+    st.big.a = st.big.b = nullptr;
     if (st.done) (void) hipEventDestroy(st.done);
     if (st.stream) (void) hipStreamDestroy(st.stream);
     st.Hs = st.X = st.Y = nullptr;
@@ -425,7 +438,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             if (wr)
             {
                 const float *src = seg ? dsrc + st.cfg.offset : mHist;              // never dereferenced when seg == 0
-                HCV_TRY(launch_rfft_ir(st.log2n, src, (long long) seg, (int) wr, st.Hs + pair * (size_t) st.Pcap * st.M, st.tw, mStream));
+                HCV_TRY(launch_rfft_ir(st.log2n, src, (long long) seg, (int) wr, st.Hs + pair * (size_t) st.Pcap * st.M, st.tw, &st.big, mStream));
             }
             st.pact[pair] = newP;
             st.P = *std::max_element(st.pact.begin(), st.pact.end());
@@ -562,7 +575,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
         hipStream_t ss = st.stream;
         HCV_TRY(hipStreamWaitEvent(ss, mEvInput, 0));
-        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, ss));
+        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, ss));
 
         MacShape sh;
         sh.M = (int) st.M;
@@ -604,7 +617,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
         const long long y_elems = (long long) T * nout_act * st.M;
         HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, ss));
-        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, ss));
+        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, &st.big, ss));
         HCV_TRY(hipEventRecord(st.done, ss));
         HCV_TRY(hipStreamWaitEvent(mStream, st.done, 0));
     }

@@ -9,15 +9,35 @@ namespace hcv
     constexpr int kMaxFFTLog2 = 20;       // PartitionedConvolve.h:19
     constexpr int kMaxLdsFFTLog2 = 15;    // N = 32768 -> 16384 complex points = 128 KiB of the CU's 160 KiB LDS
 
-    // ---- FFT family (tw = N-th roots of unity, N/2 entries) ----
+    // ---- FFT family (tw = N-th roots of unity, N/2 entries).  N <= 32768 runs inside LDS; larger sizes take the
+    //      four-step path of hcv_bigfft.hip and need a BigFFTWork (two scratch buffers + sub-transform tables).
+    struct BigFFTWork
+    {
+        float2 *a = nullptr, *b = nullptr;      // scratch, `elems` float2 each
+        size_t elems = 0;
+        const float2 *tw1 = nullptr, *tw2 = nullptr;   // (2*M1)-th and (2*M2)-th roots for the column / row pieces
+    };
+    inline bool is_big_fft(int log2n) { return log2n > kMaxLdsFFTLog2; }
+    void big_fft_split(int log2n, int &l1, int &l2);      // N/2 = 2^l1 * 2^l2
+
     hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin,
-                                  float2 *X, int R, const float2 *tw, hipStream_t st);
-    hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, hipStream_t st);
+                                  float2 *X, int R, const float2 *tw, const BigFFTWork *big, hipStream_t st);
+    hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork *big, hipStream_t st);
     hipError_t launch_rfft_rows(int log2n, const float *src, long long src_stride, long long in_len, int batch, float2 *dst, const float2 *tw,
-                                hipStream_t st);
-    hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, hipStream_t st);
+                                const BigFFTWork *big, hipStream_t st);
+    hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, const BigFFTWork *big, hipStream_t st);
     hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long long ks_stride, long long h_first, int T, int nout,
-                                        float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, hipStream_t st);
+                                        float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, const BigFFTWork *big,
+                                        hipStream_t st);
+
+    hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,
+                               int R, const float2 *tw, const BigFFTWork &w, hipStream_t st);
+    hipError_t big_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork &w, hipStream_t st);
+    hipError_t big_rfft_rows(int log2n, const float *src, long long src_stride, long long in_len, int batch, float2 *dst, const float2 *tw,
+                             const BigFFTWork &w, hipStream_t st);
+    hipError_t big_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, const BigFFTWork &w, hipStream_t st);
+    hipError_t big_rifft_overlap_add(int log2n, const float2 *Y, long long h_first, int T, int nout, float *timeline, long long tl_stride,
+                                     long long tl_mask, const float2 *tw, const BigFFTWork &w, hipStream_t st);
 
     // ---- spectral multiply-accumulate ----
     struct MacShape

@@ -14,6 +14,7 @@
 // Everything here is written for wave64 / gfx950 only.
 
 #include "hcv_kernels.h"
+#include "hcv_fft_device.h"
 
 #include <hip/hip_runtime.h>
 
@@ -22,135 +23,6 @@
 
 namespace hcv
 {
-
-// ------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
-{
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// 16-byte streaming load that bypasses cache retention (global_load_dwordx4 ... nt)
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 load_nt(const float4 *p)
-{
-    v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
-// tw holds the N-th roots of unity exp(-2*pi*i*m/N) for m in [0, N/2); the second half of the circle
-// is the negated first half.
-template <int LOG2M>
-__device__ __forceinline__ float2 root(const float2 *__restrict__ tw, int m)
-{
-    constexpr int M = 1 << LOG2M;                    // N/2 table entries
-    float2 w = tw[m & (M - 1)];
-    return (m & M) ? make_float2(-w.x, -w.y) : w;
-}
-
-// ------------------------------------------------------------------------------------------------
-// In-LDS complex FFT of M = 2^LOG2M points, forward sign, unnormalised, natural order in and out.
-// Stockham autosort, radix-4 passes plus one radix-2 pass when LOG2M is odd.  TG threads cooperate on one
-// transform; every pass is "read my butterflies into registers / barrier / write results / barrier", so a
-// single M-point LDS buffer suffices (64 KiB at N = 16384).
-// ------------------------------------------------------------------------------------------------
-
-template <int LOG2M, int TG>
-struct LdsFFT
-{
-    static constexpr int M = 1 << LOG2M;
-    static constexpr int NB4 = M / 4;
-    static constexpr int BPT4 = (NB4 + TG - 1) / TG;
-    static constexpr int NB2 = M / 2;
-    static constexpr int BPT2 = (NB2 + TG - 1) / TG;
-
-    __device__ static __forceinline__ void run(float2 *s, int tid, const float2 *__restrict__ tw)
-    {
-        int p = 1;
-#pragma unroll 1
-        for (int pass = 0; pass < LOG2M / 2; pass++, p <<= 2)
-        {
-            float2 u[BPT4][4];
-#pragma unroll
-            for (int b = 0; b < BPT4; b++)
-            {
-                int i = tid + b * TG;
-                if (NB4 % TG == 0 || i < NB4)
-                {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) u[b][r] = s[i + r * NB4];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < BPT4; b++)
-            {
-                int i = tid + b * TG;
-                if (NB4 % TG == 0 || i < NB4)
-                {
-                    int k = i & (p - 1);
-                    int j = ((i - k) << 2) + k;
-                    // twiddle exp(-2 pi i k r / (4p)) = root(k * r * (2M / 4p))
-                    int step = k * ((2 * M) / (4 * p));
-                    float2 u0 = u[b][0];
-                    float2 u1 = cmul(u[b][1], root<LOG2M>(tw, step));
-                    float2 u2 = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
-                    float2 u3 = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
-                    float2 a = make_float2(u0.x + u2.x, u0.y + u2.y);
-                    float2 c = make_float2(u0.x - u2.x, u0.y - u2.y);
-                    float2 e = make_float2(u1.x + u3.x, u1.y + u3.y);
-                    float2 d = make_float2(u1.y - u3.y, u3.x - u1.x);     // -i * (u1 - u3)
-                    s[j] = make_float2(a.x + e.x, a.y + e.y);
-                    s[j + p] = make_float2(c.x + d.x, c.y + d.y);
-                    s[j + 2 * p] = make_float2(a.x - e.x, a.y - e.y);
-                    s[j + 3 * p] = make_float2(c.x - d.x, c.y - d.y);
-                }
-            }
-            __syncthreads();
-        }
-        if (LOG2M & 1)
-        {
-            float2 u[BPT2][2];
-#pragma unroll
-            for (int b = 0; b < BPT2; b++)
-            {
-                int i = tid + b * TG;
-                if (NB2 % TG == 0 || i < NB2)
-                {
-                    u[b][0] = s[i];
-                    u[b][1] = s[i + NB2];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < BPT2; b++)
-            {
-                int i = tid + b * TG;
-                if (NB2 % TG == 0 || i < NB2)
-                {
-                    int k = i & (p - 1);
-                    int j = ((i - k) << 1) + k;
-                    float2 u0 = u[b][0];
-                    float2 u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
-                    s[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-                    s[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
-                }
-            }
-            __syncthreads();
-        }
-    }
-};
-
-// threads cooperating on one transform and transforms per 256-thread workgroup
-template <int LOG2M> struct FFTGeom
-{
-    static constexpr int M = 1 << LOG2M;
-    static constexpr int TG = (M / 4) < 256 ? (M / 4) : 256;
-    static constexpr int G = 256 / TG;
-    static constexpr int THREADS = TG * G;
-};
 
 // Real post-pass of the forward transform (the maths of pass_real_trig_table<false>,
 // HISSTools_FFT_Core.h:934-988): s holds Z = FFT_M(x_even + i x_odd); writes the packed, doubled half
@@ -802,9 +674,10 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
 }
 
 hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin,
-                              float2 *X, int R, const float2 *tw, hipStream_t st)
+                              float2 *X, int R, const float2 *tw, const BigFFTWork *big, hipStream_t st)
 {
     if (T <= 0 || nin <= 0) return hipSuccess;
+    if (is_big_fft(log2n)) return big ? big_rfft_frames(log2n, hist, hist_stride, hist_mask, h_first, T, nin, X, R, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();
@@ -816,9 +689,10 @@ hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_strid
     return hipGetLastError();
 }
 
-hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, hipStream_t st)
+hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork *big, hipStream_t st)
 {
     if (P <= 0) return hipSuccess;
+    if (is_big_fft(log2n)) return big ? big_rfft_ir(log2n, src, count, P, dst, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();
@@ -831,9 +705,10 @@ hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, f
 }
 
 hipError_t launch_rfft_rows(int log2n, const float *src, long long src_stride, long long in_len, int batch, float2 *dst, const float2 *tw,
-                            hipStream_t st)
+                            const BigFFTWork *big, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (is_big_fft(log2n)) return big ? big_rfft_rows(log2n, src, src_stride, in_len, batch, dst, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();
@@ -845,9 +720,10 @@ hipError_t launch_rfft_rows(int log2n, const float *src, long long src_stride, l
     return hipGetLastError();
 }
 
-hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, hipStream_t st)
+hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst, const float2 *tw, const BigFFTWork *big, hipStream_t st)
 {
     if (batch <= 0) return hipSuccess;
+    if (is_big_fft(log2n)) return big ? big_rifft_rows(log2n, src, batch, dst, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();
@@ -860,9 +736,11 @@ hipError_t launch_rifft_rows(int log2n, const float2 *src, int batch, float *dst
 }
 
 hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long long ks_stride, long long h_first, int T, int nout,
-                                    float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, hipStream_t st)
+                                    float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, const BigFFTWork *big, hipStream_t st)
 {
     if (T <= 0 || nout <= 0) return hipSuccess;
+    if (is_big_fft(log2n))      // the caller has already reduced the split-K partials (ksplit == 1)
+        return (big && ksplit == 1) ? big_rifft_overlap_add(log2n, Y, h_first, T, nout, timeline, tl_stride, tl_mask, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();

@@ -37,7 +37,7 @@ def truth_conv(x, h, latency=0):
 
 # ------------------------------------------------------------------------------------------- FFT (K2/K3)
 
-@pytest.mark.parametrize("l2", list(range(5, 16)))
+@pytest.mark.parametrize("l2", list(range(5, 21)))
 def test_rfft_rifft_vs_oracle(H, oracle, l2):
     n = 1 << l2
     x = np.stack([oracle.synth_audio(40 + b, n) for b in range(3)])
@@ -135,7 +135,8 @@ def test_golden_convolver(H, golden):
 
 @pytest.mark.parametrize("N,L,S,block", [
     (32, 200, 1500, 64), (64, 1000, 3000, [5, 300, 17]), (256, 5000, 12000, 512), (1024, 20000, 30000, 2048),
-    (4096, 48000, 40000, 4096), (16384, 48000, 70000, 8192), (32768, 70000, 100000, 5000)])
+    (4096, 48000, 40000, 4096), (16384, 48000, 70000, 8192), (32768, 70000, 100000, 5000),
+    (65536, 150000, 250000, 16384), (1 << 18, 300000, 700000, 30000), (1 << 20, 600000, 1700000, 32768)])
 def test_partitioned_vs_oracle(H, oracle, N, L, S, block):
     h, x = oracle.synth_ir(1, 2, L), oracle.synth_audio(3, S)
     ref = oracle.PartitionedConvolve(N, L, 0, 0)
@@ -207,6 +208,36 @@ def test_mono_single_stage_config1(H, oracle):
     gpu = H.MonoConvolve(48000, zeroLatency=False, A=16384)
     assert gpu.set(h, False) == 0
     assert rel_err(gpu.run(x, 2048), ref.run(x, 2048)) < TOL
+
+
+def test_mono_custom_large_fft_stage(H, oracle):
+    # custom partitioning with a four-step-FFT tail: MonoConvolve(L, false, 256, 4096, 131072)
+    h, x = oracle.synth_ir(2, 2, 200000), oracle.synth_audio(4, 330000)
+    ref = oracle.MonoConvolve(200000, zeroLatency=False, A=256, B=4096, C_=131072)
+    ref.setResetOffset(0)
+    assert ref.set(h, False) == 0
+    gpu = H.MonoConvolve(200000, zeroLatency=False, A=256, B=4096, C_=131072)
+    assert gpu.set(h, False) == 0
+    y = gpu.run(x, 8192)
+    assert rel_err(y, ref.run(x, 2048)) < TOL_SUM
+    assert rel_err(y, truth_conv(x, h, 128)) < TOL_SUM
+
+
+def test_zero_latency_with_fewer_than_four_sizes_keeps_the_head(H, oracle):
+    """Reference defect (not reproduced): with zeroLatency and fewer than four FFT sizes mPart1 is null, so
+    processAndSum(mPart2, ..., accumulate || mPart1) OVERWRITES the time-domain head's output
+    (MonoConvolve.cpp:195-197) and the first A/2 taps of the IR are lost.  The engine sums all stages."""
+    h, x = oracle.synth_ir(2, 2, 30000), oracle.synth_audio(4, 50000)
+    gpu = H.MonoConvolve(30000, zeroLatency=True, A=256, B=4096, C_=16384)
+    assert gpu.set(h, False) == 0
+    y = gpu.run(x, 2048)
+    assert rel_err(y, truth_conv(x, h)) < TOL
+    ref = oracle.MonoConvolve(30000, zeroLatency=True, A=256, B=4096, C_=16384)
+    ref.setResetOffset(0)
+    ref.set(h, False)
+    y_ref = ref.run(x, 2048)
+    head_only = truth_conv(x, np.concatenate([h[:128], np.zeros(h.size - 128, np.float32)]))
+    assert rel_err(y_ref + head_only, truth_conv(x, h)) < TOL     # the reference is missing exactly the head
 
 
 def test_mono_impulse_is_exact(H):

@@ -115,3 +115,24 @@ def test_synth_generator_is_mt19937(oracle):
     raw = bg.random_raw(1000).astype(np.uint64)
     expect = (2.0 * ((raw >> np.uint64(8)).astype(np.float64) / 16777216.0) - 1.0).astype(np.float32)
     assert np.array_equal(oracle.synth_audio(5, 1000), expect)
+
+
+def test_reference_defect_zero_latency_three_sizes_is_restated(oracle):
+    """MonoConvolve(zeroLatency, A, B, C): mPart1 is null so part2 overwrites the head's output
+    (MonoConvolve.cpp:195-197).  The oracle restates the reference bug-for-bug (and is bit-identical to it where the
+    compiled reference is available); the HIP engine deliberately does not reproduce it."""
+    from scipy.signal import fftconvolve
+    h, x = oracle.synth_ir(2, 2, 9000), oracle.synth_audio(4, 12000)
+    m = oracle.MonoConvolve(9000, zeroLatency=True, A=256, B=1024, C_=4096)
+    m.setResetOffset(0)
+    assert m.set(h, False) == 0
+    y = m.run(x, 512)
+    truth = fftconvolve(x.astype(np.float64), h.astype(np.float64))[: x.size]
+    head = fftconvolve(x.astype(np.float64), h[:128].astype(np.float64))[: x.size]
+    assert rel_err(y, truth) > 1e-3
+    assert rel_err(y + head, truth) < 2e-6
+    if oracle.have_ref():
+        r = oracle.MonoConvolve(9000, zeroLatency=True, A=256, B=1024, C_=4096, backend="ref")
+        r.setResetOffset(0)
+        r.set(h, False)
+        assert np.array_equal(r.run(x, 512), y)

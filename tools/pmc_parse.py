@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Turn the PMC passes of tools/pmc_traffic.sh into profiles/traffic_<workload>.json (read by bench.py).
+
+HBM bytes per launch of the tail spectral_mac = FETCH_SIZE[KB] * 1024 * fetch_factor + WRITE_SIZE[KB] * 1024 * write_factor,
+with the factors calibrated in the same run on a 1 GiB float4-coalesced copy (MI355X_MICROARCH.md §HBM: on gfx950
+FETCH_SIZE reports half the bytes of a wide coalesced stream)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+w = sys.argv[1]
+src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/pmc_{w}"
+GiB = 1 << 30
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[(re.sub(r"\(.*", "", r["Kernel_Name"]), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return agg
+
+
+out = {"workload": w, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/pmc_traffic.sh)"}
+factors = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    cal = load(f"{src}/calib_{c}/run_counter_collection.csv")
+    v = [x for (name, grid), vals in cal.items() if "copyBuffer" in name for x in vals]
+    kb = sum(v) / len(v)
+    factors[c] = GiB / (kb * 1024.0)
+    out[f"calibration_{c}"] = {"known_bytes": GiB, "counter_kb": kb, "factor": round(factors[c], 4)}
+tail = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    run = load(f"{src}/{c}/run_counter_collection.csv")
+    # the steady-state tail launch: unpredicated spectral_mac (CHECK = false) with the largest grid
+    cand = {k: v for k, v in run.items() if "spectral_mac_kernel" in k[0] and ", false," in k[0]}
+    key = max(cand, key=lambda k: (sum(cand[k]) / len(cand[k])))
+    tail[c] = sum(cand[key]) / len(cand[key])
+    out[f"{c}_kb_per_launch"] = tail[c]
+    out["kernel"] = key[0].replace("void ", "")
+    out["launches_sampled"] = len(cand[key])
+out["hbm_read_bytes_per_launch"] = int(tail["FETCH_SIZE"] * 1024 * factors["FETCH_SIZE"])
+out["hbm_write_bytes_per_launch"] = int(tail["WRITE_SIZE"] * 1024 * factors["WRITE_SIZE"])
+out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+json.dump(out, open(f"profiles/traffic_{w}.json", "w"), indent=1)
+print(json.dumps(out, indent=1))

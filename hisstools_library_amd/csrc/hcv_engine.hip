@@ -561,8 +561,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
     EmitSources src;
     src.count = 0;
-    for (size_t si = 0; si < mStages.size(); si++)
+    // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
+    static const bool tail_first = !std::getenv("HCV_TAIL_LAST");
+    for (size_t sj = 0; sj < mStages.size(); sj++)
     {
+        const size_t si = tail_first ? mStages.size() - 1 - sj : sj;
         Stage &st = *mStages[si];
         src.timeline[src.count] = st.timeline;              // the ring may still hold hops of earlier calls
         src.stride[src.count] = st.tl_len;

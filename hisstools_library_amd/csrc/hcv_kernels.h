@@ -53,9 +53,11 @@ namespace hcv
     };
     struct MacPlan
     {
-        int ot, bx, by, binblocks, outtiles, ksplit, kper;
+        int ot, tt;                 // register tile: outputs x hops per thread
+        int bx, by, tz;             // threads along bins, hop tiles per workgroup, hop-tile blocks
+        int binblocks, outtiles, ksplit, kper;
+        int nt;                     // stream H with nontemporal loads
     };
-    int mac_out_tile(int nout, int diag);
     void mac_plan(const MacShape &s, MacPlan &pl);
     hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st);
     hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,

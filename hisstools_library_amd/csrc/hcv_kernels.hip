@@ -270,178 +270,6 @@ __global__ __launch_bounds__(256) void rifft_rows_kernel(const float2 *__restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K1: spectral multiply-accumulate — the HBM-bound roofline kernel.
-//
-//   Y[ks][t][o][b] = sum over k = (i, p) in this block's k-slice of  X[i][(h - p) mod R][b] * H[o][i][p][b]
-//
-// Thread = two bins (one dwordx4 of X, OT dwordx4 of H per k), OT outputs share the X value in registers, so X
-// traffic is 1/OT of H traffic.  H is streamed exactly once per hop with 16-byte coalesced loads; the reduction
-// over (i, p) stays in registers; large reductions are split over blockIdx (split-K) and summed by the inverse
-// FFT kernel's prologue.  For short FFTs (few bins) the spare threads of the workgroup take k-sub-slices
-// (blockDim.y) and are reduced through LDS.
-//
-// bin 0 carries (DC, Nyquist) and needs two real products instead of a complex one
-// (PartitionedConvolve.cpp:398-406, 424-425): the one lane that owns bin 0 tracks the Nyquist products in a
-// side accumulator and repairs its bin after the loop.
-//
-// hv[o][i] is the first hop whose input a pair may see (per-pair reset); CHECK=false is the steady state
-// where every pair sees all P partitions.
-// ------------------------------------------------------------------------------------------------
-
-struct MacParams
-{
-    const float4 *X;        // [nin][R][M/2] float4
-    const float4 *H;        // [nout][nin_alloc][Pcap][M/2] float4
-    float4 *Y;              // [ksplit][T][nout][M/2] float4
-    const long long *hv;    // [nout][nin_alloc]
-    long long h_first;
-    int M2;                 // float4 per spectrum = M/2
-    int R, P, Pcap;
-    int nin, nin_alloc, nout;
-    int diag;               // parallel mode: output o reads input o only (nin == 1 logically)
-    int ksplit, kper;       // k-slices over blockIdx.x and their length
-    int binblocks;
-    long long ks_stride4;   // float4 stride between k-slices of Y
-};
-
-template <int OT, bool CHECK, bool NT>
-__global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 red[];
-
-    const int bb = blockIdx.x % a.binblocks;
-    const int ks = blockIdx.x / a.binblocks;
-    const int o0 = blockIdx.y * OT;
-    const int t = blockIdx.z;
-    const long long h = a.h_first + t;
-    const int hmod = (int) (h % a.R);
-
-    const int b4 = bb * blockDim.x + threadIdx.x;       // float4 index inside the spectrum
-    const bool binlive = b4 < a.M2;
-    const int b4c = binlive ? b4 : 0;
-    const bool owns_bin0 = (b4 == 0);
-
-    // this block's k-slice [kb0, kb1) of the flattened (i, p) reduction
-    const int K = a.nin * a.P;
-    const int kb0 = ks * a.kper;
-    const int kb1 = min(K, kb0 + a.kper);
-
-    float4 acc[OT];
-    float ny[OT];                                       // bin 0 only: sum of the Nyquist products x.y * h.y
-#pragma unroll
-    for (int j = 0; j < OT; j++)
-    {
-        acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ny[j] = 0.f;
-    }
-
-    const long long pair_stride4 = (long long) a.Pcap * a.M2;
-    const long long out_stride4 = (long long) a.nin_alloc * pair_stride4;
-
-    // per-output base pointers (clamped: dead outputs of a ragged last tile re-read the last live one)
-    const float4 *hbase[OT];
-#pragma unroll
-    for (int j = 0; j < OT; j++) hbase[j] = a.H + (long long) min(o0 + j, a.nout - 1) * out_stride4 + b4c;
-
-    if (kb0 < kb1)
-    {
-        const int i_first = kb0 / a.P, i_last = (kb1 - 1) / a.P;
-        for (int i = i_first; i <= i_last; i++)
-        {
-            const int pa = (i == i_first) ? kb0 - i_first * a.P : 0;
-            const int pb = (i == i_last) ? kb1 - i_last * a.P : a.P;
-
-            int lim[OT];
-            if (CHECK)
-            {
-#pragma unroll
-                for (int j = 0; j < OT; j++)
-                {
-                    long long d = h - a.hv[(long long) min(o0 + j, a.nout - 1) * a.nin_alloc + i];
-                    lim[j] = d > 0x3fffffff ? 0x3fffffff : (d < -1 ? -1 : (int) d);
-                }
-            }
-
-            const float4 *xrow = a.X + (long long) (a.diag ? 0 : i) * a.R * a.M2 + b4c;
-            const long long hoff_i = (long long) i * pair_stride4;
-
-#pragma unroll 2
-            for (int p = pa + (int) threadIdx.y; p < pb; p += (int) blockDim.y)
-            {
-                int slot = hmod - p;
-                if (slot < 0) slot += a.R;
-
-                float4 hval[OT];
-                const long long hoff = hoff_i + (long long) p * a.M2;
-#pragma unroll
-                for (int j = 0; j < OT; j++) hval[j] = NT ? load_nt(hbase[j] + hoff) : hbase[j][hoff];
-
-                float4 x;
-                if (!a.diag) x = xrow[(long long) slot * a.M2];
-
-#pragma unroll
-                for (int j = 0; j < OT; j++)
-                {
-                    if (a.diag) x = xrow[((long long) min(o0 + j, a.nout - 1) * a.R + slot) * a.M2];
-                    bool ok = true;
-                    if (CHECK) ok = p <= lim[j];
-                    if (ok)
-                    {
-                        const float4 hh = hval[j];
-                        acc[j].x += x.x * hh.x - x.y * hh.y;
-                        acc[j].y += x.x * hh.y + x.y * hh.x;
-                        acc[j].z += x.z * hh.z - x.w * hh.w;
-                        acc[j].w += x.z * hh.w + x.w * hh.z;
-                        if (owns_bin0) ny[j] += x.y * hh.y;
-                    }
-                }
-            }
-        }
-    }
-
-    if (owns_bin0)
-    {
-#pragma unroll
-        for (int j = 0; j < OT; j++)
-        {
-            acc[j].x += ny[j];                          // sum(x.x*h.x - x.y*h.y) + sum(x.y*h.y) = DC products
-            acc[j].y = ny[j];                           // Nyquist products
-        }
-    }
-
-    // reduce the k-lanes (threadIdx.y) through LDS
-    if (blockDim.y > 1)
-    {
-        const int nx = blockDim.x;
-#pragma unroll
-        for (int j = 0; j < OT; j++)
-        {
-            __syncthreads();
-            red[threadIdx.y * nx + threadIdx.x] = acc[j];
-            __syncthreads();
-            if (threadIdx.y == 0)
-            {
-                float4 s = red[threadIdx.x];
-                for (int y = 1; y < (int) blockDim.y; y++)
-                {
-                    float4 v = red[y * nx + threadIdx.x];
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-                }
-                acc[j] = s;
-            }
-        }
-    }
-
-    if (threadIdx.y == 0 && binlive)
-    {
-        float4 *y = a.Y + (long long) ks * a.ks_stride4 + ((long long) t * a.nout) * a.M2 + b4;
-#pragma unroll
-        for (int j = 0; j < OT; j++)
-            if (o0 + j < a.nout) y[(long long) (o0 + j) * a.M2] = acc[j];
-    }
-}
-
 // Split-K epilogue: Y[0][e] = sum_ks Y[ks][e].  One float4 per thread, the ksplit strided loads of a thread are
 // independent (issued back to back), neighbouring threads are contiguous: a plain coalesced streaming reduction.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict__ Y, int ksplit, long long ks_stride4, long long n4)
@@ -751,99 +579,6 @@ hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long
                            tl_stride, tl_mask, tw);
     });
     return hipGetLastError();
-}
-
-// choose OT: largest tile not exceeding the live outputs (diag mode cannot share X between outputs)
-int mac_out_tile(int nout, int diag)
-{
-    if (diag) return 1;
-    if (nout >= 16) return 16;
-    if (nout >= 8) return 8;
-    if (nout >= 4) return 4;
-    if (nout >= 2) return 2;
-    return 1;
-}
-
-static int env_int(const char *name, int dflt)
-{
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
-
-void mac_plan(const MacShape &s, MacPlan &pl)
-{
-    // tuning knobs (read once): HCV_MAC_BLOCKS = workgroups to aim for, HCV_MAC_OT = cap on the output tile
-    static const int target_blocks = env_int("HCV_MAC_BLOCKS", 512);
-    static const int ot_cap = env_int("HCV_MAC_OT", 8);
-    const int M2 = s.M / 2;
-    pl.ot = mac_out_tile(s.nout, s.diag);
-    while (pl.ot > ot_cap && pl.ot > 1) pl.ot >>= 1;
-    pl.bx = M2 < 256 ? M2 : 256;
-    pl.by = 256 / pl.bx;
-    pl.binblocks = (M2 + pl.bx - 1) / pl.bx;
-    pl.outtiles = (s.nout + pl.ot - 1) / pl.ot;
-    const long long K = (long long) (s.diag ? 1 : s.nin) * s.P;
-    long long base = (long long) pl.binblocks * pl.outtiles * s.T;
-    // aim for >= ~8 workgroups per CU across the chip, but keep every k-slice at least 8*by long
-    long long want = (target_blocks + base - 1) / base;
-    long long maxsplit = K / (8LL * pl.by);
-    if (maxsplit < 1) maxsplit = 1;
-    if (want > maxsplit) want = maxsplit;
-    if (want < 1) want = 1;
-    if (s.max_ksplit > 0 && want > s.max_ksplit) want = s.max_ksplit;
-    pl.kper = (int) ((K + want - 1) / want);
-    pl.ksplit = (int) ((K + pl.kper - 1) / pl.kper);
-    if (pl.ksplit < 1) pl.ksplit = 1;
-}
-
-template <int OT>
-static hipError_t launch_mac_ot(const MacParams &a, const MacPlan &pl, int T, bool check, hipStream_t st)
-{
-    dim3 grid(pl.binblocks * pl.ksplit, pl.outtiles, T);
-    dim3 block(pl.bx, pl.by);
-    size_t lds = pl.by > 1 ? sizeof(float4) * 256 : 0;
-    // H is streamed exactly once per launch when there is a single hop: keep it out of the caches (X stays resident)
-    static const int nt_mode = env_int("HCV_MAC_NT", 2);
-    const bool nt = nt_mode == 1 || (nt_mode == 2 && T == 1);
-    if (check)
-        hipLaunchKernelGGL((spectral_mac_kernel<OT, true, false>), grid, block, lds, st, a);
-    else if (nt)
-        hipLaunchKernelGGL((spectral_mac_kernel<OT, false, true>), grid, block, lds, st, a);
-    else
-        hipLaunchKernelGGL((spectral_mac_kernel<OT, false, false>), grid, block, lds, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
-                               long long h_first, bool check, hipStream_t st)
-{
-    if (s.T <= 0 || s.nout <= 0) return hipSuccess;
-    MacParams a;
-    a.X = reinterpret_cast<const float4 *>(X);
-    a.H = reinterpret_cast<const float4 *>(H);
-    a.Y = reinterpret_cast<float4 *>(Y);
-    a.hv = hv;
-    a.h_first = h_first;
-    a.M2 = s.M / 2;
-    a.R = s.R;
-    a.P = s.P;
-    a.Pcap = s.Pcap;
-    a.nin = s.diag ? 1 : s.nin;
-    a.nin_alloc = s.nin_alloc;
-    a.nout = s.nout;
-    a.diag = s.diag;
-    a.ksplit = pl.ksplit;
-    a.kper = pl.kper;
-    a.binblocks = pl.binblocks;
-    a.ks_stride4 = (long long) s.T * s.nout * (s.M / 2);
-    switch (pl.ot)
-    {
-        case 16: return launch_mac_ot<16>(a, pl, s.T, check, st);
-        case 8: return launch_mac_ot<8>(a, pl, s.T, check, st);
-        case 4: return launch_mac_ot<4>(a, pl, s.T, check, st);
-        case 2: return launch_mac_ot<2>(a, pl, s.T, check, st);
-        default: return launch_mac_ot<1>(a, pl, s.T, check, st);
-    }
 }
 
 hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st)

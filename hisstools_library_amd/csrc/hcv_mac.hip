@@ -1,0 +1,322 @@
+// K1: spectral multiply-accumulate — the HBM-bound roofline kernel of the partitioned convolution.
+//
+//   Y[ks][t][o][b] = sum over (i, p) in this block's k-slice of  X[i][(h_t - p) mod R][b] * H[o][i][p][b],   h_t = h_first + t
+//
+// replaces PartitionedConvolve::processPartition (PartitionedConvolve.cpp:387-426) called P times per hop per
+// (in,out) pair, plus the accumulation over inputs that NToMonoConvolve::process does in the time domain
+// (NToMonoConvolve.cpp:39-42).
+//
+// Register tile per thread:  2 bins (one 16-byte load)  x  OT outputs  x  TT hops.
+//   * the OT outputs share the input spectrum X in registers  -> X traffic is 1/OT of H traffic
+//   * the TT hops share the IR spectrum H in registers        -> when a process() call spans several hops of a stage
+//     (short stages, or batched/offline calls) H is read once per TT hops.  Along p the X operands of consecutive
+//     hops form a sliding window (hop t at partition p needs spectrum h_t - p), so each p step loads ONE new X
+//     value and shifts the window — an FIR over the hop axis.
+//   * H is streamed with nontemporal 16-byte loads when every element is used once per launch, keeping the caches
+//     for X.
+// The reduction over (input, partition) stays in registers; long reductions are split over blockIdx.x (split-K,
+// summed by reduce_partials_kernel).  For short spectra (< 256 float4 per spectrum) the spare threads of the
+// workgroup (threadIdx.y) take further hop tiles.
+//
+// bin 0 carries (DC, Nyquist) and needs two real products instead of a complex one
+// (PartitionedConvolve.cpp:398-406, 424-425): the one lane that owns bin 0 tracks the Nyquist products in a side
+// accumulator and repairs its bin after the loop.
+//
+// hv[o][i] is the first hop whose input a pair may see (per-pair reset); CHECK=false is the steady state where
+// every pair sees all P partitions.
+
+#include "hcv_kernels.h"
+#include "hcv_fft_device.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+#ifndef HCV_MAC_UNROLL
+#define HCV_MAC_UNROLL 1
+#endif
+
+namespace hcv
+{
+
+struct MacParams
+{
+    const float4 *X;        // [nin][R][M/2] float4
+    const float4 *H;        // [nout][nin_alloc][Pcap][M/2] float4
+    float4 *Y;              // [ksplit][T][nout][M/2] float4
+    const long long *hv;    // [nout][nin_alloc]
+    long long h_first;
+    int M2;                 // float4 per spectrum = M/2
+    int R, P, Pcap, T;
+    int nin, nin_alloc, nout;
+    int diag;               // parallel mode: output o reads input o only (nin == 1 logically)
+    int ksplit, kper;       // k-slices over blockIdx.x and their length
+    int binblocks;
+    long long ks_stride4;   // float4 stride between k-slices of Y
+};
+
+__device__ __forceinline__ void cmac2(float4 &acc, const float4 &x, const float4 &h)
+{
+    acc.x += x.x * h.x - x.y * h.y;
+    acc.y += x.x * h.y + x.y * h.x;
+    acc.z += x.z * h.z - x.w * h.w;
+    acc.w += x.z * h.w + x.w * h.z;
+}
+
+template <int OT, int TT, bool CHECK, bool NT>
+__global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
+{
+    const int bb = blockIdx.x % a.binblocks;
+    const int ks = blockIdx.x / a.binblocks;
+    const int o0 = blockIdx.y * OT;
+    const int tile = blockIdx.z * blockDim.y + threadIdx.y;      // hop tile of this thread row
+    const bool tile_live = tile * TT < a.T;
+    const int t0 = tile_live ? tile * TT : 0;
+    const int live_t = min(TT, a.T - t0);                        // hops of the tile that exist
+    const long long h0 = a.h_first + t0;
+    const int hmod = (int) (h0 % a.R);
+
+    const int b4 = bb * blockDim.x + threadIdx.x;                // float4 index inside the spectrum
+    const bool binlive = b4 < a.M2;
+    const int b4c = binlive ? b4 : 0;
+    const bool owns_bin0 = (b4 == 0);
+
+    // this block's k-slice [kb0, kb1) of the flattened (i, p) reduction
+    const int K = a.nin * a.P;
+    const int kb0 = ks * a.kper;
+    const int kb1 = min(K, kb0 + a.kper);
+
+    float4 acc[TT][OT];
+    float ny[TT][OT];                                            // bin 0 only: sum of the Nyquist products x.y * h.y
+#pragma unroll
+    for (int t = 0; t < TT; t++)
+#pragma unroll
+        for (int j = 0; j < OT; j++)
+        {
+            acc[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ny[t][j] = 0.f;
+        }
+
+    const long long pair_stride4 = (long long) a.Pcap * a.M2;
+    const long long out_stride4 = (long long) a.nin_alloc * pair_stride4;
+
+
+    if (kb0 < kb1)
+    {
+        const int i_first = kb0 / a.P, i_last = (kb1 - 1) / a.P;
+        for (int i = i_first; i <= i_last; i++)
+        {
+            const int pa = (i == i_first) ? kb0 - i_first * a.P : 0;
+            const int pb = (i == i_last) ? kb1 - i_last * a.P : a.P;
+
+            int lim[OT];
+            if (CHECK)
+            {
+#pragma unroll
+                for (int j = 0; j < OT; j++)
+                {
+                    long long d = h0 - a.hv[(long long) min(o0 + j, a.nout - 1) * a.nin_alloc + i];
+                    lim[j] = d > 0x3fffffff ? 0x3fffffff : (d < -0x3fffffff ? -0x3fffffff : (int) d);
+                }
+            }
+
+            // diag (parallel) mode runs with OT == 1: the input row is the output's own
+            const float4 *xrow = a.X + (long long) (a.diag ? min(o0, a.nout - 1) : i) * a.R * a.M2;
+            // wave-uniform 64-bit bases per (output, input); the per-lane part of every address is a 32-bit offset
+            // (one pair's spectra and one input's ring are far below 2^32 float4).  Dead outputs of a ragged last
+            // tile re-read the last live one.
+            const float4 *hrow[OT];
+#pragma unroll
+            for (int j = 0; j < OT; j++) hrow[j] = a.H + (long long) min(o0 + j, a.nout - 1) * out_stride4 + (long long) i * pair_stride4;
+
+            // sliding window over the hop axis: xw[t] = X[h0 + t - p]
+            float4 xw[TT];
+            if (TT > 1)
+            {
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+                {
+                    int slot = hmod + min(t, live_t - 1) - pa;
+                    if (slot < 0) slot += a.R;
+                    if (slot >= a.R) slot -= a.R;
+                    xw[t] = xrow[(unsigned) slot * (unsigned) a.M2 + (unsigned) b4c];
+                }
+            }
+
+#pragma unroll HCV_MAC_UNROLL
+            for (int p = pa; p < pb; p++)
+            {
+                float4 hval[OT];
+                const unsigned hoff = (unsigned) p * (unsigned) a.M2 + (unsigned) b4c;
+#pragma unroll
+                for (int j = 0; j < OT; j++) hval[j] = NT ? load_nt(hrow[j] + hoff) : hrow[j][hoff];
+
+                float4 xn;
+                {
+                    int slot = hmod - p - (TT > 1 ? 1 : 0);      // TT > 1: the hop the window gains at p + 1
+                    if (slot < 0) slot += a.R;
+                    xn = xrow[(unsigned) slot * (unsigned) a.M2 + (unsigned) b4c];
+                }
+                if (TT == 1) xw[0] = xn;
+
+#pragma unroll
+                for (int t = 0; t < TT; t++)
+#pragma unroll
+                    for (int j = 0; j < OT; j++)
+                    {
+                        bool ok = true;
+                        if (CHECK) ok = p <= lim[j] + t;
+                        if (ok)
+                        {
+                            cmac2(acc[t][j], xw[t], hval[j]);
+                            if (owns_bin0) ny[t][j] += xw[t].y * hval[j].y;
+                        }
+                    }
+
+                if (TT > 1)
+                {
+#pragma unroll
+                    for (int t = TT - 1; t > 0; t--) xw[t] = xw[t - 1];
+                    xw[0] = xn;
+                }
+            }
+        }
+    }
+
+    if (owns_bin0)
+    {
+#pragma unroll
+        for (int t = 0; t < TT; t++)
+#pragma unroll
+            for (int j = 0; j < OT; j++)
+            {
+                acc[t][j].x += ny[t][j];                        // sum(x.x*h.x - x.y*h.y) + sum(x.y*h.y) = DC products
+                acc[t][j].y = ny[t][j];                         // Nyquist products
+            }
+    }
+
+    if (tile_live && binlive)
+    {
+        float4 *y = a.Y + (long long) ks * a.ks_stride4 + b4;
+#pragma unroll
+        for (int t = 0; t < TT; t++)
+            if (t < live_t)
+            {
+#pragma unroll
+                for (int j = 0; j < OT; j++)
+                    if (o0 + j < a.nout) y[((long long) (t0 + t) * a.nout + (o0 + j)) * a.M2] = acc[t][j];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launch plan
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
+void mac_plan(const MacShape &s, MacPlan &pl)
+{
+    // tuning knobs (read once): HCV_MAC_BLOCKS = workgroups to aim for, HCV_MAC_OT / HCV_MAC_TT = caps on the tile
+    static const int target_blocks = env_int("HCV_MAC_BLOCKS", 768);
+    static const int ot_cap = env_int("HCV_MAC_OT", 8);
+    static const int tt_env = env_int("HCV_MAC_TT", 0);
+    // hop tiling pays through H reuse on long reductions; the short head stages run leaner (fewer registers, so they
+    // co-reside with the tail's workgroups)
+    const int tt_cap = tt_env > 0 ? tt_env : (s.P >= 32 ? 8 : 4);
+    const int M2 = s.M / 2;
+
+    int tt = 1;
+    while (tt * 2 <= s.T && tt * 2 <= tt_cap) tt *= 2;
+    pl.tt = tt;
+
+    int ot;
+    if (s.diag)
+        ot = 1;
+    else if (tt == 1)
+        ot = s.nout >= 8 ? 8 : s.nout >= 4 ? 4 : s.nout >= 2 ? 2 : 1;
+    else
+        ot = s.nout >= 3 ? 4 : 1;                              // TT > 1 kernels exist for OT in {1, 4}
+    while (ot > ot_cap && ot > 1) ot >>= 1;
+    if (tt > 1 && ot == 2) ot = 1;
+    pl.ot = ot;
+
+    pl.bx = M2 < 256 ? M2 : 256;
+    const int tiles = (s.T + tt - 1) / tt;
+    pl.by = std::max(1, std::min(256 / pl.bx, tiles));
+    pl.tz = (tiles + pl.by - 1) / pl.by;
+    pl.binblocks = (M2 + pl.bx - 1) / pl.bx;
+    pl.outtiles = (s.nout + pl.ot - 1) / pl.ot;
+
+    const long long K = (long long) (s.diag ? 1 : s.nin) * s.P;
+    const long long base = (long long) pl.binblocks * pl.outtiles * pl.tz;
+    long long want = (target_blocks + base - 1) / base;
+    long long maxsplit = K / 8;                                 // keep every k-slice at least 8 long
+    if (maxsplit < 1) maxsplit = 1;
+    if (want > maxsplit) want = maxsplit;
+    if (want < 1) want = 1;
+    if (s.max_ksplit > 0 && want > s.max_ksplit) want = s.max_ksplit;
+    pl.kper = (int) ((K + want - 1) / want);
+    pl.ksplit = (int) ((K + pl.kper - 1) / pl.kper);
+    if (pl.ksplit < 1) pl.ksplit = 1;
+    // every H element is read exactly once per launch when a single hop tile covers the call: stream it
+    static const int nt_mode = env_int("HCV_MAC_NT", 2);
+    pl.nt = (nt_mode == 1 || (nt_mode == 2 && tiles == 1)) ? 1 : 0;
+}
+
+template <int OT, int TT>
+static hipError_t launch_mac_tile(const MacParams &a, const MacPlan &pl, bool check, hipStream_t st)
+{
+    dim3 grid(pl.binblocks * pl.ksplit, pl.outtiles, pl.tz);
+    dim3 block(pl.bx, pl.by);
+    if (check)
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, true, false>), grid, block, 0, st, a);
+    else if (pl.nt)
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, false>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
+                               long long h_first, bool check, hipStream_t st)
+{
+    if (s.T <= 0 || s.nout <= 0) return hipSuccess;
+    MacParams a;
+    a.X = reinterpret_cast<const float4 *>(X);
+    a.H = reinterpret_cast<const float4 *>(H);
+    a.Y = reinterpret_cast<float4 *>(Y);
+    a.hv = hv;
+    a.h_first = h_first;
+    a.M2 = s.M / 2;
+    a.R = s.R;
+    a.P = s.P;
+    a.Pcap = s.Pcap;
+    a.T = s.T;
+    a.nin = s.diag ? 1 : s.nin;
+    a.nin_alloc = s.nin_alloc;
+    a.nout = s.nout;
+    a.diag = s.diag;
+    a.ksplit = pl.ksplit;
+    a.kper = pl.kper;
+    a.binblocks = pl.binblocks;
+    a.ks_stride4 = (long long) s.T * s.nout * (s.M / 2);
+    const int key = pl.ot * 16 + pl.tt;
+    switch (key)
+    {
+        case 8 * 16 + 1: return launch_mac_tile<8, 1>(a, pl, check, st);
+        case 4 * 16 + 1: return launch_mac_tile<4, 1>(a, pl, check, st);
+        case 2 * 16 + 1: return launch_mac_tile<2, 1>(a, pl, check, st);
+        case 1 * 16 + 1: return launch_mac_tile<1, 1>(a, pl, check, st);
+        case 4 * 16 + 2: return launch_mac_tile<4, 2>(a, pl, check, st);
+        case 1 * 16 + 2: return launch_mac_tile<1, 2>(a, pl, check, st);
+        case 4 * 16 + 4: return launch_mac_tile<4, 4>(a, pl, check, st);
+        case 1 * 16 + 4: return launch_mac_tile<1, 4>(a, pl, check, st);
+        case 4 * 16 + 8: return launch_mac_tile<4, 8>(a, pl, check, st);
+        case 1 * 16 + 8: return launch_mac_tile<1, 8>(a, pl, check, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace hcv

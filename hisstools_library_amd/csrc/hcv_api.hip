@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -276,6 +277,7 @@ namespace
         std::vector<uint64_t> mLength, part4Size;
         std::vector<uint8_t> part4Alloc;
         intptr_t resetOffset = -1;
+        mutable std::mutex stateMutex;      // per-pair bookkeeping is written by set/resize (control thread) and read by process
 
         size_t pair(uint32_t in, uint32_t out) const { return (size_t) out * (diag ? 1 : nin) + (diag ? 0 : in); }
         size_t tail() const { return layout.fixedStages.size(); }
@@ -335,11 +337,16 @@ namespace
             }
         }
 
-        bool active(size_t p) const { return mLength[p] && mLength[p] <= part4Size[p]; }
+        bool active(size_t p) const
+        {
+            std::lock_guard<std::mutex> g(stateMutex);
+            return mLength[p] && mLength[p] <= part4Size[p];
+        }
 
         // MonoConvolve::resize (.cpp:101-110)
         int resize(uint32_t in, uint32_t out, uint64_t length)
         {
+            std::lock_guard<std::mutex> g(stateMutex);
             const size_t p = pair(in, out);
             mLength[p] = 0;
             engine->set_ir(in, out, nullptr, 0, false);                  // the pair is silent until the next set
@@ -350,6 +357,7 @@ namespace
         // MonoConvolve::set (.cpp:118-140)
         int set(uint32_t in, uint32_t out, const float *ir, uint64_t length, bool requestResize, bool devicePtr)
         {
+            std::lock_guard<std::mutex> g(stateMutex);
             const size_t p = pair(in, out);
             mLength[p] = 0;
             if (requestResize) tail_equal(p, length);

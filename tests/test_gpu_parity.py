@@ -358,6 +358,79 @@ def test_capacity_growth_keeps_running_pairs(H, oracle):
     assert rel_err(y, truth) < TOL_SUM
 
 
+def test_set_while_processing_is_safe(H, oracle):
+    """Threading contract: one thread streams process(), another loads IRs concurrently.  Nothing may
+    crash or go non-finite, and once the control thread is done and the engine is reset the output is exact."""
+    import threading
+    nin, nout, L = 3, 2, 30000
+    xs = np.stack([oracle.synth_audio(i, 60000) for i in range(nin)])
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    c = H.Convolver(nin, nout, 0)
+    for (i, o), h in irs.items():
+        assert c.set(i, o, h, True) == 0
+    stop = threading.Event()
+    errors = []
+
+    def control():
+        k = 0
+        try:
+            while not stop.is_set():
+                i, o = k % nin, (k // nin) % nout
+                h = irs[(i, o)] if k % 3 else oracle.synth_ir(i + 7, o, 20000 + 1000 * (k % 5))
+                rc = c.set(i, o, h, True)
+                assert rc == 0
+                if k % 4 == 0:
+                    assert c.reset(i, o) == 0
+                k += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = threading.Thread(target=control)
+    th.start()
+    try:
+        for _ in range(3):
+            y = c.run(xs, nout, 512)
+            assert np.isfinite(y).all()
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    for (i, o), h in irs.items():
+        assert c.set(i, o, h, True) == 0
+    c.reset()
+    y = c.run(xs, nout, 512)
+    for o in range(nout):
+        truth = sum(truth_conv(xs[i], irs[(i, o)]) for i in range(nin))
+        assert rel_err(y[o], truth) < TOL_SUM
+
+
+def test_per_pair_reset_mid_stream_is_bounded(H, oracle):
+    """Per-pair reset while other pairs run (DESIGN.md deviation 3): the restarted pair is fenced at hop granularity,
+    so versus the reference (which restarts the pair's private history at the exact sample) the only difference is
+    the response to at most two hops of pre-reset input per stage; everything else — the other pair and all later
+    output — is exact."""
+    L, S, cut = 6000, 80000, 17000
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(2)])
+    h0, h1 = oracle.synth_ir(0, 0, L), oracle.synth_ir(1, 0, L)
+    c = H.Convolver(2, 1, 2)                                      # medium latency: stages 1024 / 4096 / 16384
+    assert c.set(0, 0, h0, True) == 0 and c.set(1, 0, h1, True) == 0
+    y_a = c.run(xs[:, :cut], 1, 500)[0]
+    assert c.reset(1, 0) == 0                                     # restart pair (1,0) only
+    y_b = c.run(xs[:, cut:], 1, 500)[0]
+    y = np.concatenate([y_a, y_b])
+    x1_after = np.concatenate([np.zeros(cut, np.float32), xs[1, cut:]])
+    exact = truth_conv(xs[0], h0, 512) + np.concatenate([truth_conv(xs[1, :cut], h1, 512)[:cut], np.zeros(S - cut)]) \
+        + truth_conv(x1_after, h1, 512)
+    # before the reset everything is exact
+    assert rel_err(y[:cut], exact[:cut]) < TOL_SUM
+    # after it, the deviation is the response of pair (1,0) to (a) its own pre-reset tail, which the reference drops
+    # and so do we, and (b) the leaked pre-reset samples of the hops in flight: bounded by the IR energy, gone after
+    # the leaked input has passed through the 6000-tap IR
+    settle = cut + 2 * 16384 + L
+    assert rel_err(y[settle:], exact[settle:]) < TOL_SUM
+    assert np.abs(y[cut:settle] - exact[cut:settle]).max() < 0.6 * np.abs(exact).max()
+
+
 def test_api_behaviour_checklist(H):
     from semantics import EXPECTED, checklist
     ns = types.SimpleNamespace(PartitionedConvolve=H.PartitionedConvolve, TimeDomainConvolve=H.TimeDomainConvolve, MonoConvolve=H.MonoConvolve,

@@ -120,12 +120,18 @@ namespace hcv
         std::mutex mSetMutex;       // serialises set_ir (shared IR staging buffer)
         std::string mErr;
 
-        hipStream_t mStream = nullptr, mTdStream = nullptr;
-        hipEvent_t mEvInput = nullptr, mEvTd = nullptr;
+        // mStream: control + emit (and the D2H copy of the host path); mInStream: input scatter (and the H2D copy);
+        // one stream per FFT stage; mTdStream: FIR head.  Events are double-buffered by block parity so block k+1 can
+        // start while block k is still draining (see enqueue_chunk).
+        hipStream_t mStream = nullptr, mInStream = nullptr, mTdStream = nullptr;
+        hipEvent_t mEvInput[2] = { nullptr, nullptr }, mEvTd[2] = { nullptr, nullptr }, mEvEmit[2] = { nullptr, nullptr };
+        hipEvent_t mEvCtl = nullptr;
+        bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
+        uint64_t mBlockCount = 0;
 
         // rings and staging
         float *mHist = nullptr;     long long mHistLen = 0;
-        float *mTdOut = nullptr;
+        float *mTdOut[2] = { nullptr, nullptr };   // FIR output, double-buffered by block parity
         float *mDevIn = nullptr, *mDevOut = nullptr;
         float *mPinIn = nullptr, *mPinOut = nullptr;
         float *mIrBuf = nullptr;    uint64_t mIrCap = 0;

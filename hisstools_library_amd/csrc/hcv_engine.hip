@@ -84,7 +84,7 @@ struct Engine::Stage
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream
-    hipEvent_t done = nullptr;
+    hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
     std::vector<uint32_t> pact;
@@ -174,11 +174,23 @@ bool Engine::init(const EngineCfg &cfg)
     }
 
     HCV_TRY(hipStreamCreateWithFlags(&mStream, hipStreamNonBlocking));
-    HCV_TRY(hipStreamCreateWithFlags(&mTdStream, hipStreamNonBlocking));
-    HCV_TRY(hipEventCreateWithFlags(&mEvInput, hipEventDisableTiming));
-    HCV_TRY(hipEventCreateWithFlags(&mEvTd, hipEventDisableTiming));
+    {
+        int least = 0, greatest = 0;
+        (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+        static const bool use_prio = !(std::getenv("HCV_STREAM_PRIO") && std::atoi(std::getenv("HCV_STREAM_PRIO")) == 0);
+        HCV_TRY(hipStreamCreateWithPriority(&mTdStream, hipStreamNonBlocking, use_prio ? least : 0));
+        HCV_TRY(hipStreamCreateWithPriority(&mInStream, hipStreamNonBlocking, use_prio ? greatest : 0));
+    }
+    for (int k = 0; k < 2; k++)
+    {
+        HCV_TRY(hipEventCreateWithFlags(&mEvInput[k], hipEventDisableTiming));
+        HCV_TRY(hipEventCreateWithFlags(&mEvTd[k], hipEventDisableTiming));
+        HCV_TRY(hipEventCreateWithFlags(&mEvEmit[k], hipEventDisableTiming));
+    }
+    HCV_TRY(hipEventCreateWithFlags(&mEvCtl, hipEventDisableTiming));
 
-    mHistLen = pow2ceil((long long) mMaxBlock + std::max<long long>(nmax, 4096));
+    // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
+    mHistLen = pow2ceil(3LL * mMaxBlock + std::max<long long>(nmax, 4096));
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
 
     HCV_TRY(hipMalloc(&mHist, sizeof(float) * mCfg.nin * mHistLen));
@@ -189,7 +201,7 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipHostMalloc(&mPinOut, sizeof(float) * mCfg.nout * mMaxBlock, hipHostMallocDefault));
     if (mCfg.has_td)
     {
-        HCV_TRY(hipMalloc(&mTdOut, sizeof(float) * mCfg.nout * mMaxBlock));
+        for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTdOut[k], sizeof(float) * mCfg.nout * mMaxBlock));
         HCV_TRY(hipMalloc(&mTaps, sizeof(float) * pairs * 2048));
         HCV_TRY(hipMemset(mTaps, 0, sizeof(float) * pairs * 2048));
         HCV_TRY(hipMalloc(&mTdValid, sizeof(long long) * pairs));
@@ -247,11 +259,21 @@ bool Engine::alloc_stage(Stage &st)
         HCV_TRY(hipMalloc(&st.big.a, sizeof(float2) * st.big.elems));
         HCV_TRY(hipMalloc(&st.big.b, sizeof(float2) * st.big.elems));
     }
-    st.tl_len = pow2ceil((long long) mMaxBlock + st.M);
+    st.tl_len = pow2ceil(2LL * mMaxBlock + st.M);       // two blocks deep (block k+1 adds while block k is emitted)
     HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
     HCV_TRY(hipMemset(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len));
-    HCV_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
-    HCV_TRY(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    {
+        // the largest stage carries the HBM-bound critical path: give its stream the highest priority so the
+        // latency-bound work of the other streams fills in around it instead of delaying it
+        int least = 0, greatest = 0;
+        (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+        uint32_t nmax = 0;
+        for (const StageCfg &sc : mCfg.stages) nmax = std::max(nmax, sc.fft_size);
+        static const bool use_prio = !(std::getenv("HCV_STREAM_PRIO") && std::atoi(std::getenv("HCV_STREAM_PRIO")) == 0);
+        const int prio = (use_prio && st.N == nmax) ? greatest : least;
+        HCV_TRY(hipStreamCreateWithPriority(&st.stream, hipStreamNonBlocking, use_prio ? prio : 0));
+    }
+    for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming));
     return true;
 }
 
@@ -265,20 +287,24 @@ void Engine::free_stage(Stage &st)
     if (st.big.a) (void) hipFree(st.big.a);
     if (st.big.b) (void) hipFree(st.big.b);
     st.big.a = st.big.b = nullptr;
-    if (st.done) (void) hipEventDestroy(st.done);
+    for (int k = 0; k < 2; k++)
+        if (st.done[k]) (void) hipEventDestroy(st.done[k]);
     if (st.stream) (void) hipStreamDestroy(st.stream);
     st.Hs = st.X = st.Y = nullptr;
     st.hv = nullptr;
     st.timeline = nullptr;
-    st.done = nullptr;
+    st.done[0] = st.done[1] = nullptr;
     st.stream = nullptr;
 }
 
 Engine::~Engine()
 {
     (void) hipSetDevice(mDevice);
-    if (mStream) (void) hipStreamSynchronize(mStream);
+    if (mInStream) (void) hipStreamSynchronize(mInStream);
     if (mTdStream) (void) hipStreamSynchronize(mTdStream);
+    for (Stage *st : mStages)
+        if (st->stream) (void) hipStreamSynchronize(st->stream);
+    if (mStream) (void) hipStreamSynchronize(mStream);
     for (Stage *st : mStages)
     {
         free_stage(*st);
@@ -291,7 +317,8 @@ Engine::~Engine()
         delete ev;
     }
     if (mHist) (void) hipFree(mHist);
-    if (mTdOut) (void) hipFree(mTdOut);
+    for (int k = 0; k < 2; k++)
+        if (mTdOut[k]) (void) hipFree(mTdOut[k]);
     if (mDevIn) (void) hipFree(mDevIn);
     if (mDevOut) (void) hipFree(mDevOut);
     if (mPinIn) (void) hipHostFree(mPinIn);
@@ -299,8 +326,14 @@ Engine::~Engine()
     if (mIrBuf) (void) hipFree(mIrBuf);
     if (mTaps) (void) hipFree(mTaps);
     if (mTdValid) (void) hipFree(mTdValid);
-    if (mEvInput) (void) hipEventDestroy(mEvInput);
-    if (mEvTd) (void) hipEventDestroy(mEvTd);
+    for (int k = 0; k < 2; k++)
+    {
+        if (mEvInput[k]) (void) hipEventDestroy(mEvInput[k]);
+        if (mEvTd[k]) (void) hipEventDestroy(mEvTd[k]);
+        if (mEvEmit[k]) (void) hipEventDestroy(mEvEmit[k]);
+    }
+    if (mEvCtl) (void) hipEventDestroy(mEvCtl);
+    if (mInStream) (void) hipStreamDestroy(mInStream);
     if (mStream) (void) hipStreamDestroy(mStream);
     if (mTdStream) (void) hipStreamDestroy(mTdStream);
 }
@@ -383,6 +416,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
         mErr = "stage regrow failed";
         return false;
     }
+    mCtlDirty = true;
     (void) hipFree(st.Hs);
     (void) hipFree(st.X);
     st.Hs = nHs;
@@ -459,6 +493,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
         }
         mLoaded[pair] = any ? 1 : 0;
         mPending[pair] = 1;                                                         // set() always ends in reset()
+        mCtlDirty = true;
     }
     HCV_TRY(hipStreamSynchronize(mStream));
     return true;
@@ -483,6 +518,7 @@ void Engine::reset_all()
 bool Engine::global_reset()
 {
     mN = 0;
+    mCtlDirty = true;
     HCV_TRY(hipMemsetAsync(mHist, 0, sizeof(float) * mCfg.nin * mHistLen, mStream));
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     for (Stage *st : mStages)
@@ -514,6 +550,7 @@ bool Engine::apply_pending_resets()
         // A single pair restarts while others keep running.  The pair must ignore input older than "now"; with one
         // shared input ring per input this is enforced at hop granularity for the FFT stages (the hop in progress is
         // still visible to the pair) and exactly for the time-domain head.  See DESIGN.md "per-pair reset".
+        mCtlDirty = true;
         for (size_t p = 0; p < mPending.size(); p++)
         {
             if (!mPending[p]) continue;
@@ -536,33 +573,56 @@ bool Engine::apply_pending_resets()
 
 // One block of at most max_block samples, everything device side.  Caller holds mMutex.
 //
-// Stream plan:   main:   scatter ─┬────────────────────────────────────────────┬─ emit
-//                stage s:         └ rfft_frames → spectral_mac → reduce → rifft ┤      (one stream per FFT stage)
-//                head:            └ fir_head ───────────────────────────────────┘
-// The stages only meet in emit(), so the latency-bound short stages and the FIR head hide under the HBM-bound tail.
+// Stream plan for block k (q = k & 1; every event and the FIR output buffer exist twice, indexed by block parity):
+//
+//   in stream:    wait readers(k-2) ─ scatter_input ─ record in[q]
+//   stage s:      wait in[q], emit[q] (= emit of block k-2) ─ rfft_frames → spectral_mac → reduce → rifft_overlap_add ─ record done_s[q]
+//   head stream:  wait in[q], emit[q]                       ─ fir_head → tdout[q]                                   ─ record td[q]
+//   main stream:  wait done_s[q] for all s, td[q] ─ emit(tdout[q]) ─ record emit[q]
+//
+// The stages only meet in emit(), so the latency-bound short stages and the FIR head hide under the HBM-bound tail;
+// and because block k+1's scatter and FFTs do not wait for block k's emit, consecutive asynchronous calls overlap.
+// Ring depths make that safe: the history ring holds three blocks + a frame (a block's readers must be done before
+// the block two later is scattered over them), each stage timeline holds two blocks + a hop (emit(k-2) must have
+// cleared what block k's hops are added into).
 bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B)
 {
     const long long n0 = mN;
     const long long hmask = mHistLen - 1;
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+    const int q = (int) (mBlockCount & 1);
 
-    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, mStream));
-    HCV_TRY(hipEventRecord(mEvInput, mStream));
+    // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
+    if (mCtlDirty)
+    {
+        HCV_TRY(hipEventRecord(mEvCtl, mStream));
+        HCV_TRY(hipStreamWaitEvent(mInStream, mEvCtl, 0));
+        mCtlDirty = false;
+    }
+    // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
+    static const bool pipeline = !(std::getenv("HCV_PIPELINE") && std::atoi(std::getenv("HCV_PIPELINE")) == 0);
+    if (!pipeline) HCV_TRY(hipStreamWaitEvent(mInStream, mEvEmit[q ^ 1], 0));
+    // the block two back read the history this scatter may overwrite
+    for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(mInStream, st->done[q], 0));
+    HCV_TRY(hipStreamWaitEvent(mInStream, mEvTd[q], 0));
+    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, mInStream));
+    HCV_TRY(hipEventRecord(mEvInput[q], mInStream));
 
     const bool td = mCfg.has_td && mTdLpad > 0;
     if (td)
     {
-        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput, 0));
+        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput[q], 0));
+        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvEmit[q], 0));      // emit(k-2) has consumed tdout[q]
         const bool check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
         HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
-                                n0, (int) B, mTdValid, check, mTdOut, mMaxBlock, mTdStream));
-        HCV_TRY(hipEventRecord(mEvTd, mTdStream));
+                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, mTdStream));
+        HCV_TRY(hipEventRecord(mEvTd[q], mTdStream));
     }
 
     EmitSources src;
     src.count = 0;
-    // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     static const bool tail_first = !std::getenv("HCV_TAIL_LAST");
+    // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     for (size_t sj = 0; sj < mStages.size(); sj++)
     {
         const size_t si = tail_first ? mStages.size() - 1 - sj : sj;
@@ -577,7 +637,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         if (T <= 0) continue;
 
         hipStream_t ss = st.stream;
-        HCV_TRY(hipStreamWaitEvent(ss, mEvInput, 0));
+        HCV_TRY(hipStreamWaitEvent(ss, mEvInput[q], 0));
+        HCV_TRY(hipStreamWaitEvent(ss, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
         HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, ss));
 
         MacShape sh;
@@ -621,13 +682,16 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const long long y_elems = (long long) T * nout_act * st.M;
         HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, ss));
         HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, &st.big, ss));
-        HCV_TRY(hipEventRecord(st.done, ss));
-        HCV_TRY(hipStreamWaitEvent(mStream, st.done, 0));
+        HCV_TRY(hipEventRecord(st.done[q], ss));
+        HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
     }
 
-    if (td) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd, 0));
-    HCV_TRY(launch_emit(src, n0, (int) B, (int) nout_act, td ? mTdOut : nullptr, mMaxBlock, dout, out_stride, mStream));
+    if (td) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd[q], 0));
+    HCV_TRY(hipStreamWaitEvent(mStream, mEvInput[q], 0));           // a block with no live stage still orders after its scatter
+    HCV_TRY(launch_emit(src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
+    HCV_TRY(hipEventRecord(mEvEmit[q], mStream));
     mN += B;
+    mBlockCount++;
     return true;
 }
 
@@ -646,7 +710,7 @@ bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_a
         {
             std::lock_guard<std::mutex> g(mMutex);
             if (!apply_pending_resets()) return false;
-            if (rows_in) HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
+            if (rows_in) HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mInStream));
             if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
             HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
         }

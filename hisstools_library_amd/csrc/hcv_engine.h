@@ -107,6 +107,7 @@ namespace hcv
         bool alloc_stage(Stage &st);
         void free_stage(Stage &st);
         bool global_reset();
+        bool select_streams();
         bool apply_pending_resets();
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
         size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }
@@ -124,6 +125,8 @@ namespace hcv
         // one stream per FFT stage; mTdStream: FIR head.  Events are double-buffered by block parity so block k+1 can
         // start while block k is still draining (see enqueue_chunk).
         hipStream_t mStream = nullptr, mInStream = nullptr, mTdStream = nullptr;
+        hipStream_t mInStreams[2] = { nullptr, nullptr }, mTdStreams[2] = { nullptr, nullptr };   // [1] = prioritised set
+        int mStreamSet = 0;
         hipEvent_t mEvInput[2] = { nullptr, nullptr }, mEvTd[2] = { nullptr, nullptr }, mEvEmit[2] = { nullptr, nullptr };
         hipEvent_t mEvCtl = nullptr;
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
@@ -137,6 +140,9 @@ namespace hcv
         float *mIrBuf = nullptr;    uint64_t mIrCap = 0;
 
         // time-domain head
+        float2 *mHeadSpec = nullptr;        // [nout][nin_alloc][M0] head taps as ONE zero-latency partition of the first FFT stage
+        float2 *mHeadY = nullptr;           // [Tmax0][nout][M0]
+        bool mHeadFFT = false;              // the head may take the FFT path (taps fit one hop of the first stage)
         float *mTaps = nullptr;
         long long *mTdValid = nullptr;
         std::vector<uint32_t> mTdCount;     // taps per pair

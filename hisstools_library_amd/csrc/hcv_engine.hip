@@ -84,6 +84,7 @@ struct Engine::Stage
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream
+    hipStream_t streams[2] = { nullptr, nullptr };   // [0] default priority, [1] prioritised set (see Engine::select_streams)
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
@@ -177,9 +178,12 @@ bool Engine::init(const EngineCfg &cfg)
     {
         int least = 0, greatest = 0;
         (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
-        static const bool use_prio = !(std::getenv("HCV_STREAM_PRIO") && std::atoi(std::getenv("HCV_STREAM_PRIO")) == 0);
-        HCV_TRY(hipStreamCreateWithPriority(&mTdStream, hipStreamNonBlocking, use_prio ? least : 0));
-        HCV_TRY(hipStreamCreateWithPriority(&mInStream, hipStreamNonBlocking, use_prio ? greatest : 0));
+        HCV_TRY(hipStreamCreateWithFlags(&mTdStreams[0], hipStreamNonBlocking));
+        HCV_TRY(hipStreamCreateWithPriority(&mTdStreams[1], hipStreamNonBlocking, least));
+        HCV_TRY(hipStreamCreateWithFlags(&mInStreams[0], hipStreamNonBlocking));
+        HCV_TRY(hipStreamCreateWithPriority(&mInStreams[1], hipStreamNonBlocking, greatest));
+        mTdStream = mTdStreams[0];
+        mInStream = mInStreams[0];
     }
     for (int k = 0; k < 2; k++)
     {
@@ -224,6 +228,23 @@ bool Engine::init(const EngineCfg &cfg)
         if (!st->tw) return false;
         if (!alloc_stage(*st)) return false;
     }
+    // Head through the FFT: the head's taps (<= one hop of the first FFT stage, MonoConvolve.cpp:235-240) form one extra,
+    // zero-latency partition of that stage, whose input spectra exist anyway.  Used for hop-aligned blocks of larger
+    // matrices, where the direct-form FIR would cost more than all FFT-stage MACs together; ragged blocks and small
+    // engines keep the direct form (fir_head_kernel).
+    if (mCfg.has_td && !mStages.empty())
+    {
+        const Stage &s0 = *mStages[0];
+        const uint64_t lim = mCfg.td_length ? mCfg.td_length : 2044;
+        static const bool allow = !(std::getenv("HCV_HEAD_FFT") && std::atoi(std::getenv("HCV_HEAD_FFT")) == 0);
+        if (allow && lim <= s0.M && !is_big_fft(s0.log2n) && (size_t) mCfg.nout * mNinAlloc >= 16)
+        {
+            mHeadFFT = true;
+            HCV_TRY(hipMalloc(&mHeadSpec, sizeof(float2) * pairs * s0.M));
+            HCV_TRY(hipMemset(mHeadSpec, 0, sizeof(float2) * pairs * s0.M));
+            HCV_TRY(hipMalloc(&mHeadY, sizeof(float2) * (size_t) s0.Tmax * mCfg.nout * s0.M));
+        }
+    }
     HCV_TRY(hipDeviceSynchronize());
     return true;
 }
@@ -263,15 +284,17 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
     HCV_TRY(hipMemset(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len));
     {
-        // the largest stage carries the HBM-bound critical path: give its stream the highest priority so the
-        // latency-bound work of the other streams fills in around it instead of delaying it
+        // Two stream sets.  Set 1 is prioritised: the largest stage carries the HBM-bound critical path and gets the
+        // highest priority so the latency-bound work of the other streams fills in around it instead of delaying it.
+        // Priority queues add cross-stream hand-off latency, which would dominate small (launch-bound) engines, so set 0
+        // (all default priority) is used until the tail's spectra are large (select_streams).
         int least = 0, greatest = 0;
         (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
         uint32_t nmax = 0;
         for (const StageCfg &sc : mCfg.stages) nmax = std::max(nmax, sc.fft_size);
-        static const bool use_prio = !(std::getenv("HCV_STREAM_PRIO") && std::atoi(std::getenv("HCV_STREAM_PRIO")) == 0);
-        const int prio = (use_prio && st.N == nmax) ? greatest : least;
-        HCV_TRY(hipStreamCreateWithPriority(&st.stream, hipStreamNonBlocking, use_prio ? prio : 0));
+        HCV_TRY(hipStreamCreateWithFlags(&st.streams[0], hipStreamNonBlocking));
+        HCV_TRY(hipStreamCreateWithPriority(&st.streams[1], hipStreamNonBlocking, st.N == nmax ? greatest : least));
+        st.stream = st.streams[0];
     }
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming));
     return true;
@@ -289,7 +312,9 @@ void Engine::free_stage(Stage &st)
     st.big.a = st.big.b = nullptr;
     for (int k = 0; k < 2; k++)
         if (st.done[k]) (void) hipEventDestroy(st.done[k]);
-    if (st.stream) (void) hipStreamDestroy(st.stream);
+    for (int k = 0; k < 2; k++)
+        if (st.streams[k]) (void) hipStreamDestroy(st.streams[k]);
+    st.streams[0] = st.streams[1] = nullptr;
     st.Hs = st.X = st.Y = nullptr;
     st.hv = nullptr;
     st.timeline = nullptr;
@@ -325,6 +350,8 @@ Engine::~Engine()
     if (mPinOut) (void) hipHostFree(mPinOut);
     if (mIrBuf) (void) hipFree(mIrBuf);
     if (mTaps) (void) hipFree(mTaps);
+    if (mHeadSpec) (void) hipFree(mHeadSpec);
+    if (mHeadY) (void) hipFree(mHeadY);
     if (mTdValid) (void) hipFree(mTdValid);
     for (int k = 0; k < 2; k++)
     {
@@ -333,9 +360,12 @@ Engine::~Engine()
         if (mEvEmit[k]) (void) hipEventDestroy(mEvEmit[k]);
     }
     if (mEvCtl) (void) hipEventDestroy(mEvCtl);
-    if (mInStream) (void) hipStreamDestroy(mInStream);
+    for (int k = 0; k < 2; k++)
+    {
+        if (mInStreams[k]) (void) hipStreamDestroy(mInStreams[k]);
+        if (mTdStreams[k]) (void) hipStreamDestroy(mTdStreams[k]);
+    }
     if (mStream) (void) hipStreamDestroy(mStream);
-    if (mTdStream) (void) hipStreamDestroy(mTdStream);
 }
 
 uint64_t Engine::stage_capacity(size_t s) const
@@ -486,6 +516,12 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             float *dst = mTaps + pair * 2048;
             if (taps) HCV_TRY(hipMemcpyAsync(dst, dsrc + mCfg.td_offset, sizeof(float) * taps, hipMemcpyDeviceToDevice, mStream));
             HCV_TRY(hipMemsetAsync(dst + taps, 0, sizeof(float) * (2048 - taps), mStream));
+            if (mHeadFFT)
+            {
+                Stage &s0 = *mStages[0];
+                const float *src = taps ? dsrc + mCfg.td_offset : mHist;
+                HCV_TRY(launch_rfft_ir(s0.log2n, src, (long long) taps, 1, mHeadSpec + pair * (size_t) s0.M, s0.tw, &s0.big, mStream));
+            }
             mTdCount[pair] = (uint32_t) taps;
             uint32_t mx = *std::max_element(mTdCount.begin(), mTdCount.end());
             mTdLpad = ((mx + 15) / 16) * 16;
@@ -571,6 +607,29 @@ bool Engine::apply_pending_resets()
     return true;
 }
 
+// Pick the stream set for the coming blocks: prioritised streams once the largest stage streams >= 128 MiB of IR
+// spectra per hop (then the tail MAC runs for tens of microseconds or more and is worth protecting).  Switching sets
+// drains the engine first; it only happens when IRs are loaded or cleared.
+bool Engine::select_streams()
+{
+    static const int force = std::getenv("HCV_STREAM_PRIO") ? std::atoi(std::getenv("HCV_STREAM_PRIO")) : -1;
+    size_t big = 0;
+    for (Stage *st : mStages)
+    {
+        size_t live = 0;
+        for (uint32_t p : st->pact) live += p;
+        big = std::max(big, live * st->M * sizeof(float2));
+    }
+    const int want = force >= 0 ? (force ? 1 : 0) : (big >= (size_t(128) << 20) ? 1 : 0);
+    if (want == mStreamSet) return true;
+    HCV_TRY(hipStreamSynchronize(mStream));
+    mStreamSet = want;
+    mInStream = mInStreams[want];
+    mTdStream = mTdStreams[want];
+    for (Stage *st : mStages) st->stream = st->streams[want];
+    return true;
+}
+
 // One block of at most max_block samples, everything device side.  Caller holds mMutex.
 //
 // Stream plan for block k (q = k & 1; every event and the FIR output buffer exist twice, indexed by block parity):
@@ -595,6 +654,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
     if (mCtlDirty)
     {
+        if (!select_streams()) return false;
         HCV_TRY(hipEventRecord(mEvCtl, mStream));
         HCV_TRY(hipStreamWaitEvent(mInStream, mEvCtl, 0));
         mCtlDirty = false;
@@ -608,12 +668,16 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, mInStream));
     HCV_TRY(hipEventRecord(mEvInput[q], mInStream));
 
-    const bool td = mCfg.has_td && mTdLpad > 0;
+    const bool td_any = mCfg.has_td && mTdLpad > 0;
+    const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
+    // hop-aligned block of a larger matrix: the head goes through the first stage's FFTs (see init)
+    const bool head_fft = td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
+    const bool td = td_any && !head_fft;
     if (td)
     {
         HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput[q], 0));
         HCV_TRY(hipStreamWaitEvent(mTdStream, mEvEmit[q], 0));      // emit(k-2) has consumed tdout[q]
-        const bool check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
+        const bool check = td_check;
         HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
                                 n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, mTdStream));
         HCV_TRY(hipEventRecord(mEvTd[q], mTdStream));
@@ -631,7 +695,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         src.stride[src.count] = st.tl_len;
         src.mask[src.count] = st.tl_len - 1;
         src.count++;
-        if (!st.P) continue;
+        const bool head_here = head_fft && si == 0;
+        if (!st.P && !head_here) continue;
         const long long h_first = n0 / st.M;
         const int T = (int) ((n0 + B) / st.M - h_first);
         if (T <= 0) continue;
@@ -640,6 +705,33 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(hipStreamWaitEvent(ss, mEvInput[q], 0));
         HCV_TRY(hipStreamWaitEvent(ss, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
         HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, ss));
+
+        if (head_here)
+        {
+            // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i], emitted with NO latency (hop h at h*M)
+            MacShape hs;
+            hs.M = (int) st.M;
+            hs.R = (int) st.R;
+            hs.P = 1;
+            hs.Pcap = 1;
+            hs.nin = (int) nin_act;
+            hs.nin_alloc = (int) mNinAlloc;
+            hs.nout = (int) nout_act;
+            hs.diag = mCfg.diag ? 1 : 0;
+            hs.T = T;
+            hs.max_ksplit = 1;
+            MacPlan hp;
+            mac_plan(hs, hp);
+            HCV_TRY(launch_spectral_mac(hs, hp, st.X, mHeadSpec, mHeadY, st.hv, h_first, false, ss));
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, mHeadY, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                             &st.big, ss));
+        }
+        if (!st.P)
+        {
+            HCV_TRY(hipEventRecord(st.done[q], ss));
+            HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+            continue;
+        }
 
         MacShape sh;
         sh.M = (int) st.M;

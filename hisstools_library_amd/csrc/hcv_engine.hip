@@ -80,6 +80,13 @@ struct Engine::Stage
     uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
     float2 *Hs = nullptr, *X = nullptr, *Y = nullptr;
     size_t y_elems = 0;
+    // Deferred ("time-spread") mode, the GPU form of the reference's partition scheduler (PartitionedConvolve.cpp:321-348):
+    // partitions 1..P-1 of hop h+1 only need spectra up to hop h, so they are accumulated into Ypre in the BACKGROUND
+    // right after hop h's boundary; the boundary of hop h+1 then only pays partition 0 + the inverse FFT.
+    float2 *Ypre = nullptr;             // [nout][M] sum over p >= 1 for the next hop
+    long long pre_hop = -1;             // hop index Ypre was accumulated for (-1 = none)
+    hipEvent_t bg_done = nullptr;       // recorded after the background accumulation
+    bool bg_pending = false;
     float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
@@ -268,6 +275,8 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMalloc(&st.Y, sizeof(float2) * st.y_elems));
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
+    HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) mCfg.nout * st.M));
+    HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
     if (is_big_fft(st.log2n))
     {
         int l1, l2;
@@ -307,6 +316,10 @@ void Engine::free_stage(Stage &st)
     if (st.Y) (void) hipFree(st.Y);
     if (st.hv) (void) hipFree(st.hv);
     if (st.timeline) (void) hipFree(st.timeline);
+    if (st.Ypre) (void) hipFree(st.Ypre);
+    if (st.bg_done) (void) hipEventDestroy(st.bg_done);
+    st.Ypre = nullptr;
+    st.bg_done = nullptr;
     if (st.big.a) (void) hipFree(st.big.a);
     if (st.big.b) (void) hipFree(st.big.b);
     st.big.a = st.big.b = nullptr;
@@ -402,6 +415,22 @@ void Engine::set_td_window(uint64_t offset, uint64_t length)
     mCfg.td_length = length;
 }
 
+// Control work (IR loads, resets, regrow) changes what a background accumulation reads or means: order it after any
+// background MAC still in flight and drop the pre-accumulated spectra.  Caller holds mMutex.
+bool Engine::fence_background()
+{
+    for (Stage *st : mStages)
+    {
+        if (st->bg_pending)
+        {
+            HCV_TRY(hipStreamWaitEvent(mStream, st->bg_done, 0));
+            st->bg_pending = false;
+        }
+        st->pre_hop = -1;
+    }
+    return true;
+}
+
 // Capacity growth of a stage (MonoConvolve::resize / set(..., requestResize) reallocate the tail partition,
 // MonoConvolve.cpp:101-110,123; here all pairs of a stage share one allocation, so growing re-strides it).
 bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
@@ -412,6 +441,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     Stage &st = *mStages[s];
     const uint32_t newP = (uint32_t) std::max<uint64_t>(1, (capacity + st.M - 1) / st.M);
     if (newP <= st.Pcap) return true;
+    if (!fence_background()) return false;
 
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     const uint32_t newR = newP + st.Tmax;
@@ -486,6 +516,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
 
     {
         std::lock_guard<std::mutex> g(mMutex);
+        if (!fence_background()) return false;
         if (len && !device_ptr) HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mStream));
         const size_t pair = pair_index(in, out);
         bool any = false;
@@ -577,6 +608,7 @@ bool Engine::apply_pending_resets()
         if (mLoaded[p] && !mPending[p]) all = false;
     }
     if (!any) return true;
+    if (!fence_background()) return false;
     if (all)
     {
         if (!global_reset()) return false;
@@ -623,6 +655,7 @@ bool Engine::select_streams()
     const int want = force >= 0 ? (force ? 1 : 0) : (big >= (size_t(128) << 20) ? 1 : 0);
     if (want == mStreamSet) return true;
     HCV_TRY(hipStreamSynchronize(mStream));
+    for (Stage *st : mStages) HCV_TRY(hipStreamSynchronize(st->stream));    // background accumulations included
     mStreamSet = want;
     mInStream = mInStreams[want];
     mTdStream = mTdStreams[want];
@@ -720,6 +753,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             hs.diag = mCfg.diag ? 1 : 0;
             hs.T = T;
             hs.max_ksplit = 1;
+            hs.target_blocks = 0;
             MacPlan hp;
             mac_plan(hs, hp);
             HCV_TRY(launch_spectral_mac(hs, hp, st.X, mHeadSpec, mHeadY, st.hv, h_first, false, ss));
@@ -733,10 +767,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             continue;
         }
 
+        // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
+        // reference, PartitionedConvolve.cpp:285,322,373): right after a reset the reduction is short
+        const long long p_live = std::min<long long>(st.P, h_first + T);
         MacShape sh;
         sh.M = (int) st.M;
         sh.R = (int) st.R;
-        sh.P = (int) st.P;
+        sh.P = (int) p_live;
         sh.Pcap = (int) st.Pcap;
         sh.nin = (int) nin_act;
         sh.nin_alloc = (int) mNinAlloc;
@@ -744,13 +781,19 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         sh.diag = mCfg.diag ? 1 : 0;
         sh.T = T;
         sh.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M));
-        MacPlan pl;
-        mac_plan(sh, pl);
+        sh.target_blocks = 0;
         const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
+        const long long y_elems = (long long) T * nout_act * st.M;
+
+        // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
+        static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
+        const bool defer = allow_defer && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && !is_big_fft(st.log2n) && nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+        const bool have_pre = defer && st.pre_hop == h_first;
 
         EventPair *ev = nullptr;
-        if (mProfiling)
+        auto begin_event = [&]() -> bool
         {
+            if (!mProfiling) return true;
             for (EventPair *c : mEvents)
                 if (!c->live) { ev = c; break; }
             if (!ev)
@@ -763,17 +806,69 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             ev->stage = si;
             ev->live = true;
             HCV_TRY(hipEventRecord(ev->a, ss));
-        }
-        HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, ss));
-        if (ev) HCV_TRY(hipEventRecord(ev->b, ss));
-        st.launches++;
-        st.hops += (uint64_t) T;
-        st.last_ksplit = (uint32_t) pl.ksplit;
-        st.last_ot = (uint32_t) pl.ot;
+            return true;
+        };
 
-        const long long y_elems = (long long) T * nout_act * st.M;
-        HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, ss));
-        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, &st.big, ss));
+        MacPlan pl;
+        if (have_pre)
+        {
+            // boundary of a hop whose partitions 1..P-1 were accumulated in the background: partition 0 only
+            MacShape s0 = sh;
+            s0.P = 1;
+            s0.max_ksplit = 1;
+            mac_plan(s0, pl);
+            HCV_TRY(launch_spectral_mac(s0, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, ss));
+            // inverse FFT of Y (partition 0) + Ypre (partitions >= 1): the two buffers are read as two "partials"
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 2, (long long) (st.Ypre - st.Y), h_first, 1, (int) nout_act, st.timeline, st.tl_len,
+                                             st.tl_len - 1, st.tw, &st.big, ss));
+        }
+        else
+        {
+            mac_plan(sh, pl);
+            if (!begin_event()) return false;
+            HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, ss));
+            if (ev) HCV_TRY(hipEventRecord(ev->b, ss));
+            st.launches++;
+            st.hops += (uint64_t) T;
+            st.last_ksplit = (uint32_t) pl.ksplit;
+            st.last_ot = (uint32_t) pl.ot;
+            HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, ss));
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, &st.big,
+                                             ss));
+        }
+        HCV_TRY(hipEventRecord(st.done[q], ss));
+        HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+
+        st.pre_hop = -1;
+        if (defer)
+        {
+            // background: Ypre for hop h+1 = sum_{p>=1} X[h+1-p] H[p]  ==  a (P-1)-partition MAC at hop h over H shifted by
+            // one partition.  Queued behind this block's result on the stage stream; nothing in this call waits for it.
+            MacShape sb = sh;
+            sb.P = (int) std::min<long long>(st.P - 1, h_first + 1);    // partitions p' = p - 1 <= h that have input
+            MacPlan pb;
+            // partials live in st.Y behind slice 0 (which the critical path of the next boundary reuses only after this)
+            sb.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M));
+            // small footprint: there is a whole hop of real time to finish, and the calls in between need free CUs
+            static const int bg_blocks = std::getenv("HCV_BG_BLOCKS") ? std::atoi(std::getenv("HCV_BG_BLOCKS")) : 128;
+            sb.target_blocks = bg_blocks;
+            mac_plan(sb, pb);
+            ev = nullptr;
+            if (!begin_event()) return false;
+            const bool bcheck = (h_first - st.max_hv) < (long long) st.P - 1;
+            HCV_TRY(launch_spectral_mac(sb, pb, st.X, st.Hs + st.M, st.Y, st.hv, h_first, bcheck, ss));
+            if (ev) HCV_TRY(hipEventRecord(ev->b, ss));
+            st.launches++;
+            st.hops += 1;
+            st.last_ksplit = (uint32_t) pb.ksplit;
+            st.last_ot = (uint32_t) pb.ot;
+            HCV_TRY(launch_reduce_partials(st.Y, pb.ksplit, y_elems, y_elems, ss));
+            HCV_TRY(hipMemcpyAsync(st.Ypre, st.Y, sizeof(float2) * (size_t) nout_act * st.M, hipMemcpyDeviceToDevice, ss));
+            HCV_TRY(hipEventRecord(st.bg_done, ss));
+            st.bg_pending = true;
+            st.pre_hop = h_first + 1;
+        }
+        continue;
         HCV_TRY(hipEventRecord(st.done[q], ss));
         HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
     }
@@ -861,6 +956,11 @@ void Engine::collect_events()
     for (EventPair *ev : mEvents)
     {
         if (!ev->live) continue;
+        if (hipEventQuery(ev->b) == hipErrorNotReady)       // background accumulation still running: collect it next time
+        {
+            (void) hipGetLastError();
+            continue;
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ev->a, ev->b) == hipSuccess && ev->stage < mStages.size()) mStages[ev->stage]->ms += ms;
         else (void) hipGetLastError();

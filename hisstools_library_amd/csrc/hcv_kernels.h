@@ -50,6 +50,7 @@ namespace hcv
         int diag;           // parallel (diagonal) mode
         int T;              // hops in this launch
         int max_ksplit;     // 0 = unlimited (bounded by the Y partial buffer)
+        int target_blocks;  // 0 = default; > 0 = aim for this many workgroups (background work keeps a small footprint)
     };
     struct MacPlan
     {

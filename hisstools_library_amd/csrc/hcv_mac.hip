@@ -251,7 +251,8 @@ void mac_plan(const MacShape &s, MacPlan &pl)
 
     const long long K = (long long) (s.diag ? 1 : s.nin) * s.P;
     const long long base = (long long) pl.binblocks * pl.outtiles * pl.tz;
-    long long want = (target_blocks + base - 1) / base;
+    const long long tgt = s.target_blocks > 0 ? s.target_blocks : target_blocks;
+    long long want = std::max<long long>(1, tgt / base);
     long long maxsplit = K / 8;                                 // keep every k-slice at least 8 long
     if (maxsplit < 1) maxsplit = 1;
     if (want > maxsplit) want = maxsplit;

@@ -317,6 +317,51 @@ def test_convolver_double_api_and_parallel(H, oracle):
         assert rel_err(y[o], truth_conv(xs[o], irs[o])) < TOL
 
 
+def test_head_paths_agree_on_mixed_block_sizes(H, oracle):
+    """>= 16 pairs: hop-aligned blocks take the head through the first stage's FFTs, ragged blocks through the
+    direct-form FIR kernel; any mixture must give the same stream (and match the oracle)."""
+    nin = nout = 4
+    L, S = 3000, 12000
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    ref = oracle.Convolver(nin, nout, 0)
+    ref.setResetOffset(0)
+    outs = []
+    for blocks in (512, [512, 100, 412, 1024, 37, 91, 128], 128, [1000, 24]):
+        c = H.Convolver(nin, nout, 0)
+        for (i, o), h in irs.items():
+            assert c.set(i, o, h, True) == 0
+        outs.append(c.run(xs, nout, blocks))
+    for (i, o), h in irs.items():
+        assert ref.set(i, o, h, True) == 0
+    y_ref = ref.run(xs, nout, 512)
+    for y in outs:
+        for o in range(nout):
+            assert rel_err(y[o], y_ref[o]) < TOL_SUM
+            assert rel_err(y[o], sum(truth_conv(xs[i], irs[(i, o)]) for i in range(nin))) < TOL_SUM
+
+
+def test_small_blocks_use_deferred_tail_and_match(H, oracle):
+    """Calls shorter than the tail hop: partitions 1..P-1 are accumulated in the background between hop boundaries
+    (the engine's form of the reference's time-spread scheduler, PartitionedConvolve.cpp:321-348); the output must not
+    depend on it."""
+    h, x = oracle.synth_ir(6, 6, 70000), oracle.synth_audio(6, 120000)
+    outs = []
+    for block in (128, 1000, 8192, 30000):
+        m = H.MonoConvolve(70000, latency=1)
+        assert m.set(h, True) == 0
+        outs.append(m.run(x, block))
+    truth = truth_conv(x, h, 128)
+    for y in outs:
+        assert rel_err(y, truth) < TOL
+    # a reset in the middle of a hop drops the pre-accumulated spectra
+    m = H.MonoConvolve(70000, latency=1)
+    m.set(h, True)
+    m.run(x[:20000], 256)
+    m.reset()
+    assert rel_err(m.run(x, 256), truth) < TOL
+
+
 def test_silent_and_cleared_pairs(H, oracle):
     xs = np.stack([oracle.synth_audio(i, 4000) for i in range(2)])
     h = oracle.synth_ir(0, 0, 2000)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-call latency of synchronous small-block process() calls (real-time usage): tools/latency.py <workload> <block> [hops]
+Prints mean / p50 / p99 / max milliseconds per call and the real-time budget of the block at the workload's sample rate."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import hisstools_library_amd as H
+import bench
+
+w, B = sys.argv[1], int(sys.argv[2])
+hops = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+nin, nout, L, fs, layout = bench.WORKLOADS[w]
+dev = torch.device("cuda", 0)
+conv = H.Convolver(nin, nout, 0, device=0, maxBlock=max(B, 8192), custom=(L, *layout))
+g = torch.Generator(device=dev)
+decay = torch.pow(torch.tensor(10.0, device=dev), -3.0 * torch.arange(L, device=dev, dtype=torch.float32) / L)
+for o in range(nout):
+    for i in range(nin):
+        g.manual_seed(1000 * i + o + 1)
+        h = (torch.rand(L, generator=g, device=dev) * 2 - 1) * decay
+        h = h / torch.linalg.vector_norm(h)
+        torch.cuda.synchronize()
+        assert conv.set_dev(i, o, h.data_ptr(), L, True) == 0
+tail = [s for s in layout[1:] if s][-1]
+ncalls = hops * (tail // 2) // B
+xs = torch.rand((nin, B), device=dev) * 2 - 1
+ys = torch.zeros((nout, B), device=dev)
+torch.cuda.synchronize()
+# prime: run a full IR length so every partition is live
+prime = (L // (tail // 2) + 2) * (tail // 2) // 8192
+big = torch.rand((nin, 8192), device=dev) * 2 - 1
+bigy = torch.zeros((nout, 8192), device=dev)
+for _ in range(prime):
+    conv.process_dev(big.data_ptr(), 8192, bigy.data_ptr(), 8192, nin, nout, 8192)
+conv.synchronize()
+ts = []
+paced = os.environ.get("PACED", "1") != "0"      # real-time pacing: call k is issued no earlier than k * B / fs
+t_start = time.perf_counter()
+for k in range(ncalls):
+    if paced:
+        while time.perf_counter() < t_start + k * B / fs:
+            pass
+    t0 = time.perf_counter()
+    conv.process_dev(xs.data_ptr(), B, ys.data_ptr(), B, nin, nout, B, sync=True)
+    ts.append(time.perf_counter() - t0)
+ts = np.array(ts) * 1e3
+print(f"{w} block={B} paced={int(paced)} defer={os.environ.get('HCV_DEFER','1')}: calls={ncalls} mean={ts.mean():.3f} p50={np.percentile(ts,50):.3f} p99={np.percentile(ts,99):.3f} "
+      f"max={ts.max():.3f} ms | budget {1e3*B/fs:.3f} ms | sum={ts.sum():.1f} ms for {1e3*ncalls*B/fs:.1f} ms of audio")
+slow = [(i, round(float(t), 3)) for i, t in enumerate(ts) if t > 0.6]
+print("   calls > 0.6 ms:", slow[:24])

@@ -33,8 +33,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 tail = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     run = load(f"{src}/{c}/run_counter_collection.csv")
-    # the steady-state tail launch: unpredicated spectral_mac (CHECK = false) with the largest grid
-    cand = {k: v for k, v in run.items() if "spectral_mac_kernel" in k[0] and ", false," in k[0]}
+    # the steady-state tail launch: the unpredicated single-hop spectral_mac (<OT, 1, false, NT>) moving the most bytes
+    cand = {k: v for k, v in run.items() if "spectral_mac_kernel" in k[0] and ", 1, false," in k[0]}
     key = max(cand, key=lambda k: (sum(cand[k]) / len(cand[k])))
     tail[c] = sum(cand[key]) / len(cand[key])
     out[f"{c}_kb_per_launch"] = tail[c]

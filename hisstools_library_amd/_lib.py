@@ -80,6 +80,7 @@ SIGNATURES = {
     "hcv_convolver_process_f64": (C.c_int, [vp, C.POINTER(f64p), C.POINTER(f64p), usz, usz, usz]),
     "hcv_convolver_create_on": (vp, [u32, u32, C.c_int, C.c_int, u32]),
     "hcv_convolver_create_custom": (vp, [u32, u32, C.c_int, uptr, C.c_int, u32, u32, u32, u32, C.c_int, u32]),
+    "hcv_convolver_create_extended": (vp, [u32, u32, C.c_int, uptr, C.c_int, u32, u32, u32, u32, C.c_int, u32, u32]),
     "hcv_convolver_set_f32_dev": (C.c_int, [vp, u32, u32, vp, uptr, C.c_int]),
     "hcv_convolver_process_f32_dev": (C.c_int, [vp, vp, usz, vp, usz, usz, usz, usz, C.c_int]),
     "hcv_convolver_synchronize": (C.c_int, [vp]),

@@ -263,14 +263,15 @@ class NToMonoConvolve:
 class Convolver:
     """Convolver(numIns, numOuts, latency) — N x M matrix; Convolver(numIO, latency=...) — parallel (diagonal)."""
 
-    def __init__(self, numIns, numOuts=None, latency=kLatencyZero, device=-1, maxBlock=0, custom=None):
+    def __init__(self, numIns, numOuts=None, latency=kLatencyZero, device=-1, maxBlock=0, custom=None, tailRatio=0):
         self.L = _lib.load()
         if custom is not None:
-            # MI355X extension: custom partitioning / capacity (maxLength, zeroLatency, A, B, C, D)
+            # MI355X extension: custom partitioning / capacity (maxLength, zeroLatency, A, B, C, D) and, with tailRatio,
+            # the extended far-tail ladder (hcv_convolver_create_extended)
             maxLength, zero, A, B, C_, D = custom
             parallel = numOuts is None
-            self.h = _need(self.L.hcv_convolver_create_custom(numIns, numIns if parallel else numOuts, int(parallel), maxLength,
-                                                              int(bool(zero)), A, B, C_, D, device, maxBlock), "Convolver")
+            self.h = _need(self.L.hcv_convolver_create_extended(numIns, numIns if parallel else numOuts, int(parallel), maxLength,
+                                                                int(bool(zero)), A, B, C_, D, device, maxBlock, tailRatio), "Convolver")
         elif numOuts is None:
             self.h = _need(self.L.hcv_convolver_create_parallel(numIns, int(latency)), "Convolver")
         elif device >= 0 or maxBlock:

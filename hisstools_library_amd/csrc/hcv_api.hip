@@ -264,8 +264,39 @@ namespace
             return true;
         }
 
+        // MI355X extension (no reference analogue): continue the non-uniform partitioning ladder past the reference's
+        // largest FFT.  A stage of hop H can serve IR samples from offset H - latency onwards, so the reference's tail
+        // (hop largest/2) is capped where a `ratio` times larger FFT can take over, and so on up to 2^20.  The sum is
+        // the same convolution; the far tail just moves ratio x fewer bytes per sample per rung.  Only rungs the IR can
+        // reach (maxLength) are created.
+        void extend_tail(uint64_t maxLength, uint32_t ratio)
+        {
+            if (ratio < 2) return;
+            const uint64_t latency = zeroLatency ? 0 : sizes[0] >> 1;
+            uint64_t cur = largest, curOffset = tailOffset;
+            while (cur * ratio <= (uint64_t(1) << 20))
+            {
+                const uint64_t next = cur * ratio, nextOffset = (next >> 1) - latency;
+                if (nextOffset >= maxLength) break;
+                StageCfg st;
+                st.fft_size = (uint32_t) cur;
+                st.offset = curOffset;
+                st.length = nextOffset - curOffset;
+                st.capacity = st.length;
+                fixedStages.push_back(st);
+                cur = next;
+                curOffset = nextOffset;
+            }
+            largest = (uint32_t) cur;
+            tailOffset = (uint32_t) curOffset;
+        }
+
         // capacity of the tail PartitionedConvolve for a MemorySwap size (allocator lambda, :249-252)
-        uint64_t tail_capacity(uint64_t size) const { return std::max<uint64_t>(size, largest) - tailOffset; }
+        uint64_t tail_capacity(uint64_t size) const
+        {
+            const uint64_t reach = std::max<uint64_t>(size, largest);
+            return reach > tailOffset ? reach - tailOffset : largest >> 1;
+        }
     };
 
     struct Matrix
@@ -379,7 +410,7 @@ namespace
     };
 
     Matrix *make_matrix(uint32_t numIns, uint32_t numOuts, bool parallel, uint64_t maxLength, bool zeroLatency, uint32_t A, uint32_t B, uint32_t C,
-                        uint32_t D, int device, uint32_t maxBlock, std::string *err)
+                        uint32_t D, int device, uint32_t maxBlock, std::string *err, uint32_t tailRatio = 0)
     {
         std::unique_ptr<Matrix> m(new Matrix());
         if (!m->layout.build(zeroLatency, A, B, C, D))
@@ -388,6 +419,7 @@ namespace
             set_error(m->layout.error);
             return nullptr;
         }
+        m->layout.extend_tail(maxLength, tailRatio);
         if (!m->build(numIns, numOuts, parallel, maxLength, device, maxBlock))
         {
             if (err) *err = tlsError;
@@ -556,6 +588,19 @@ extern "C" hcv_convolver *hcv_convolver_create_custom(uint32_t numIns, uint32_t 
     numIns = numIns < 1 ? 1 : numIns;
     return wrap(make_matrix(numIns, numOuts, parallel != 0, maxLength, zeroLatency != 0, A, B, C, D, device < 0 ? gDefaultDevice : device, maxBlock,
                             nullptr));
+}
+
+extern "C" hcv_convolver *hcv_convolver_create_extended(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency, uint32_t A,
+                                                        uint32_t B, uint32_t C, uint32_t D, int device, uint32_t maxBlock, uint32_t tailRatio)
+{
+    numIns = numIns < 1 ? 1 : numIns;
+    if (tailRatio != 0 && tailRatio != 2 && tailRatio != 4 && tailRatio != 8)
+    {
+        set_error("tailRatio must be 0, 2, 4 or 8");
+        return nullptr;
+    }
+    return wrap(make_matrix(numIns, numOuts, parallel != 0, maxLength, zeroLatency != 0, A, B, C, D, device < 0 ? gDefaultDevice : device, maxBlock,
+                            nullptr, tailRatio));
 }
 
 extern "C" void hcv_convolver_destroy(hcv_convolver *h) { delete h; }

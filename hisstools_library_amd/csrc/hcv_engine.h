@@ -107,7 +107,6 @@ namespace hcv
         bool alloc_stage(Stage &st);
         void free_stage(Stage &st);
         bool global_reset();
-        bool select_streams();
         bool fence_background();
         bool apply_pending_resets();
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
@@ -126,8 +125,6 @@ namespace hcv
         // one stream per FFT stage; mTdStream: FIR head.  Events are double-buffered by block parity so block k+1 can
         // start while block k is still draining (see enqueue_chunk).
         hipStream_t mStream = nullptr, mInStream = nullptr, mTdStream = nullptr;
-        hipStream_t mInStreams[2] = { nullptr, nullptr }, mTdStreams[2] = { nullptr, nullptr };   // [1] = prioritised set
-        int mStreamSet = 0;
         hipEvent_t mEvInput[2] = { nullptr, nullptr }, mEvTd[2] = { nullptr, nullptr }, mEvEmit[2] = { nullptr, nullptr };
         hipEvent_t mEvCtl = nullptr;
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
@@ -142,7 +139,7 @@ namespace hcv
 
         // time-domain head
         float2 *mHeadSpec = nullptr;        // [nout][nin_alloc][M0] head taps as ONE zero-latency partition of the first FFT stage
-        float2 *mHeadY = nullptr;           // [Tmax0][nout][M0]
+        float2 *mHeadYq[2] = { nullptr, nullptr };   // [Tmax0][nout][M0], by block parity
         bool mHeadFFT = false;              // the head may take the FFT path (taps fit one hop of the first stage)
         float *mTaps = nullptr;
         long long *mTdValid = nullptr;

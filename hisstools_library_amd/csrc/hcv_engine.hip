@@ -78,7 +78,9 @@ struct Engine::Stage
     int log2n = 0;
     uint32_t N = 0, M = 0;
     uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
-    float2 *Hs = nullptr, *X = nullptr, *Y = nullptr;
+    float2 *Hs = nullptr, *X = nullptr;
+    float2 *Y = nullptr;                // scratch of the current block = Yq[block parity]
+    float2 *Yq[2] = { nullptr, nullptr };   // split-K partials, double-buffered so MAC(k+1) can run while block k is inverted
     size_t y_elems = 0;
     // Deferred ("time-spread") mode, the GPU form of the reference's partition scheduler (PartitionedConvolve.cpp:321-348):
     // partitions 1..P-1 of hop h+1 only need spectra up to hop h, so they are accumulated into Ypre in the BACKGROUND
@@ -90,8 +92,9 @@ struct Engine::Stage
     float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
-    hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream
-    hipStream_t streams[2] = { nullptr, nullptr };   // [0] default priority, [1] prioritised set (see Engine::select_streams)
+    hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream (the MAC stream)
+    hipStream_t streamF = nullptr, streamI = nullptr;   // forward-FFT / inverse-FFT side streams of a split (large) stage
+    hipEvent_t fft_done[2] = { nullptr, nullptr }, mac_done[2] = { nullptr, nullptr };
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
@@ -169,6 +172,11 @@ bool Engine::init(const EngineCfg &cfg)
     }
     if (mMaxBlock < 16) mMaxBlock = 16;
 
+    if (mCfg.stages.size() > (size_t) kMaxStages)
+    {
+        mErr = "too many FFT stages";
+        return false;
+    }
     uint32_t nmax = 0;
     for (const StageCfg &sc : mCfg.stages)
     {
@@ -182,16 +190,8 @@ bool Engine::init(const EngineCfg &cfg)
     }
 
     HCV_TRY(hipStreamCreateWithFlags(&mStream, hipStreamNonBlocking));
-    {
-        int least = 0, greatest = 0;
-        (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HCV_TRY(hipStreamCreateWithFlags(&mTdStreams[0], hipStreamNonBlocking));
-        HCV_TRY(hipStreamCreateWithPriority(&mTdStreams[1], hipStreamNonBlocking, least));
-        HCV_TRY(hipStreamCreateWithFlags(&mInStreams[0], hipStreamNonBlocking));
-        HCV_TRY(hipStreamCreateWithPriority(&mInStreams[1], hipStreamNonBlocking, greatest));
-        mTdStream = mTdStreams[0];
-        mInStream = mInStreams[0];
-    }
+    HCV_TRY(hipStreamCreateWithFlags(&mTdStream, hipStreamNonBlocking));
+    HCV_TRY(hipStreamCreateWithFlags(&mInStream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++)
     {
         HCV_TRY(hipEventCreateWithFlags(&mEvInput[k], hipEventDisableTiming));
@@ -249,7 +249,7 @@ bool Engine::init(const EngineCfg &cfg)
             mHeadFFT = true;
             HCV_TRY(hipMalloc(&mHeadSpec, sizeof(float2) * pairs * s0.M));
             HCV_TRY(hipMemset(mHeadSpec, 0, sizeof(float2) * pairs * s0.M));
-            HCV_TRY(hipMalloc(&mHeadY, sizeof(float2) * (size_t) s0.Tmax * mCfg.nout * s0.M));
+            for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mHeadYq[k], sizeof(float2) * (size_t) s0.Tmax * mCfg.nout * s0.M));
         }
     }
     HCV_TRY(hipDeviceSynchronize());
@@ -262,7 +262,7 @@ bool Engine::alloc_stage(Stage &st)
     uint64_t cap = st.cfg.capacity ? st.cfg.capacity : st.M;
     st.Pcap = (uint32_t) std::max<uint64_t>(1, (cap + st.M - 1) / st.M);
     st.Tmax = mMaxBlock / st.M + 1;
-    st.R = st.Pcap + st.Tmax;
+    st.R = st.Pcap + 2 * st.Tmax;      // FFT of block k+1 may write while the MAC of block k still reads
     const size_t hs_elems = pairs * st.Pcap * st.M;
     const size_t x_elems = (size_t) mCfg.nin * st.R * st.M;
     // room for split-K partials: up to 64 slices for short spectra, fewer as the bin axis alone fills the chip
@@ -272,7 +272,8 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMemset(st.Hs, 0, sizeof(float2) * hs_elems));
     HCV_TRY(hipMalloc(&st.X, sizeof(float2) * x_elems));
     HCV_TRY(hipMemset(st.X, 0, sizeof(float2) * x_elems));
-    HCV_TRY(hipMalloc(&st.Y, sizeof(float2) * st.y_elems));
+    for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&st.Yq[k], sizeof(float2) * st.y_elems));
+    st.Y = st.Yq[0];
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
     HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) mCfg.nout * st.M));
@@ -292,18 +293,13 @@ bool Engine::alloc_stage(Stage &st)
     st.tl_len = pow2ceil(2LL * mMaxBlock + st.M);       // two blocks deep (block k+1 adds while block k is emitted)
     HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
     HCV_TRY(hipMemset(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len));
+    HCV_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+    HCV_TRY(hipStreamCreateWithFlags(&st.streamF, hipStreamNonBlocking));
+    HCV_TRY(hipStreamCreateWithFlags(&st.streamI, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++)
     {
-        // Two stream sets.  Set 1 is prioritised: the largest stage carries the HBM-bound critical path and gets the
-        // highest priority so the latency-bound work of the other streams fills in around it instead of delaying it.
-        // Priority queues add cross-stream hand-off latency, which would dominate small (launch-bound) engines, so set 0
-        // (all default priority) is used until the tail's spectra are large (select_streams).
-        int least = 0, greatest = 0;
-        (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
-        uint32_t nmax = 0;
-        for (const StageCfg &sc : mCfg.stages) nmax = std::max(nmax, sc.fft_size);
-        HCV_TRY(hipStreamCreateWithFlags(&st.streams[0], hipStreamNonBlocking));
-        HCV_TRY(hipStreamCreateWithPriority(&st.streams[1], hipStreamNonBlocking, st.N == nmax ? greatest : least));
-        st.stream = st.streams[0];
+        HCV_TRY(hipEventCreateWithFlags(&st.fft_done[k], hipEventDisableTiming));
+        HCV_TRY(hipEventCreateWithFlags(&st.mac_done[k], hipEventDisableTiming));
     }
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming));
     return true;
@@ -313,7 +309,17 @@ void Engine::free_stage(Stage &st)
 {
     if (st.Hs) (void) hipFree(st.Hs);
     if (st.X) (void) hipFree(st.X);
-    if (st.Y) (void) hipFree(st.Y);
+    for (int k = 0; k < 2; k++)
+    {
+        if (st.Yq[k]) (void) hipFree(st.Yq[k]);
+        if (st.fft_done[k]) (void) hipEventDestroy(st.fft_done[k]);
+        if (st.mac_done[k]) (void) hipEventDestroy(st.mac_done[k]);
+        st.Yq[k] = nullptr;
+        st.fft_done[k] = st.mac_done[k] = nullptr;
+    }
+    if (st.streamF) (void) hipStreamDestroy(st.streamF);
+    if (st.streamI) (void) hipStreamDestroy(st.streamI);
+    st.streamF = st.streamI = nullptr;
     if (st.hv) (void) hipFree(st.hv);
     if (st.timeline) (void) hipFree(st.timeline);
     if (st.Ypre) (void) hipFree(st.Ypre);
@@ -325,10 +331,9 @@ void Engine::free_stage(Stage &st)
     st.big.a = st.big.b = nullptr;
     for (int k = 0; k < 2; k++)
         if (st.done[k]) (void) hipEventDestroy(st.done[k]);
-    for (int k = 0; k < 2; k++)
-        if (st.streams[k]) (void) hipStreamDestroy(st.streams[k]);
-    st.streams[0] = st.streams[1] = nullptr;
+    if (st.stream) (void) hipStreamDestroy(st.stream);
     st.Hs = st.X = st.Y = nullptr;
+    st.stream = nullptr;
     st.hv = nullptr;
     st.timeline = nullptr;
     st.done[0] = st.done[1] = nullptr;
@@ -341,7 +346,11 @@ Engine::~Engine()
     if (mInStream) (void) hipStreamSynchronize(mInStream);
     if (mTdStream) (void) hipStreamSynchronize(mTdStream);
     for (Stage *st : mStages)
+    {
         if (st->stream) (void) hipStreamSynchronize(st->stream);
+        if (st->streamF) (void) hipStreamSynchronize(st->streamF);
+        if (st->streamI) (void) hipStreamSynchronize(st->streamI);
+    }
     if (mStream) (void) hipStreamSynchronize(mStream);
     for (Stage *st : mStages)
     {
@@ -364,7 +373,8 @@ Engine::~Engine()
     if (mIrBuf) (void) hipFree(mIrBuf);
     if (mTaps) (void) hipFree(mTaps);
     if (mHeadSpec) (void) hipFree(mHeadSpec);
-    if (mHeadY) (void) hipFree(mHeadY);
+    for (int k = 0; k < 2; k++)
+        if (mHeadYq[k]) (void) hipFree(mHeadYq[k]);
     if (mTdValid) (void) hipFree(mTdValid);
     for (int k = 0; k < 2; k++)
     {
@@ -373,11 +383,8 @@ Engine::~Engine()
         if (mEvEmit[k]) (void) hipEventDestroy(mEvEmit[k]);
     }
     if (mEvCtl) (void) hipEventDestroy(mEvCtl);
-    for (int k = 0; k < 2; k++)
-    {
-        if (mInStreams[k]) (void) hipStreamDestroy(mInStreams[k]);
-        if (mTdStreams[k]) (void) hipStreamDestroy(mTdStreams[k]);
-    }
+    if (mInStream) (void) hipStreamDestroy(mInStream);
+    if (mTdStream) (void) hipStreamDestroy(mTdStream);
     if (mStream) (void) hipStreamDestroy(mStream);
 }
 
@@ -444,7 +451,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     if (!fence_background()) return false;
 
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
-    const uint32_t newR = newP + st.Tmax;
+    const uint32_t newR = newP + 2 * st.Tmax;
     float2 *nHs = nullptr, *nX = nullptr;
     const size_t hs_bytes = sizeof(float2) * pairs * newP * st.M;
     const size_t x_bytes = sizeof(float2) * (size_t) mCfg.nin * newR * st.M;
@@ -639,30 +646,6 @@ bool Engine::apply_pending_resets()
     return true;
 }
 
-// Pick the stream set for the coming blocks: prioritised streams once the largest stage streams >= 128 MiB of IR
-// spectra per hop (then the tail MAC runs for tens of microseconds or more and is worth protecting).  Switching sets
-// drains the engine first; it only happens when IRs are loaded or cleared.
-bool Engine::select_streams()
-{
-    static const int force = std::getenv("HCV_STREAM_PRIO") ? std::atoi(std::getenv("HCV_STREAM_PRIO")) : -1;
-    size_t big = 0;
-    for (Stage *st : mStages)
-    {
-        size_t live = 0;
-        for (uint32_t p : st->pact) live += p;
-        big = std::max(big, live * st->M * sizeof(float2));
-    }
-    const int want = force >= 0 ? (force ? 1 : 0) : (big >= (size_t(128) << 20) ? 1 : 0);
-    if (want == mStreamSet) return true;
-    HCV_TRY(hipStreamSynchronize(mStream));
-    for (Stage *st : mStages) HCV_TRY(hipStreamSynchronize(st->stream));    // background accumulations included
-    mStreamSet = want;
-    mInStream = mInStreams[want];
-    mTdStream = mTdStreams[want];
-    for (Stage *st : mStages) st->stream = st->streams[want];
-    return true;
-}
-
 // One block of at most max_block samples, everything device side.  Caller holds mMutex.
 //
 // Stream plan for block k (q = k & 1; every event and the FIR output buffer exist twice, indexed by block parity):
@@ -687,7 +670,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
     if (mCtlDirty)
     {
-        if (!select_streams()) return false;
         HCV_TRY(hipEventRecord(mEvCtl, mStream));
         HCV_TRY(hipStreamWaitEvent(mInStream, mEvCtl, 0));
         mCtlDirty = false;
@@ -718,11 +700,10 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
     EmitSources src;
     src.count = 0;
-    static const bool tail_first = !std::getenv("HCV_TAIL_LAST");
     // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     for (size_t sj = 0; sj < mStages.size(); sj++)
     {
-        const size_t si = tail_first ? mStages.size() - 1 - sj : sj;
+        const size_t si = mStages.size() - 1 - sj;
         Stage &st = *mStages[si];
         src.timeline[src.count] = st.timeline;              // the ring may still hold hops of earlier calls
         src.stride[src.count] = st.tl_len;
@@ -734,14 +715,27 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const int T = (int) ((n0 + B) / st.M - h_first);
         if (T <= 0) continue;
 
-        hipStream_t ss = st.stream;
-        HCV_TRY(hipStreamWaitEvent(ss, mEvInput[q], 0));
-        HCV_TRY(hipStreamWaitEvent(ss, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
-        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, ss));
+        // Optional (HCV_SPLIT=1): split a large stage over three streams — forward FFTs | spectral_mac | reduce + inverse
+        // FFT — so that its MACs run back to back.  Measured slower than one stream per stage on this stack (c5 2.09 vs
+        // 1.98 ms/step, ns64 2.95 vs 2.55): every additional active stream competes for hardware queues.
+        static const bool allow_split = std::getenv("HCV_SPLIT") && std::atoi(std::getenv("HCV_SPLIT")) == 1;
+        size_t live = 0;
+        for (uint32_t p : st.pact) live += p;
+        const bool split = allow_split && live * st.M * sizeof(float2) >= (size_t(128) << 20);
+        hipStream_t sF = split ? st.streamF : st.stream, sM = st.stream, sI = split ? st.streamI : st.stream;
+        st.Y = st.Yq[q];
+
+        HCV_TRY(hipStreamWaitEvent(sF, mEvInput[q], 0));
+        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
+        if (split)
+        {
+            HCV_TRY(hipEventRecord(st.fft_done[q], sF));
+            HCV_TRY(hipStreamWaitEvent(sM, st.fft_done[q], 0));
+        }
 
         if (head_here)
         {
-            // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i], emitted with NO latency (hop h at h*M)
+            // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
             MacShape hs;
             hs.M = (int) st.M;
             hs.R = (int) st.R;
@@ -756,15 +750,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             hs.target_blocks = 0;
             MacPlan hp;
             mac_plan(hs, hp);
-            HCV_TRY(launch_spectral_mac(hs, hp, st.X, mHeadSpec, mHeadY, st.hv, h_first, false, ss));
-            HCV_TRY(launch_rifft_overlap_add(st.log2n, mHeadY, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
-                                             &st.big, ss));
-        }
-        if (!st.P)
-        {
-            HCV_TRY(hipEventRecord(st.done[q], ss));
-            HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
-            continue;
+            HCV_TRY(launch_spectral_mac(hs, hp, st.X, mHeadSpec, mHeadYq[q], st.hv, h_first, false, sM));
         }
 
         // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
@@ -787,7 +773,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
         // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
         static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
-        const bool defer = allow_defer && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && !is_big_fft(st.log2n) && nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+        const bool defer = allow_defer && st.P > 0 && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && nout_act == mCfg.nout &&
+                           nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
         const bool have_pre = defer && st.pre_hop == h_first;
 
         EventPair *ev = nullptr;
@@ -805,72 +792,103 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             }
             ev->stage = si;
             ev->live = true;
-            HCV_TRY(hipEventRecord(ev->a, ss));
+            HCV_TRY(hipEventRecord(ev->a, sM));
             return true;
         };
 
+        // ---- MAC phase (stream sM)
         MacPlan pl;
-        if (have_pre)
+        pl.ksplit = 1;
+        if (st.P)
         {
-            // boundary of a hop whose partitions 1..P-1 were accumulated in the background: partition 0 only
-            MacShape s0 = sh;
-            s0.P = 1;
-            s0.max_ksplit = 1;
-            mac_plan(s0, pl);
-            HCV_TRY(launch_spectral_mac(s0, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, ss));
-            // inverse FFT of Y (partition 0) + Ypre (partitions >= 1): the two buffers are read as two "partials"
-            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 2, (long long) (st.Ypre - st.Y), h_first, 1, (int) nout_act, st.timeline, st.tl_len,
-                                             st.tl_len - 1, st.tw, &st.big, ss));
+            if (have_pre)
+            {
+                // boundary of a hop whose partitions 1..P-1 were accumulated in the background: partition 0 only
+                MacShape s0 = sh;
+                s0.P = 1;
+                s0.max_ksplit = 1;
+                mac_plan(s0, pl);
+                HCV_TRY(launch_spectral_mac(s0, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, sM));
+            }
+            else
+            {
+                mac_plan(sh, pl);
+                if (!begin_event()) return false;
+                HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, sM));
+                if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
+                st.launches++;
+                st.hops += (uint64_t) T;
+                st.last_ksplit = (uint32_t) pl.ksplit;
+                st.last_ot = (uint32_t) pl.ot;
+            }
         }
-        else
+        if (split)
         {
-            mac_plan(sh, pl);
-            if (!begin_event()) return false;
-            HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, ss));
-            if (ev) HCV_TRY(hipEventRecord(ev->b, ss));
-            st.launches++;
-            st.hops += (uint64_t) T;
-            st.last_ksplit = (uint32_t) pl.ksplit;
-            st.last_ot = (uint32_t) pl.ot;
-            HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, ss));
-            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw, &st.big,
-                                             ss));
+            HCV_TRY(hipEventRecord(st.mac_done[q], sM));
+            HCV_TRY(hipStreamWaitEvent(sI, st.mac_done[q], 0));
         }
-        HCV_TRY(hipEventRecord(st.done[q], ss));
+
+        // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
+        HCV_TRY(hipStreamWaitEvent(sI, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
+        if (head_here)
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, mHeadYq[q], 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                             &st.big, sI));           // h_first - 1: emitted with NO latency (hop h at h*M)
+        if (st.P)
+        {
+            if (have_pre)
+            {
+                // inverse FFT of Y (partition 0) + Ypre (partitions >= 1): the two buffers are read as two "partials"
+                if (is_big_fft(st.log2n))
+                {
+                    HCV_TRY(launch_reduce_partials(st.Y, 2, (long long) (st.Ypre - st.Y), y_elems, sI));
+                    HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1,
+                                                     st.tw, &st.big, sI));
+                }
+                else
+                    HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 2, (long long) (st.Ypre - st.Y), h_first, 1, (int) nout_act, st.timeline, st.tl_len,
+                                                     st.tl_len - 1, st.tw, &st.big, sI));
+            }
+            else
+            {
+                HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, sI));
+                HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                                 &st.big, sI));
+            }
+        }
+        HCV_TRY(hipEventRecord(st.done[q], sI));
         HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
 
         st.pre_hop = -1;
         if (defer)
         {
             // background: Ypre for hop h+1 = sum_{p>=1} X[h+1-p] H[p]  ==  a (P-1)-partition MAC at hop h over H shifted by
-            // one partition.  Queued behind this block's result on the stage stream; nothing in this call waits for it.
+            // one partition.  Queued on the MAC stream behind this block; nothing in this call waits for it.  It works in
+            // the OTHER parity's scratch (this block's is still being inverted) and only touches Ypre after that.
             MacShape sb = sh;
             sb.P = (int) std::min<long long>(st.P - 1, h_first + 1);    // partitions p' = p - 1 <= h that have input
             MacPlan pb;
-            // partials live in st.Y behind slice 0 (which the critical path of the next boundary reuses only after this)
             sb.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M));
             // small footprint: there is a whole hop of real time to finish, and the calls in between need free CUs
             static const int bg_blocks = std::getenv("HCV_BG_BLOCKS") ? std::atoi(std::getenv("HCV_BG_BLOCKS")) : 128;
             sb.target_blocks = bg_blocks;
             mac_plan(sb, pb);
+            float2 *scratch = st.Yq[q ^ 1];
             ev = nullptr;
             if (!begin_event()) return false;
             const bool bcheck = (h_first - st.max_hv) < (long long) st.P - 1;
-            HCV_TRY(launch_spectral_mac(sb, pb, st.X, st.Hs + st.M, st.Y, st.hv, h_first, bcheck, ss));
-            if (ev) HCV_TRY(hipEventRecord(ev->b, ss));
+            HCV_TRY(launch_spectral_mac(sb, pb, st.X, st.Hs + st.M, scratch, st.hv, h_first, bcheck, sM));
+            if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
             st.launches++;
             st.hops += 1;
             st.last_ksplit = (uint32_t) pb.ksplit;
             st.last_ot = (uint32_t) pb.ot;
-            HCV_TRY(launch_reduce_partials(st.Y, pb.ksplit, y_elems, y_elems, ss));
-            HCV_TRY(hipMemcpyAsync(st.Ypre, st.Y, sizeof(float2) * (size_t) nout_act * st.M, hipMemcpyDeviceToDevice, ss));
-            HCV_TRY(hipEventRecord(st.bg_done, ss));
+            HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, y_elems, y_elems, sM));
+            HCV_TRY(hipStreamWaitEvent(sM, st.done[q], 0));          // the inverse of this block may still be reading Ypre
+            HCV_TRY(hipMemcpyAsync(st.Ypre, scratch, sizeof(float2) * (size_t) nout_act * st.M, hipMemcpyDeviceToDevice, sM));
+            HCV_TRY(hipEventRecord(st.bg_done, sM));
             st.bg_pending = true;
             st.pre_hop = h_first + 1;
         }
-        continue;
-        HCV_TRY(hipEventRecord(st.done[q], ss));
-        HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
     }
 
     if (td) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd[q], 0));

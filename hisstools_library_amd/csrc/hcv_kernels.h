@@ -72,7 +72,8 @@ namespace hcv
     // ---- ring bookkeeping ----
     hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,
                                     long long n0, hipStream_t st);
-    constexpr int kMaxStages = 4;         // MonoConvolve builds at most 4 FFT stages (MonoConvolve.cpp:235-252)
+    constexpr int kMaxStages = 8;         // MonoConvolve builds at most 4 FFT stages (MonoConvolve.cpp:235-252); the extended
+                                          // tail ladder (hcv_api.hip) adds up to 3 more
     struct EmitSources
     {
         float *timeline[kMaxStages];

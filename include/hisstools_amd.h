@@ -135,6 +135,12 @@ HCV_API int hcv_convolver_process_f64(hcv_convolver *h, const double *const *ins
 HCV_API hcv_convolver *hcv_convolver_create_on(uint32_t numIns, uint32_t numOuts, int latency, int device, uint32_t maxBlock);
 HCV_API hcv_convolver *hcv_convolver_create_custom(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency,
                                                    uint32_t A, uint32_t B, uint32_t C, uint32_t D, int device, uint32_t maxBlock);
+/* As create_custom, plus an extended non-uniform partitioning of the far tail: past the reference's largest FFT the IR
+ * is served by FFTs `tailRatio` (2, 4 or 8; 0 = off) times larger per rung, up to 2^20, as far as maxLength reaches.
+ * Same convolution, same latency; the far tail moves tailRatio x fewer HBM bytes per sample per rung. */
+HCV_API hcv_convolver *hcv_convolver_create_extended(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency,
+                                                     uint32_t A, uint32_t B, uint32_t C, uint32_t D, int device, uint32_t maxBlock,
+                                                     uint32_t tailRatio);
 /* IR already in HBM on the object's device */
 HCV_API int hcv_convolver_set_f32_dev(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const float *input_dev, uintptr_t length, int resize);
 /* ins_dev: [numIns][in_stride] floats, outs_dev: [numOuts][out_stride] floats, both in HBM.  Asynchronous on the object's

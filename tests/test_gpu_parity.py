@@ -512,6 +512,32 @@ def _sparse_matrix_case(H, nin, nout, L, S, block, latency, seed):
         assert rel_err(y[o], t) < TOL_SUM, (o, rel_err(y[o], t))
 
 
+@pytest.mark.parametrize("ratio,latency_zero", [(8, True), (4, True), (8, False)])
+def test_extended_tail_ladder_matches_reference_layout(H, oracle, ratio, latency_zero):
+    """MI355X extension: past the reference's largest FFT the far tail is served by `ratio` times larger FFTs per
+    rung (up to 2^20).  It must be the same convolution with the same latency as the reference partitioning."""
+    nin, nout, L, S = 2, 2, 700000, 900000
+    irs = {(i, o): oracle.synth_ir(i, o, L - 1000 * i - 10 * o) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    lat = 0 if latency_zero else 128
+    c = H.Convolver(nin, nout, custom=(L, latency_zero, 256, 1024, 4096, 16384), tailRatio=ratio, maxBlock=32768)
+    st = c.stage_stats()
+    assert [s["fft_size"] for s in st][-1] == (1 << 20)           # the ladder reached the largest FFT
+    for (i, o), h in irs.items():
+        assert c.set(i, o, h, True) == 0
+    y = c.run(xs, nout, [8192, 32768, 1000, 333])
+    for o in range(nout):
+        truth = sum(truth_conv(xs[i], irs[(i, o)], lat) for i in range(nin))
+        assert rel_err(y[o], truth) < TOL_SUM
+    # and the plain reference layout gives the same stream
+    r = H.Convolver(nin, nout, custom=(L, latency_zero, 256, 1024, 4096, 16384), maxBlock=32768)
+    for (i, o), h in irs.items():
+        assert r.set(i, o, h, True) == 0
+    y_r = r.run(xs[:, :200000], nout, 8192)
+    for o in range(nout):
+        assert rel_err(y[o][:200000], y_r[o]) < TOL_SUM
+
+
 def test_config4_shape_64x64_2s_impulse_irs(H):
     _sparse_matrix_case(H, 64, 64, 96000, 3 * 8192 + 100, 8192, 0, seed=4)
 

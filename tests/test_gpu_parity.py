@@ -362,6 +362,37 @@ def test_small_blocks_use_deferred_tail_and_match(H, oracle):
     assert rel_err(m.run(x, 256), truth) < TOL
 
 
+def test_process_argument_edge_cases(H, oracle):
+    """numIns / numOuts smaller than constructed, calls longer than the engine's internal block, zero-length calls."""
+    nin, nout, L, S = 3, 3, 4000, 90000
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    c = H.Convolver(nin, nout, 1)
+    for (i, o), h in irs.items():
+        assert c.set(i, o, h, True) == 0
+    # one call far longer than the internal block (32768): chunked internally, same stream
+    y = np.zeros((nout, S), np.float32)
+    c.process(xs, y)
+    for o in range(nout):
+        assert rel_err(y[o], sum(truth_conv(xs[i], irs[(i, o)], 128) for i in range(nin))) < TOL_SUM
+    # a zero-length call is a no-op
+    c.process(xs[:, :0], np.zeros((nout, 0), np.float32))
+    # fewer active inputs / outputs than constructed (Convolver.cpp:148-153, NToMonoConvolve.cpp:41)
+    c.reset()
+    y2 = np.full((nout, 5000), 7.0, np.float32)
+    c.process(np.ascontiguousarray(xs[:, :5000]), y2, numIns=2, numOuts=2)
+    for o in range(2):
+        assert rel_err(y2[o], sum(truth_conv(xs[i, :5000], irs[(i, o)], 128) for i in range(2))) < TOL_SUM
+    assert (y2[2] == 7.0).all()                                   # rows beyond numOuts are not written
+    # the double overload clamps to the constructed sizes and converts through float (Convolver.cpp:156-183)
+    c.reset()
+    xd = xs[:, :4096].astype(np.float64)
+    yd = np.zeros((nout, 4096), np.float64)
+    c.process(xd, yd, numIns=9, numOuts=9)
+    for o in range(nout):
+        assert rel_err(yd[o], sum(truth_conv(xs[i, :4096], irs[(i, o)], 128) for i in range(nin))) < TOL_SUM
+
+
 def test_silent_and_cleared_pairs(H, oracle):
     xs = np.stack([oracle.synth_audio(i, 4000) for i in range(2)])
     h = oracle.synth_ir(0, 0, 2000)

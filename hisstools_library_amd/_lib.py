@@ -89,6 +89,9 @@ SIGNATURES = {
     "hcv_convolver_num_stages": (C.c_int, [vp]),
     "hcv_convolver_stage_stats": (C.c_int, [vp, C.c_int, C.POINTER(StageStats)]),
     "hcv_convolver_clear_stats": (None, [vp]),
+    "hcv_spectral_size": (usz, [usz, usz, C.c_int]),
+    "hcv_spectral_convolve_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
+    "hcv_spectral_correlate_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
 }
 
 _lib = None

@@ -108,6 +108,43 @@ def hisstools_rifft(realp, imagp, log2n: int):
     return out[0] if one else out
 
 
+# ------------------------------------------------------------------------------------------- spectral_processor (next row)
+
+class EdgeMode(IntEnum):               # spectral_processor::EdgeMode, SpectralProcessor.hpp:22
+    Linear = 0
+    Wrap = 1
+    WrapCentre = 2
+    Fold = 3
+    FoldRepeat = 4
+
+
+class spectral_processor:
+    """Real overloads of spectral_processor<float>::convolve / correlate (SpectralProcessor.hpp:173-184)."""
+
+    def __init__(self, max_fft_size=1 << 20):
+        self.L = _lib.load()
+        self._max = max_fft_size
+
+    def convolved_size(self, size1, size2, mode):
+        return self.L.hcv_spectral_size(size1, size2, int(mode))
+
+    correlated_size = convolved_size
+
+    def _run(self, fn, in1, in2, mode, what):
+        a, b = _f32(in1), _f32(in2)
+        n = self.L.hcv_spectral_size(a.size, b.size, int(mode))
+        out = np.zeros(n, np.float32)
+        if n:
+            _check(fn(_fp(a), a.size, _fp(b), b.size, int(mode), _fp(out)), what)
+        return out
+
+    def convolve(self, in1, in2, mode=EdgeMode.Linear):
+        return self._run(self.L.hcv_spectral_convolve_f32, in1, in2, mode, "spectral_processor.convolve")
+
+    def correlate(self, in1, in2, mode=EdgeMode.Linear):
+        return self._run(self.L.hcv_spectral_correlate_f32, in1, in2, mode, "spectral_processor.correlate")
+
+
 # ------------------------------------------------------------------------------------------- classes
 
 class PartitionedConvolve:

@@ -914,3 +914,193 @@ extern "C" int hcv_rifft_f32(const float *realp, const float *imagp, size_t batc
     if (dout) (void) hipFree(dout);
     return ok ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------------ spectral_processor (next row)
+//
+// spectral_processor<float>::convolve / correlate, real overloads (SpectralProcessor.hpp:173-184): both inputs are
+// transformed with the real FFT kernels, multiplied bin-wise on the device, inverted and arranged per edge mode.
+// Host code only sizes the problem and lays the inputs out (zero padding, mirrored edges); it does no arithmetic.
+
+namespace
+{
+    enum { EDGE_LINEAR = 0, EDGE_WRAP = 1, EDGE_WRAP_CENTRE = 2, EDGE_FOLD = 3, EDGE_FOLD_REPEAT = 4 };
+
+    struct OpSizes                                              // op_sizes, SpectralProcessor.hpp:318-357
+    {
+        int mode;
+        bool fold;
+        size_t size1, size2, mn, mx, linear, fold_copy, fft;
+        unsigned fft_log2;
+    };
+
+    unsigned spectral_log2(size_t size)                         // calc_fft_size_log2, :231-243
+    {
+        unsigned count = 0;
+        while (count < 8 * sizeof(size_t) && (size >> count)) count++;
+        if (count && size == (size_t(1) << (count - 1))) return count - 1;
+        return count;
+    }
+
+    OpSizes op_sizes(size_t n1, size_t n2, int mode)
+    {
+        OpSizes s;
+        s.mode = mode;
+        s.fold = mode == EDGE_FOLD || mode == EDGE_FOLD_REPEAT;
+        s.size1 = n1;
+        s.size2 = n2;
+        s.mn = std::min(n1, n2);
+        s.mx = std::max(n1, n2);
+        s.linear = n1 + n2 - 1;
+        s.fold_copy = s.mx + ((s.mn >> 1) << 1);
+        s.fft_log2 = spectral_log2(s.fold ? s.fold_copy + (s.mn - 1) : s.linear);
+        s.fft = size_t(1) << s.fft_log2;
+        return s;
+    }
+
+    void copy_fold(float *dst, const float *in, size_t size, size_t fold_size, bool repeat)   // :361-377
+    {
+        const size_t off = repeat ? 0 : 1;
+        std::memcpy(dst + fold_size, in, sizeof(float) * size);
+        for (size_t i = 0; i < fold_size; i++)
+        {
+            dst[i] = in[off + fold_size - 1 - i];
+            dst[fold_size + size + i] = in[size - off - 1 - i];
+        }
+    }
+}
+
+extern "C" size_t hcv_spectral_size(size_t size1, size_t size2, int mode)                      // calc_conv_corr_size, :549-560
+{
+    if (!size1 || !size2 || mode < 0 || mode > EDGE_FOLD_REPEAT) return 0;
+    const OpSizes s = op_sizes(size1, size2, mode);
+    if (s.fft_log2 > (unsigned) hcv::kMaxFFTLog2) return 0;     // our "max_fft_size" is 2^20
+    return mode != EDGE_LINEAR ? s.mx : s.linear;
+}
+
+static int spectral_binary(const float *in1, size_t n1, const float *in2, size_t n2, int mode, bool correlate, float *out)
+{
+    const size_t result = hcv_spectral_size(n1, n2, mode);
+    if (!result) return 0;                                      // the reference returns without touching `out` (:651-652)
+    if (hcv_device_count() <= 0)
+    {
+        set_error("no HIP device available (no CPU fallback)");
+        return -1;
+    }
+    if (gDefaultDevice >= 0) (void) hipSetDevice(gDefaultDevice);
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+
+    const OpSizes s = op_sizes(n1, n2, mode);
+    // the device FFTs start at 32 points; a larger circular size is equivalent as long as every index below uses it
+    const unsigned log2n = std::max(s.fft_log2, 5u);
+    const size_t fft = size_t(1) << log2n, half = fft >> 1;
+
+    std::vector<float> host(2 * fft, 0.f);
+    float *h1 = host.data(), *h2 = host.data() + fft;
+    const size_t fold_size = s.mn >> 1;
+    const bool repeat = mode == EDGE_FOLD_REPEAT;
+    if (s.fold && n1 >= n2) copy_fold(h1, in1, n1, fold_size, repeat); else std::memcpy(h1, in1, sizeof(float) * n1);
+    if (s.fold && n1 < n2) copy_fold(h2, in2, n2, fold_size, repeat); else std::memcpy(h2, in2, sizeof(float) * n2);
+
+    std::string err;
+    const float2 *tw = hcv::twiddles(dev, (int) log2n, &err);
+    if (!tw)
+    {
+        set_error(err);
+        return -1;
+    }
+    bool ok = true;
+    float *din = nullptr, *dt = nullptr, *dout = nullptr;
+    float2 *dspec = nullptr;
+    ScopedBigWork big(dev, log2n, 2);
+    ok = big.ok;
+    if (ok) HCV_API_TRY(hipMalloc(&din, sizeof(float) * 2 * fft));
+    if (ok) HCV_API_TRY(hipMalloc(&dspec, sizeof(float2) * 2 * half));
+    if (ok) HCV_API_TRY(hipMalloc(&dt, sizeof(float) * fft));
+    if (ok) HCV_API_TRY(hipMalloc(&dout, sizeof(float) * result));
+    if (ok) HCV_API_TRY(hipMemcpy(din, host.data(), sizeof(float) * 2 * fft, hipMemcpyHostToDevice));
+    if (ok) HCV_API_TRY(hcv::launch_rfft_rows((int) log2n, din, (long long) fft, (long long) fft, 2, dspec, tw, &big.w, nullptr));
+    if (ok) HCV_API_TRY(hcv::launch_spectral_pointwise(dspec, dspec + half, (int) half, 0.25f / (float) fft, correlate ? 1 : 0, nullptr));
+    if (ok) HCV_API_TRY(hcv::launch_rifft_rows((int) log2n, dspec, 1, dt, tw, &big.w, nullptr));
+
+    auto seg = [&](size_t o_off, size_t off, size_t n, int op)
+    {
+        if (ok) HCV_API_TRY(hcv::launch_segment_op(dout, dt, (long long) o_off, (long long) off, (long long) n, op, nullptr));
+    };
+    auto copy = [&](size_t o_off, size_t off, size_t n) { seg(o_off, off, n, 0); };
+    auto wrap = [&](size_t o_off, size_t last, size_t n) { seg(o_off, last - n, n, 1); };     // adds t[last-n .. last)
+    auto zero = [&](size_t a, size_t b) { if (b > a) seg(a, 0, b - a, 2); };
+
+    if (n1 == 1 && n2 == 1)
+        copy(0, 0, 1);                                          // circular product of two 1-sample signals
+    else if (!correlate)
+    {
+        const size_t min_m1 = s.mn - 1;                         // arrange_convolve, :448-486
+        switch (mode)
+        {
+            case EDGE_LINEAR: copy(0, 0, s.linear); break;
+            case EDGE_WRAP: copy(0, 0, s.mx); wrap(0, s.linear, min_m1); break;
+            case EDGE_WRAP_CENTRE:
+            {
+                const size_t wrapped = min_m1 >> 1;
+                copy(0, wrapped, s.mx);
+                wrap(0, s.linear, min_m1 - wrapped);
+                wrap(s.mx - wrapped, wrapped, wrapped);
+                break;
+            }
+            default: copy(0, min_m1, s.mx); break;
+        }
+    }
+    else
+    {
+        const size_t size2_m1 = s.size2 - 1;                    // arrange_correlate, :488-545 (fft = the size actually used)
+        switch (mode)
+        {
+            case EDGE_LINEAR: copy(0, 0, s.size1); copy(s.size1, fft - size2_m1, size2_m1); break;
+            case EDGE_WRAP:
+                copy(0, 0, s.size1);
+                zero(s.size1, s.size2);
+                wrap(s.mx - size2_m1, fft, size2_m1);
+                break;
+            case EDGE_WRAP_CENTRE:
+            {
+                const size_t w1 = (s.mn - 1) >> 1;
+                const size_t w2 = std::min(size2_m1, s.mx - w1);
+                const size_t w3 = size2_m1 - w2;
+                const size_t offset = w3 ? 0 : s.mx - (size2_m1 + w1);
+                zero(0, s.mx);
+                copy(0, w1, s.size1 - w1);
+                copy(s.mx - w1, 0, w1);
+                wrap(offset, fft, w2);
+                wrap(s.mx - w3, fft - w2, w3);
+                break;
+            }
+            default:
+                if (s.size1 >= s.size2)
+                    copy(0, 0, s.mx);
+                else
+                {
+                    const size_t cs = s.mx - 1;
+                    copy(0, 0, 1);
+                    copy(1, fft - cs, cs);
+                }
+                break;
+        }
+    }
+    if (ok) HCV_API_TRY(hipMemcpy(out, dout, sizeof(float) * result, hipMemcpyDeviceToHost));
+    if (din) (void) hipFree(din);
+    if (dspec) (void) hipFree(dspec);
+    if (dt) (void) hipFree(dt);
+    if (dout) (void) hipFree(dout);
+    return ok ? 0 : -1;
+}
+
+extern "C" int hcv_spectral_convolve_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out)
+{
+    return spectral_binary(in1, size1, in2, size2, mode, false, out);
+}
+
+extern "C" int hcv_spectral_correlate_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out)
+{
+    return spectral_binary(in1, size1, in2, size2, mode, true, out);
+}

@@ -83,6 +83,9 @@ namespace hcv
     };
     hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, const float *td, long long td_stride, float *out,
                            long long out_stride, hipStream_t st);
+    // ---- one-shot spectral convolution / correlation ----
+    hipError_t launch_spectral_pointwise(float2 *a, const float2 *b, int M, float scale, int correlate, hipStream_t st);
+    hipError_t launch_segment_op(float *out, const float *t, long long o_off, long long off, long long n, int op, hipStream_t st);
     hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st);
     hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st);
     hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st);

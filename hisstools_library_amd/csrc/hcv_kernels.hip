@@ -472,6 +472,38 @@ __global__ void regrow_ring_kernel(const float4 *__restrict__ src, float4 *__res
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M2; e += gridDim.x * blockDim.x) d[e] = s[e];
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-shot spectral convolution / correlation (spectral_processor::convolve/correlate, real overloads —
+// SpectralProcessor.hpp:617-674): bin-wise product of two packed half spectra and the output arrangement.
+// ------------------------------------------------------------------------------------------------
+
+// a = scale * (a op b): op = complex product (convolve) or product with the conjugate of b (correlate); bin 0 holds
+// (DC, Nyquist) and takes two real products (real_operation, SpectralFunctions.hpp:63-83)
+__global__ void spectral_pointwise_kernel(float2 *__restrict__ a, const float2 *__restrict__ b, int M, float scale, int correlate)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    const float2 x = a[k], y = b[k];
+    if (k == 0)
+        a[0] = make_float2(scale * (x.x * y.x), scale * (x.y * y.y));
+    else if (!correlate)
+        a[k] = make_float2(scale * (x.x * y.x - x.y * y.y), scale * (x.y * y.x + x.x * y.y));
+    else
+        a[k] = make_float2(scale * (x.x * y.x + x.y * y.y), scale * (x.y * y.x - x.x * y.y));
+}
+
+// out[o_off + i] (=, +=) t[off + i]  or  out[o_off + i] = 0 : the copy / wrap / zero steps of arrange_convolve and
+// arrange_correlate (SpectralProcessor.hpp:448-545); op 0 copy, 1 add, 2 zero
+__global__ void segment_op_kernel(float *__restrict__ out, const float *__restrict__ t, long long o_off, long long off, long long n, int op)
+{
+    for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+    {
+        if (op == 0) out[o_off + i] = t[off + i];
+        else if (op == 1) out[o_off + i] += t[off + i];
+        else out[o_off + i] = 0.f;
+    }
+}
+
 // ================================================================================================
 // launchers
 // ================================================================================================
@@ -639,6 +671,20 @@ hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, co
     if (B <= 0 || nout <= 0) return hipSuccess;
     dim3 grid(std::min((B + 255) / 256, 64), nout);
     hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, src, n0, B, td, td_stride, out, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectral_pointwise(float2 *a, const float2 *b, int M, float scale, int correlate, hipStream_t st)
+{
+    hipLaunchKernelGGL(spectral_pointwise_kernel, dim3((M + 255) / 256), dim3(256), 0, st, a, b, M, scale, correlate);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_op(float *out, const float *t, long long o_off, long long off, long long n, int op, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int grid = (int) std::min<long long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(segment_op_kernel, dim3(grid), dim3(256), 0, st, out, t, o_off, off, n, op);
     return hipGetLastError();
 }
 

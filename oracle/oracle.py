@@ -460,3 +460,53 @@ class Convolver:
         outs = np.zeros((numOuts, total), np.float32)
         secs = self.L.conv_stream(self.h, _fp(ins), _fp(outs), nin, numOuts, total, block)
         return outs, secs
+
+
+# --------------------------------------------------------------------------------------- spectral_processor (next row)
+
+REF_SPECTRAL_PATH = os.path.join(_HERE, "_ref", "libhisstools_ref_spectral.so")
+_spectral = {}
+
+
+def have_ref_spectral() -> bool:
+    return os.path.exists(REF_SPECTRAL_PATH)
+
+
+def _spectral_lib(backend):
+    if backend in _spectral:
+        return _spectral[backend]
+    if backend == "port":
+        L = lib("port").cdll
+        size = _decl(L, "hcvo_spectral_size", _sz, _sz, _sz, C.c_int, _sz)
+        conv = _decl(L, "hcvo_spectral_convolve_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p, _sz)
+        corr = _decl(L, "hcvo_spectral_correlate_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p, _sz)
+        cap = 1 << 24
+        fns = (lambda a, b, m: size(a, b, m, cap), lambda *x: conv(*x, cap), lambda *x: corr(*x, cap))
+    else:
+        if not have_ref_spectral():
+            raise FileNotFoundError(REF_SPECTRAL_PATH)
+        L = C.CDLL(REF_SPECTRAL_PATH)
+        fns = (_decl(L, "ref_spectral_size", _sz, _sz, _sz, C.c_int),
+               _decl(L, "ref_spectral_convolve_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p),
+               _decl(L, "ref_spectral_correlate_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p))
+    _spectral[backend] = fns
+    return fns
+
+
+def spectral_size(n1, n2, mode, backend="port"):
+    return _spectral_lib(backend)[0](n1, n2, int(mode))
+
+
+def spectral_convolve(in1, in2, mode, backend="port", correlate=False):
+    """spectral_processor<float>::convolve / correlate (real overloads)."""
+    size, conv, corr = _spectral_lib(backend)
+    a, b = _f32(in1), _f32(in2)
+    n = size(a.size, b.size, int(mode))
+    out = np.zeros(n, np.float32)
+    if n:
+        (corr if correlate else conv)(_fp(a), a.size, _fp(b), b.size, int(mode), _fp(out))
+    return out
+
+
+def spectral_correlate(in1, in2, mode, backend="port"):
+    return spectral_convolve(in1, in2, mode, backend, correlate=True)

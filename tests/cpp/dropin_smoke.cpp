@@ -5,6 +5,7 @@
 #include "hisstools_amd/PartitionedConvolve.h"
 #include "hisstools_amd/TimeDomainConvolve.h"
 #include "hisstools_amd/HISSTools_FFT.h"
+#include "hisstools_amd/SpectralProcessor.h"
 
 #include <cmath>
 #include <cstdio>
@@ -53,5 +54,17 @@ int main()
             worst = std::fmax(worst, std::fabs(t - y[o][n]));
         }
     std::printf("drop-in Convolver 2x2: max abs error %.3e\n", worst);
-    return worst < 5e-6 ? 0 : 1;
+    if (!(worst < 5e-6)) return 1;
+
+    // spectral_processor<float>::convolve (SpectralProcessor.hpp:178-181) through the drop-in header
+    spectral_processor<float> sp;
+    const float a[5] = { 1.f, 2.f, 3.f, 4.f, 5.f }, b[3] = { 1.f, -1.f, 0.5f };
+    float lin[7] = { 0 };
+    if (sp.convolved_size(5, 3, spectral_processor<float>::EdgeMode::Linear) != 7) return 1;
+    sp.convolve(lin, { a, 5 }, { b, 3 }, spectral_processor<float>::EdgeMode::Linear);
+    const float expect[7] = { 1.f, 1.f, 1.5f, 2.f, 2.5f, -3.f, 2.5f };
+    for (int i = 0; i < 7; i++)
+        if (std::fabs(lin[i] - expect[i]) > 1e-5f) return 1;
+    std::printf("drop-in spectral_processor::convolve ok\n");
+    return 0;
 }

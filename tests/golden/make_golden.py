@@ -99,6 +99,20 @@ for o in range(3):
     assert c.set(o, o, irs[o], True) == 0
 G["par_irs"], G["par_x"], G["par_y"] = irs, xs, c.run(xs, 3, 256)
 
+# ---- spectral_processor<float>::convolve / correlate, real overloads (first "next" row); separate fixture file
+S = {}
+if O.have_ref_spectral():
+    cases = [(10, 4), (4, 10), (7, 7), (1, 1), (1, 9), (100, 33), (33, 100), (512, 512), (1000, 129), (2, 3), (3000, 2047)]
+    for ci, (n1, n2) in enumerate(cases):
+        a, b = audio(200 + ci, n1), audio(300 + ci, n2)
+        S[f"sp{ci}_a"], S[f"sp{ci}_b"] = a, b
+        for mode in range(5):
+            S[f"sp{ci}_conv{mode}"] = O.spectral_convolve(a, b, mode, BE)
+            S[f"sp{ci}_corr{mode}"] = O.spectral_correlate(a, b, mode, BE)
+    sout = os.path.join(ROOT, "tests", "golden", "golden_spectral_v1.npz")
+    np.savez_compressed(sout, **{k: np.asarray(v, np.float32) for k, v in S.items()})
+    print("wrote", sout, os.path.getsize(sout), "bytes,", sum(v.size for v in S.values()), "floats")
+
 out = os.path.join(ROOT, "tests", "golden", "golden_v1.npz")
 np.savez_compressed(out, **{k: np.asarray(v, np.float32) for k, v in G.items()})
 print("wrote", out, os.path.getsize(out), "bytes,", sum(v.size for v in G.values()), "floats")

@@ -715,14 +715,17 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const int T = (int) ((n0 + B) / st.M - h_first);
         if (T <= 0) continue;
 
-        // Optional (HCV_SPLIT=1): split a large stage over three streams — forward FFTs | spectral_mac | reduce + inverse
-        // FFT — so that its MACs run back to back.  Measured slower than one stream per stage on this stack (c5 2.09 vs
-        // 1.98 ms/step, ns64 2.95 vs 2.55): every additional active stream competes for hardware queues.
-        static const bool allow_split = std::getenv("HCV_SPLIT") && std::atoi(std::getenv("HCV_SPLIT")) == 1;
+        // A large stage's forward FFTs and inverse side can run off its MAC stream so that its MACs go back to back:
+        //   HCV_SPLIT=2  forward FFT on the (otherwise idle) input stream right behind the scatter, reduce + inverse FFT on
+        //                the main stream in front of emit — no additional streams
+        //   HCV_SPLIT=1  two dedicated side streams (measured slower: every extra active stream competes for hardware queues)
+        static const int split_mode = std::getenv("HCV_SPLIT") ? std::atoi(std::getenv("HCV_SPLIT")) : 0;
         size_t live = 0;
         for (uint32_t p : st.pact) live += p;
-        const bool split = allow_split && live * st.M * sizeof(float2) >= (size_t(128) << 20);
-        hipStream_t sF = split ? st.streamF : st.stream, sM = st.stream, sI = split ? st.streamI : st.stream;
+        const bool split = split_mode > 0 && si + 1 == mStages.size() && live * st.M * sizeof(float2) >= (size_t(128) << 20);
+        hipStream_t sM = st.stream;
+        hipStream_t sF = !split ? st.stream : (split_mode == 2 ? mInStream : st.streamF);
+        hipStream_t sI = !split ? st.stream : (split_mode == 2 ? mStream : st.streamI);
         st.Y = st.Yq[q];
 
         HCV_TRY(hipStreamWaitEvent(sF, mEvInput[q], 0));

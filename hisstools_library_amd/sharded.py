@@ -107,6 +107,22 @@ class ShardedConvolver:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.row_group)
         return outs
 
+    def process_dev(self, ins, outs=None):
+        """HBM-resident variant: `ins` is a float32 CUDA tensor [numIns][n] on this rank's GPU (same on every rank);
+        returns this rank's rows as a CUDA tensor [nout_local][n].  In the grid layout the partial blocks are summed
+        with ONE RCCL all-reduce on the device buffer — the only collective on the data path."""
+        import torch
+        n = ins.shape[1]
+        if outs is None:
+            outs = torch.zeros((self.nout_local, n), dtype=torch.float32, device=ins.device)
+        if self.engine is not None and self.nin_local > 0:
+            local_in = ins[self.in_lo:self.in_hi].contiguous()
+            torch.cuda.current_stream(ins.device).synchronize()          # the engine runs on its own streams
+            self.engine.process_dev(local_in.data_ptr(), n, outs.data_ptr(), n, self.nin_local, self.nout_local, n, sync=True)
+        if self.row_group is not None:
+            self.dist.all_reduce(outs, op=self.dist.ReduceOp.SUM, group=self.row_group)
+        return outs
+
     def gather(self, local_outs: np.ndarray) -> np.ndarray:
         """Assemble [numOuts][n] on every rank (optional; not part of the data path in the rows layout)."""
         import torch

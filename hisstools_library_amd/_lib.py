@@ -27,6 +27,12 @@ class StageStats(C.Structure):
                 ("ksplit", u32), ("out_tile", u32)]
 
 
+class FFTCall(C.Structure):          # hcv_fft_call
+    _fields_ = [("op", C.c_int), ("precision", C.c_int), ("log2n", C.c_uint), ("batch", usz),
+                ("src_a", vp), ("src_b", vp), ("dst_a", vp), ("dst_b", vp),
+                ("src_stride", usz), ("dst_stride", usz), ("in_length", usz)]
+
+
 # name -> (restype, argtypes); must list every symbol include/hisstools_amd.h declares
 SIGNATURES = {
     "hcv_version": (C.c_char_p, []),
@@ -92,6 +98,8 @@ SIGNATURES = {
     "hcv_spectral_size": (usz, [usz, usz, C.c_int]),
     "hcv_spectral_convolve_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
     "hcv_spectral_correlate_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
+    "hcv_fft_exec": (C.c_int, [C.POINTER(FFTCall)]),
+    "hcv_fft_exec_dev": (C.c_int, [C.POINTER(FFTCall), vp, C.c_int]),
 }
 
 _lib = None

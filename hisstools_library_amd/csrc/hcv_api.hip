@@ -6,6 +6,7 @@
 
 #include "../../include/hisstools_amd.h"
 #include "hcv_engine.h"
+#include "hcv_fftx.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1103,4 +1104,171 @@ extern "C" int hcv_spectral_convolve_f32(const float *in1, size_t size1, const f
 extern "C" int hcv_spectral_correlate_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out)
 {
     return spectral_binary(in1, size1, in2, size2, mode, true, out);
+}
+
+// ------------------------------------------------------------------------------------------------ the full FFT surface (next row 2)
+//
+// HISSTools_FFT.h:87-369 as one batched entry point; the kernels are in hcv_fftx.hip.  The host variant only moves
+// bytes: upload the source extent, run, download the destination extent.
+
+namespace
+{
+    struct FftOperand
+    {
+        size_t len = 0, elem = 0;       // elements per transform, bytes per element
+        bool two = false;               // split (a and b) or samples (a only)
+    };
+
+    bool use_default_device(int &dev)
+    {
+        if (hcv_device_count() <= 0)
+        {
+            set_error("no HIP device available");
+            return false;
+        }
+        if (gDefaultDevice >= 0) (void) hipSetDevice(gDefaultDevice);
+        return hipGetDevice(&dev) == hipSuccess;
+    }
+
+    hcv::FxCall to_fx(const hcv_fft_call &c)
+    {
+        hcv::FxCall f;
+        f.op = c.op; f.precision = c.precision; f.log2n = c.log2n; f.batch = c.batch;
+        f.src_a = c.src_a; f.src_b = c.src_b; f.dst_a = c.dst_a; f.dst_b = c.dst_b;
+        f.src_stride = c.src_stride; f.dst_stride = c.dst_stride; f.in_length = c.in_length;
+        return f;
+    }
+
+    // shapes of the two operands, and default (dense) strides
+    void fft_operands(hcv::FxCall &f, FftOperand &src, FftOperand &dst)
+    {
+        const size_t n = size_t(1) << f.log2n, half = n >> 1;
+        const size_t real_bytes = f.precision == hcv::FX_F32 ? 4 : 8;
+        const bool complex_op = f.op == hcv::FX_FFT || f.op == hcv::FX_IFFT;
+        const size_t split_len = complex_op ? n : half;
+        src.elem = dst.elem = real_bytes;
+        switch (f.op)
+        {
+            case hcv::FX_RFFT_ZIP:
+            case hcv::FX_UNZIP:
+                f.in_length = std::min(f.in_length, n);
+                src.len = f.in_length; src.two = false;
+                src.elem = f.precision == hcv::FX_F64 ? 8 : 4;
+                dst.len = half; dst.two = true;
+                break;
+            case hcv::FX_RIFFT_ZIP:
+            case hcv::FX_ZIP:
+                src.len = half; src.two = true;
+                dst.len = half ? n : 0; dst.two = false;
+                break;
+            default:
+                src.len = dst.len = split_len;
+                src.two = dst.two = true;
+        }
+        if (!f.src_stride) f.src_stride = src.len;
+        if (!f.dst_stride) f.dst_stride = dst.len;
+    }
+}
+
+extern "C" int hcv_fft_exec_dev(const hcv_fft_call *call, void *stream, int sync)
+{
+    if (!call)
+    {
+        set_error("hcv_fft_exec_dev: null descriptor");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    hcv::FxCall f = to_fx(*call);
+    std::string err;
+    if (!hcv::fftx_valid(f, &err))
+    {
+        set_error(err);
+        return -1;
+    }
+    FftOperand src, dst;
+    fft_operands(f, src, dst);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hcv::fftx_exec(dev, f, st, &err);
+    if (e == hipSuccess && sync) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+    {
+        set_error(err.empty() ? std::string("hcv_fft_exec_dev: ") + hipGetErrorString(e) : err);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int hcv_fft_exec(const hcv_fft_call *call)
+{
+    if (!call)
+    {
+        set_error("hcv_fft_exec: null descriptor");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    hcv::FxCall f = to_fx(*call);
+    std::string err;
+    if (!hcv::fftx_valid(f, &err))
+    {
+        set_error(err);
+        return -1;
+    }
+    if (!f.batch) return 0;
+    FftOperand src, dst;
+    fft_operands(f, src, dst);
+    const bool in_place = call->src_a == call->dst_a;
+    if (in_place && (src.two != dst.two || src.elem != dst.elem || (src.two && call->src_b != call->dst_b) || f.src_stride != f.dst_stride))
+    {
+        set_error("hcv_fft_exec: operands may alias only exactly (same layout, both arrays)");
+        return -1;
+    }
+    const size_t src_extent = src.len ? (f.batch - 1) * f.src_stride + src.len : 0;
+    const size_t dst_extent = dst.len ? (f.batch - 1) * f.dst_stride + dst.len : 0;
+    if (!dst_extent) return 0;
+
+    bool ok = true;
+    void *d[4] = { nullptr, nullptr, nullptr, nullptr };            // src a, src b, dst a, dst b
+    auto up = [&](void *&p, const void *host, size_t elems, size_t elem_bytes, bool copy)
+    {
+        if (!ok) return;
+        HCV_API_TRY(hipMalloc(&p, std::max<size_t>(16, elems * elem_bytes)));
+        if (ok && copy && elems) HCV_API_TRY(hipMemcpy(p, host, elems * elem_bytes, hipMemcpyHostToDevice));
+    };
+    up(d[0], call->src_a, src_extent, src.elem, true);
+    if (src.two) up(d[1], call->src_b, src_extent, src.elem, true);
+    if (in_place)
+    {
+        d[2] = d[0];
+        d[3] = d[1];
+    }
+    else
+    {
+        // gaps between strided destination rows keep the caller's bytes
+        const bool gaps = f.dst_stride != dst.len && f.batch > 1;
+        up(d[2], call->dst_a, dst_extent, dst.elem, gaps);
+        if (dst.two) up(d[3], call->dst_b, dst_extent, dst.elem, gaps);
+    }
+    if (ok)
+    {
+        f.src_a = d[0]; f.src_b = d[1]; f.dst_a = d[2]; f.dst_b = d[3];
+        hipError_t e = hcv::fftx_exec(dev, f, nullptr, &err);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess)
+        {
+            set_error(err.empty() ? std::string("hcv_fft_exec: ") + hipGetErrorString(e) : err);
+            ok = false;
+        }
+    }
+    if (ok) HCV_API_TRY(hipMemcpy(call->dst_a, d[2], dst_extent * dst.elem, hipMemcpyDeviceToHost));
+    if (ok && dst.two) HCV_API_TRY(hipMemcpy(call->dst_b, d[3], dst_extent * dst.elem, hipMemcpyDeviceToHost));
+    if (!in_place)
+    {
+        if (d[2]) (void) hipFree(d[2]);
+        if (d[3]) (void) hipFree(d[3]);
+    }
+    if (d[0]) (void) hipFree(d[0]);
+    if (d[1]) (void) hipFree(d[1]);
+    return ok ? 0 : -1;
 }

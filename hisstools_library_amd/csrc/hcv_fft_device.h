@@ -24,24 +24,29 @@ __device__ __forceinline__ float4 load_nt(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
 // tw holds the N-th roots of unity exp(-2*pi*i*m/N) for m in [0, N/2); the second half of the circle
-// is the negated first half.
-template <int LOG2M>
-__device__ __forceinline__ float2 root(const float2 *__restrict__ tw, int m)
+// is the negated first half.  C = float2 (the convolution path) or double2 (the double FFT surface).
+template <int LOG2M, class C>
+__device__ __forceinline__ C root(const C *__restrict__ tw, int m)
 {
     constexpr int M = 1 << LOG2M;                    // N/2 table entries
-    float2 w = tw[m & (M - 1)];
-    return (m & M) ? make_float2(-w.x, -w.y) : w;
+    C w = tw[m & (M - 1)];
+    return (m & M) ? C(-w.x, -w.y) : w;
 }
 
 // ------------------------------------------------------------------------------------------------
 // In-LDS complex FFT of M = 2^LOG2M points, forward sign, unnormalised, natural order in and out.
 // Stockham autosort, radix-4 passes plus one radix-2 pass when LOG2M is odd.  TG threads cooperate on one
 // transform; every pass is "read my butterflies into registers / barrier / write results / barrier", so a
-// single M-point LDS buffer suffices (64 KiB at N = 16384).
+// single M-point LDS buffer suffices (64 KiB at N = 16384 in float).
 // ------------------------------------------------------------------------------------------------
 
-template <int LOG2M, int TG>
+template <int LOG2M, int TG, class C = float2>
 struct LdsFFT
 {
     static constexpr int M = 1 << LOG2M;
@@ -50,13 +55,13 @@ struct LdsFFT
     static constexpr int NB2 = M / 2;
     static constexpr int BPT2 = (NB2 + TG - 1) / TG;
 
-    __device__ static __forceinline__ void run(float2 *s, int tid, const float2 *__restrict__ tw)
+    __device__ static __forceinline__ void run(C *s, int tid, const C *__restrict__ tw)
     {
         int p = 1;
 #pragma unroll 1
         for (int pass = 0; pass < LOG2M / 2; pass++, p <<= 2)
         {
-            float2 u[BPT4][4];
+            C u[BPT4][4];
 #pragma unroll
             for (int b = 0; b < BPT4; b++)
             {
@@ -78,25 +83,25 @@ struct LdsFFT
                     int j = ((i - k) << 2) + k;
                     // twiddle exp(-2 pi i k r / (4p)) = root(k * r * (2M / 4p))
                     int step = k * ((2 * M) / (4 * p));
-                    float2 u0 = u[b][0];
-                    float2 u1 = cmul(u[b][1], root<LOG2M>(tw, step));
-                    float2 u2 = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
-                    float2 u3 = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
-                    float2 a = make_float2(u0.x + u2.x, u0.y + u2.y);
-                    float2 c = make_float2(u0.x - u2.x, u0.y - u2.y);
-                    float2 e = make_float2(u1.x + u3.x, u1.y + u3.y);
-                    float2 d = make_float2(u1.y - u3.y, u3.x - u1.x);     // -i * (u1 - u3)
-                    s[j] = make_float2(a.x + e.x, a.y + e.y);
-                    s[j + p] = make_float2(c.x + d.x, c.y + d.y);
-                    s[j + 2 * p] = make_float2(a.x - e.x, a.y - e.y);
-                    s[j + 3 * p] = make_float2(c.x - d.x, c.y - d.y);
+                    C u0 = u[b][0];
+                    C u1 = cmul(u[b][1], root<LOG2M>(tw, step));
+                    C u2 = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
+                    C u3 = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
+                    C a = C(u0.x + u2.x, u0.y + u2.y);
+                    C c = C(u0.x - u2.x, u0.y - u2.y);
+                    C e = C(u1.x + u3.x, u1.y + u3.y);
+                    C d = C(u1.y - u3.y, u3.x - u1.x);     // -i * (u1 - u3)
+                    s[j] = C(a.x + e.x, a.y + e.y);
+                    s[j + p] = C(c.x + d.x, c.y + d.y);
+                    s[j + 2 * p] = C(a.x - e.x, a.y - e.y);
+                    s[j + 3 * p] = C(c.x - d.x, c.y - d.y);
                 }
             }
             __syncthreads();
         }
         if (LOG2M & 1)
         {
-            float2 u[BPT2][2];
+            C u[BPT2][2];
 #pragma unroll
             for (int b = 0; b < BPT2; b++)
             {
@@ -116,10 +121,10 @@ struct LdsFFT
                 {
                     int k = i & (p - 1);
                     int j = ((i - k) << 1) + k;
-                    float2 u0 = u[b][0];
-                    float2 u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
-                    s[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-                    s[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+                    C u0 = u[b][0];
+                    C u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
+                    s[j] = C(u0.x + u1.x, u0.y + u1.y);
+                    s[j + p] = C(u0.x - u1.x, u0.y - u1.y);
                 }
             }
             __syncthreads();

@@ -1,0 +1,617 @@
+// The general hisstools_* FFT surface on gfx950 (see hcv_fftx.h).  Reference behaviour restated:
+//   hisstools_fft / ifft      HISSTools_FFT_Core.h:1325-1346   in-place complex transform of split data; the inverse is the
+//                                                              forward transform with the real/imaginary pointers exchanged
+//   hisstools_rfft / rifft    HISSTools_FFT_Core.h:1350-1374   complex transform of N/2 points + the real pass (:934-988):
+//                                                              forward spectrum doubled, DC/Nyquist packed in bin 0
+//   small cases               HISSTools_FFT_Core.h:994-1150    complex 2 points and real 2 / 4 points
+//   unzip / unzip_zero / zip  HISSTools_FFT_Core.h:1199-1287   even/odd de/interleave, zero padding, odd trailing sample
+//
+// Device plan per transform of M complex points (M = N/2 for the real transforms):
+//   M <= 2                    one thread per transform                                           (fx_tiny_kernel)
+//   M <= 16384 (f32) / 8192 (f64)   one LDS-resident Stockham transform per thread group: HBM is read once and
+//                             written once, the real pre/post pass and the zip/unzip are fused into the load/store
+//   larger, up to 2^22        four-step through HBM: column transforms (+ twiddle) into scratch, row transforms out; the
+//                             loads are fused into the column pass and the stores into the row pass (the forward real
+//                             post pass needs bins k and M-k together, so it runs as a third pass)
+
+#include "hcv_fftx.h"
+#include "hcv_engine.h"
+#include "hcv_fft_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace hcv
+{
+
+namespace
+{
+    template <class T> struct Cx;
+    template <> struct Cx<float> { typedef float2 type; };
+    template <> struct Cx<double> { typedef double2 type; };
+
+    enum { L_SPLIT = 0, L_ZIP = 1, L_PRE = 2 };
+    enum { S_SPLIT = 0, S_ZIP = 1, S_POST = 2 };
+
+    template <class T> struct FxK
+    {
+        const void *sa;                 // split real part, or the interleaved samples (float when src_f32)
+        const T *sb;                    // split imaginary part
+        T *da, *db;                     // split destination, or da = interleaved samples
+        long long sstride, dstride, in_len;
+        int load, store, swap_out, src_f32;
+        long long batch;
+    };
+
+    // -------------------------------------------------------------------------------------------- element access
+
+    // element n of the M-point complex input of transform q
+    template <class T, class C>
+    __device__ __forceinline__ C fx_load(const FxK<T> &a, long long q, int n, int M, const C *__restrict__ twN)
+    {
+        if (a.load == L_SPLIT)
+        {
+            const T *re = static_cast<const T *>(a.sa) + q * a.sstride;
+            const T *im = a.sb + q * a.sstride;
+            return C(re[n], im[n]);
+        }
+        if (a.load == L_ZIP)
+        {
+            const long long i0 = 2LL * n;
+            if (a.src_f32)
+            {
+                const float *x = static_cast<const float *>(a.sa) + q * a.sstride;
+                return C(i0 < a.in_len ? (T) x[i0] : (T) 0, i0 + 1 < a.in_len ? (T) x[i0 + 1] : (T) 0);
+            }
+            const T *x = static_cast<const T *>(a.sa) + q * a.sstride;
+            return C(i0 < a.in_len ? x[i0] : (T) 0, i0 + 1 < a.in_len ? x[i0 + 1] : (T) 0);
+        }
+        // L_PRE: pass_real_trig_table<true> (Core.h:934-988), delivered with re/im exchanged so that the forward
+        // transform that follows acts as the inverse (Core.h:1341-1346)
+        const T *re = static_cast<const T *>(a.sa) + q * a.sstride;
+        const T *im = a.sb + q * a.sstride;
+        if (n == 0)
+        {
+            const T r = re[0], i = im[0];
+            return C(r - i, r + i);
+        }
+        const bool lo = n <= M / 2;
+        const int k = lo ? n : M - n, m = M - k;
+        const C w = twN[k];
+        const T c = -w.x, sn = w.y;
+        const T r1 = re[k], i1 = im[k], r2 = re[m], i2 = im[m];
+        const T r3 = r1 + r2, i3 = i1 + i2, r4 = r1 - r2, i4 = i1 - i2;
+        const T u1 = (c * i3) + (sn * r4);
+        const T u2 = (sn * i3) - (c * r4);
+        return lo ? C(u2 + i4, r3 + u1) : C(u2 - i4, r3 - u1);
+    }
+
+    template <class T, class C>
+    __device__ __forceinline__ void fx_store(const FxK<T> &a, long long q, int k, C v)
+    {
+        if (a.swap_out) v = C(v.y, v.x);
+        if (a.store == S_SPLIT)
+        {
+            a.da[q * a.dstride + k] = v.x;
+            a.db[q * a.dstride + k] = v.y;
+        }
+        else
+        {
+            T *o = a.da + q * a.dstride + 2LL * k;
+            o[0] = v.x;
+            o[1] = v.y;
+        }
+    }
+
+    // pass_real_trig_table<false> for the bin pair (k, M-k), k in [0, M/2]
+    template <class T, class C>
+    __device__ __forceinline__ void fx_post(const FxK<T> &a, long long q, int k, int M, C z1, C z2, const C *__restrict__ twN)
+    {
+        T *re = a.da + q * a.dstride, *im = a.db + q * a.dstride;
+        if (k == 0)
+        {
+            const T t1 = z1.x + z1.y, t2 = z1.x - z1.y;
+            re[0] = t1 + t1;
+            im[0] = t2 + t2;
+            return;
+        }
+        const int m = M - k;
+        const C w = twN[k];
+        const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+        const T u1 = (w.x * i3) + (w.y * r4);
+        const T u2 = (w.y * i3) - (w.x * r4);
+        re[k] = r3 + u1;
+        im[k] = u2 + i4;
+        re[m] = r3 - u1;
+        im[m] = u2 - i4;
+    }
+
+    // -------------------------------------------------------------------------------------------- LDS-resident transforms
+
+    template <class T, int LOG2M>
+    __global__ __launch_bounds__(256) void fx_lds_kernel(FxK<T> a, const typename Cx<T>::type *__restrict__ tw)
+    {
+        typedef typename Cx<T>::type C;
+        typedef FFTGeom<LOG2M> Gm;
+        constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
+        C *lds = reinterpret_cast<C *>(fx_raw);
+
+        const int g = threadIdx.x / TG, t = threadIdx.x % TG;
+        const long long q = (long long) blockIdx.x * G + g;
+        const bool live = q < a.batch;
+        C *s = lds + g * M;
+        if (live)
+            for (int n = t; n < M; n += TG) s[n] = fx_load<T, C>(a, q, n, M, tw);
+        __syncthreads();
+        LdsFFT<LOG2M, TG, C>::run(s, t, tw);
+        if (!live) return;
+        if (a.store == S_POST)
+        {
+            for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, q, k, M, s[k], s[(M - k) & (M - 1)], tw);
+        }
+        else
+        {
+            for (int k = t; k < M; k += TG) fx_store<T, C>(a, q, k, s[k]);
+        }
+    }
+
+    // -------------------------------------------------------------------------------------------- tiny transforms (M <= 2)
+
+    // kind: 0 complex, 1 real forward, 2 real inverse; one thread per transform
+    template <class T>
+    __global__ void fx_tiny_kernel(FxK<T> a, int kind, int log2n)
+    {
+        typedef typename Cx<T>::type C;
+        const long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (q >= a.batch) return;
+        const int M = kind == 0 ? (1 << log2n) : ((1 << log2n) >> 1);
+        if (M == 0) return;
+        // the pre pass does not apply at these sizes: read the packed spectrum as plain split data
+        FxK<T> ld = a;
+        if (ld.load == L_PRE) ld.load = L_SPLIT;
+        T re[2], im[2];
+        for (int n = 0; n < M; n++)
+        {
+            const C v = fx_load<T, C>(ld, q, n, M, nullptr);
+            re[n] = v.x;
+            im[n] = v.y;
+        }
+        if (kind == 0)
+        {
+            if (M == 2)                                             // small_fft, Core.h:1000-1011
+            {
+                const T r1 = re[0], r2 = re[1], i1 = im[0], i2 = im[1];
+                re[0] = r1 + r2; re[1] = r1 - r2; im[0] = i1 + i2; im[1] = i1 - i2;
+            }
+        }
+        else if (kind == 1)
+        {
+            if (M == 1)                                             // small_real_fft<false>, Core.h:1101-1108
+            {
+                const T r1 = re[0] + re[0], r2 = im[0] + im[0];
+                re[0] = r1 + r2; im[0] = r1 - r2;
+            }
+            else                                                    // Core.h:1110-1128
+            {
+                const T r1 = re[0] + re[1], r2 = re[0] - re[1], i1 = im[0] + im[1], i2 = im[1] - im[0];
+                const T r3 = r1 + i1, i3 = r1 - i1;
+                re[0] = r3 + r3; re[1] = r2 + r2; im[0] = i3 + i3; im[1] = i2 + i2;
+            }
+        }
+        else
+        {
+            if (M == 1)                                             // small_real_fft<true>
+            {
+                const T r1 = re[0], r2 = im[0];
+                re[0] = r1 + r2; im[0] = r1 - r2;
+            }
+            else                                                    // Core.h:1130-1148
+            {
+                const T i1 = re[0], r2 = re[1] + re[1], i2 = im[0], r4 = im[1] + im[1];
+                const T r1 = i1 + i2, r3 = i1 - i2;
+                re[0] = r1 + r2; re[1] = r1 - r2; im[0] = r3 - r4; im[1] = r3 + r4;
+            }
+        }
+        FxK<T> sv = a;
+        sv.swap_out = 0;                                            // the explicit formulas above already give (re, im)
+        if (sv.store == S_POST) sv.store = S_SPLIT;
+        for (int k = 0; k < M; k++) fx_store<T, C>(sv, q, k, C(re[k], im[k]));
+    }
+
+    // -------------------------------------------------------------------------------------------- four-step passes
+
+    __host__ __device__ constexpr int fx_tile(int points, int elem_bytes, int want)
+    {
+        return (128 * 1024 / (points * elem_bytes)) < want ? (128 * 1024 / (points * elem_bytes)) : want;
+    }
+
+    template <class C>
+    __device__ __forceinline__ C fx_root_rt(const C *__restrict__ tw, int idx, int M)
+    {
+        const C w = tw[idx & (M - 1)];
+        return (idx & M) ? C(-w.x, -w.y) : w;
+    }
+
+    // M = M1 * M2, n = M2*n1 + n2, k = k1 + M1*k2.   cols: for every n2 an M1-point transform over n1, times W_M^(n2 k1)
+    template <class T, int L1>
+    __global__ __launch_bounds__(256) void fx_cols_kernel(FxK<T> a, typename Cx<T>::type *__restrict__ work, int M2, int M, long long q0,
+                                                          const typename Cx<T>::type *__restrict__ tw1, const typename Cx<T>::type *__restrict__ twN)
+    {
+        typedef typename Cx<T>::type C;
+        constexpr int M1 = 1 << L1;
+        constexpr int TG = (M1 / 4) < 256 ? (M1 / 4) : 256;
+        constexpr int G = 256 / TG;
+        constexpr int COLS = fx_tile(M1, (int) sizeof(C), 128 / (int) sizeof(C));
+        static_assert(G <= COLS, "one thread group per column");
+        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
+        C *lds = reinterpret_cast<C *>(fx_raw);                                // [COLS][M1]
+
+        const int col0 = blockIdx.x * COLS;
+        const long long q = q0 + blockIdx.y;
+        for (int e = threadIdx.x; e < COLS * M1; e += 256)
+        {
+            const int c = e % COLS, n1 = e / COLS;
+            lds[c * M1 + n1] = fx_load<T, C>(a, q, n1 * M2 + col0 + c, M, twN);
+        }
+        __syncthreads();
+        const int g = threadIdx.x / TG, t = threadIdx.x % TG;
+        for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(lds + (c0 + g) * M1, t, tw1);
+        C *out = work + (long long) blockIdx.y * M;
+        for (int e = threadIdx.x; e < COLS * M1; e += 256)
+        {
+            const int c = e % COLS, k1 = e / COLS;
+            const int n2 = col0 + c;
+            out[(long long) k1 * M2 + n2] = cmul(lds[c * M1 + k1], fx_root_rt(twN, 2 * n2 * k1, M));
+        }
+    }
+
+    // rows: for every k1 an M2-point transform over n2; element k2 of row k1 is bin k1 + M1*k2
+    template <class T, int L2>
+    __global__ __launch_bounds__(256) void fx_rows_kernel(const typename Cx<T>::type *__restrict__ work, FxK<T> a, typename Cx<T>::type *__restrict__ post,
+                                                          int M1, int M, long long q0, const typename Cx<T>::type *__restrict__ tw2)
+    {
+        typedef typename Cx<T>::type C;
+        constexpr int M2 = 1 << L2;
+        constexpr int TG = (M2 / 4) < 256 ? (M2 / 4) : 256;
+        constexpr int G = 256 / TG;
+        constexpr int ROWS = fx_tile(M2, (int) sizeof(C), 8);
+        static_assert(G <= ROWS, "one thread group per row");
+        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
+        C *lds = reinterpret_cast<C *>(fx_raw);                                // [ROWS][M2]
+
+        const int row0 = blockIdx.x * ROWS;
+        const C *in = work + (long long) blockIdx.y * M + (long long) row0 * M2;
+        for (int e = threadIdx.x; e < ROWS * M2; e += 256) lds[e] = in[e];
+        __syncthreads();
+        const int g = threadIdx.x / TG, t = threadIdx.x % TG;
+        for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(lds + (r0 + g) * M2, t, tw2);
+        const long long q = q0 + blockIdx.y;
+        for (int e = threadIdx.x; e < ROWS * M2; e += 256)
+        {
+            const int r = e % ROWS, k2 = e / ROWS;
+            const int k = row0 + r + M1 * k2;
+            const C v = lds[r * M2 + k2];
+            if (a.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
+            else fx_store<T, C>(a, q, k, v);
+        }
+    }
+
+    template <class T>
+    __global__ void fx_post_kernel(const typename Cx<T>::type *__restrict__ Z, FxK<T> a, int M, long long q0, const typename Cx<T>::type *__restrict__ twN)
+    {
+        typedef typename Cx<T>::type C;
+        const int k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k > M / 2) return;
+        const C *z = Z + (long long) blockIdx.y * M;
+        fx_post<T, C>(a, q0 + blockIdx.y, k, M, z[k], z[(M - k) & (M - 1)], twN);
+    }
+
+    // -------------------------------------------------------------------------------------------- zip / unzip
+
+    template <class T, class U>
+    __global__ void fx_unzip_kernel(const U *__restrict__ in, T *__restrict__ re, T *__restrict__ im, long long half, long long in_len,
+                                    long long sstride, long long dstride, long long batch)
+    {
+        const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (k >= half) return;
+        for (long long q = blockIdx.y; q < batch; q += gridDim.y)
+        {
+            const U *x = in + q * sstride;
+            re[q * dstride + k] = (2 * k < in_len) ? (T) x[2 * k] : (T) 0;
+            im[q * dstride + k] = (2 * k + 1 < in_len) ? (T) x[2 * k + 1] : (T) 0;
+        }
+    }
+
+    template <class T>
+    __global__ void fx_zip_kernel(const T *__restrict__ re, const T *__restrict__ im, T *__restrict__ out, long long half, long long sstride,
+                                  long long dstride, long long batch)
+    {
+        const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+        if (k >= half) return;
+        for (long long q = blockIdx.y; q < batch; q += gridDim.y)
+        {
+            T *o = out + q * dstride + 2 * k;
+            o[0] = re[q * sstride + k];
+            o[1] = im[q * sstride + k];
+        }
+    }
+
+    // -------------------------------------------------------------------------------------------- host: tables and scratch
+
+    std::mutex gFxMutex;
+    std::map<std::pair<int, int>, double2 *> gTwF64;
+
+    struct Scratch
+    {
+        void *a = nullptr, *b = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<int, Scratch> gScratch;
+
+    const double2 *twiddles_f64(int device, int log2n, std::string *err)
+    {
+        std::lock_guard<std::mutex> g(gFxMutex);
+        auto key = std::make_pair(device, log2n);
+        auto it = gTwF64.find(key);
+        if (it != gTwF64.end()) return it->second;
+        const size_t half = size_t(1) << (log2n - 1);
+        std::vector<double2> host(half);
+        const double pi = 3.14159265358979323846264338327950288;
+        for (size_t m = 0; m < half; m++)
+        {
+            const double angle = -(double) m * pi / (double) half;
+            host[m] = make_double2(std::cos(angle), std::sin(angle));
+        }
+        double2 *dev = nullptr;
+        hipError_t e = hipMalloc(&dev, half * sizeof(double2));
+        if (e == hipSuccess) e = hipMemcpy(dev, host.data(), half * sizeof(double2), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+        {
+            if (err) *err = std::string("twiddle table upload failed: ") + hipGetErrorString(e);
+            if (dev) (void) hipFree(dev);
+            return nullptr;
+        }
+        gTwF64[key] = dev;
+        return dev;
+    }
+
+    template <class T> const typename Cx<T>::type *fx_twiddles(int device, int log2n, std::string *err);
+    template <> const float2 *fx_twiddles<float>(int device, int log2n, std::string *err) { return twiddles(device, log2n, err); }
+    template <> const double2 *fx_twiddles<double>(int device, int log2n, std::string *err) { return twiddles_f64(device, log2n, err); }
+
+    // grow-only per-device scratch for the four-step path (two buffers of `bytes`)
+    hipError_t scratch(int device, size_t bytes, Scratch &out)
+    {
+        std::lock_guard<std::mutex> g(gFxMutex);
+        Scratch &s = gScratch[device];
+        if (s.bytes < bytes)
+        {
+            if (s.a) (void) hipFree(s.a);                           // hipFree waits for work that still uses the old buffers
+            if (s.b) (void) hipFree(s.b);
+            s = Scratch();
+            hipError_t e = hipMalloc(&s.a, bytes);
+            if (e == hipSuccess) e = hipMalloc(&s.b, bytes);
+            if (e != hipSuccess)
+            {
+                if (s.a) (void) hipFree(s.a);
+                s = Scratch();
+                return e;
+            }
+            s.bytes = bytes;
+        }
+        out = s;
+        return hipSuccess;
+    }
+
+    template <class K> hipError_t allow_big_lds(K kernel, size_t bytes)
+    {
+        if (bytes <= 64 * 1024) return hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+    }
+
+    template <class T> constexpr int max_lds_log2m() { return sizeof(T) == 4 ? 14 : 13; }
+
+    // -------------------------------------------------------------------------------------------- host: launches
+
+    template <class T, int L> hipError_t launch_lds(const FxK<T> &k, const typename Cx<T>::type *tw, hipStream_t st)
+    {
+        typedef typename Cx<T>::type C;
+        typedef FFTGeom<L> Gm;
+        const size_t lds = sizeof(C) * Gm::M * Gm::G;
+        hipError_t e = allow_big_lds(fx_lds_kernel<T, L>, lds);
+        if (e != hipSuccess) return e;
+        const long long grid = (k.batch + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL((fx_lds_kernel<T, L>), dim3((unsigned) grid), dim3(Gm::THREADS), lds, st, k, tw);
+        return hipGetLastError();
+    }
+
+    template <class T> hipError_t dispatch_lds(int lm, const FxK<T> &k, const typename Cx<T>::type *tw, hipStream_t st)
+    {
+        switch (lm)
+        {
+#define FX_CASE(L) case L: return launch_lds<T, L>(k, tw, st);
+            FX_CASE(2) FX_CASE(3) FX_CASE(4) FX_CASE(5) FX_CASE(6) FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11) FX_CASE(12) FX_CASE(13)
+#undef FX_CASE
+            case 14:
+                if constexpr (sizeof(T) == 4) return launch_lds<T, 14>(k, tw, st);
+                return hipErrorInvalidValue;
+            default: return hipErrorInvalidValue;
+        }
+    }
+
+    template <class T, int L1> hipError_t launch_cols(const FxK<T> &k, typename Cx<T>::type *work, int M2, int M, long long q0, int nb,
+                                                      const typename Cx<T>::type *tw1, const typename Cx<T>::type *twN, hipStream_t st)
+    {
+        typedef typename Cx<T>::type C;
+        constexpr int COLS = fx_tile(1 << L1, (int) sizeof(C), 128 / (int) sizeof(C));
+        const size_t lds = sizeof(C) * COLS * (size_t(1) << L1);
+        hipError_t e = allow_big_lds(fx_cols_kernel<T, L1>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / COLS, nb), dim3(256), lds, st, k, work, M2, M, q0, tw1, twN);
+        return hipGetLastError();
+    }
+
+    template <class T, int L2> hipError_t launch_rows(const typename Cx<T>::type *work, const FxK<T> &k, typename Cx<T>::type *post, int M1, int M,
+                                                      long long q0, int nb, const typename Cx<T>::type *tw2, hipStream_t st)
+    {
+        typedef typename Cx<T>::type C;
+        constexpr int ROWS = fx_tile(1 << L2, (int) sizeof(C), 8);
+        const size_t lds = sizeof(C) * ROWS * (size_t(1) << L2);
+        hipError_t e = allow_big_lds(fx_rows_kernel<T, L2>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((fx_rows_kernel<T, L2>), dim3(M1 / ROWS, nb), dim3(256), lds, st, work, k, post, M1, M, q0, tw2);
+        return hipGetLastError();
+    }
+
+    template <class T> hipError_t run_big(int device, int lm, const FxK<T> &k, hipStream_t st, std::string *err)
+    {
+        typedef typename Cx<T>::type C;
+        const int l2 = (lm + 1) / 2, l1 = lm - l2;
+        const int M = 1 << lm, M1 = 1 << l1, M2 = 1 << l2;
+        const C *twN = fx_twiddles<T>(device, lm + 1, err);
+        const C *tw1 = fx_twiddles<T>(device, l1 + 1, err);
+        const C *tw2 = fx_twiddles<T>(device, l2 + 1, err);
+        if (!twN || !tw1 || !tw2) return hipErrorOutOfMemory;
+        // scratch for up to 64 MiB of transforms per pass
+        const size_t per = sizeof(C) * (size_t) M;
+        const long long chunk = std::max<long long>(1, std::min<long long>(k.batch, (long long) ((size_t(64) << 20) / per)));
+        Scratch s;
+        hipError_t e = scratch(device, per * (size_t) chunk, s);
+        if (e != hipSuccess) return e;
+        C *work = static_cast<C *>(s.a), *post = static_cast<C *>(s.b);
+        for (long long q0 = 0; q0 < k.batch; q0 += chunk)
+        {
+            const int nb = (int) std::min<long long>(chunk, k.batch - q0);
+            switch (l1)
+            {
+#define FX_CASE(L) case L: e = launch_cols<T, L>(k, work, M2, M, q0, nb, tw1, twN, st); break;
+                FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)
+#undef FX_CASE
+                default: e = hipErrorInvalidValue;
+            }
+            if (e != hipSuccess) return e;
+            switch (l2)
+            {
+#define FX_CASE(L) case L: e = launch_rows<T, L>(work, k, post, M1, M, q0, nb, tw2, st); break;
+                FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)
+#undef FX_CASE
+                default: e = hipErrorInvalidValue;
+            }
+            if (e != hipSuccess) return e;
+            if (k.store == S_POST)
+                hipLaunchKernelGGL(fx_post_kernel<T>, dim3((M / 2 + 1 + 255) / 256, nb), dim3(256), 0, st, post, k, M, q0, twN);
+        }
+        return hipGetLastError();
+    }
+
+    template <class T> hipError_t run_typed(int device, const FxCall &c, bool src_f32, hipStream_t st, std::string *err)
+    {
+        typedef typename Cx<T>::type C;
+        const long long n = 1LL << c.log2n;
+        if (c.op == FX_UNZIP)
+        {
+            const long long half = n >> 1, in_len = std::min<long long>((long long) c.in_length, n);
+            if (!half) return hipSuccess;
+            dim3 grid((unsigned) ((half + 255) / 256), (unsigned) std::min<size_t>(c.batch, 65535));
+            if (src_f32 && sizeof(T) == 8)
+                hipLaunchKernelGGL((fx_unzip_kernel<T, float>), grid, dim3(256), 0, st, static_cast<const float *>(c.src_a), static_cast<T *>(c.dst_a),
+                                   static_cast<T *>(c.dst_b), half, in_len, (long long) c.src_stride, (long long) c.dst_stride, (long long) c.batch);
+            else
+                hipLaunchKernelGGL((fx_unzip_kernel<T, T>), grid, dim3(256), 0, st, static_cast<const T *>(c.src_a), static_cast<T *>(c.dst_a),
+                                   static_cast<T *>(c.dst_b), half, in_len, (long long) c.src_stride, (long long) c.dst_stride, (long long) c.batch);
+            return hipGetLastError();
+        }
+        if (c.op == FX_ZIP)
+        {
+            const long long half = n >> 1;
+            if (!half) return hipSuccess;
+            dim3 grid((unsigned) ((half + 255) / 256), (unsigned) std::min<size_t>(c.batch, 65535));
+            hipLaunchKernelGGL(fx_zip_kernel<T>, grid, dim3(256), 0, st, static_cast<const T *>(c.src_a), static_cast<const T *>(c.src_b),
+                               static_cast<T *>(c.dst_a), half, (long long) c.src_stride, (long long) c.dst_stride, (long long) c.batch);
+            return hipGetLastError();
+        }
+
+        FxK<T> k = {};
+        k.sstride = (long long) c.src_stride;
+        k.dstride = (long long) c.dst_stride;
+        k.batch = (long long) c.batch;
+        k.src_f32 = src_f32 ? 1 : 0;
+        const bool complex_op = c.op == FX_FFT || c.op == FX_IFFT;
+        const int lm = complex_op ? (int) c.log2n : (int) c.log2n - 1;          // complex points = 2^lm (lm = -1: a 1-sample real transform)
+        int kind = 0;
+        switch (c.op)
+        {
+            case FX_FFT:
+                k.sa = c.src_a; k.sb = static_cast<const T *>(c.src_b); k.da = static_cast<T *>(c.dst_a); k.db = static_cast<T *>(c.dst_b);
+                k.load = L_SPLIT; k.store = S_SPLIT;
+                break;
+            case FX_IFFT:                                                        // Core.h:1341-1346: exchange the pointers
+                k.sa = c.src_b; k.sb = static_cast<const T *>(c.src_a); k.da = static_cast<T *>(c.dst_b); k.db = static_cast<T *>(c.dst_a);
+                k.load = L_SPLIT; k.store = S_SPLIT;
+                break;
+            case FX_RFFT:
+                k.sa = c.src_a; k.sb = static_cast<const T *>(c.src_b); k.da = static_cast<T *>(c.dst_a); k.db = static_cast<T *>(c.dst_b);
+                k.load = L_SPLIT; k.store = S_POST; kind = 1;
+                break;
+            case FX_RFFT_ZIP:
+                k.sa = c.src_a; k.da = static_cast<T *>(c.dst_a); k.db = static_cast<T *>(c.dst_b);
+                k.in_len = std::min<long long>((long long) c.in_length, n);
+                k.load = L_ZIP; k.store = S_POST; kind = 1;
+                break;
+            case FX_RIFFT:
+                k.sa = c.src_a; k.sb = static_cast<const T *>(c.src_b); k.da = static_cast<T *>(c.dst_a); k.db = static_cast<T *>(c.dst_b);
+                k.load = L_PRE; k.store = S_SPLIT; k.swap_out = 1; kind = 2;
+                break;
+            case FX_RIFFT_ZIP:
+                k.sa = c.src_a; k.sb = static_cast<const T *>(c.src_b); k.da = static_cast<T *>(c.dst_a);
+                k.load = L_PRE; k.store = S_ZIP; k.swap_out = 1; kind = 2;
+                break;
+            default: return hipErrorInvalidValue;
+        }
+        if (lm < 0) return hipSuccess;                                           // nothing to transform or move
+        if (lm <= 1)
+        {
+            if (complex_op && lm == 0 && c.src_a == c.dst_a) return hipSuccess;
+            hipLaunchKernelGGL(fx_tiny_kernel<T>, dim3((unsigned) ((k.batch + 255) / 256)), dim3(256), 0, st, k, kind, (int) c.log2n);
+            return hipGetLastError();
+        }
+        if (lm <= max_lds_log2m<T>())
+        {
+            const C *tw = fx_twiddles<T>(device, lm + 1, err);
+            if (!tw) return hipErrorOutOfMemory;
+            return dispatch_lds<T>(lm, k, tw, st);
+        }
+        return run_big<T>(device, lm, k, st, err);
+    }
+}
+
+bool fftx_valid(const FxCall &c, std::string *err)
+{
+    auto fail = [&](const char *m) { if (err) *err = m; return false; };
+    if (c.op < 0 || c.op >= FX_NUM_OPS) return fail("hcv_fft_exec: unknown operation");
+    if (c.precision < FX_F32 || c.precision > FX_F32_TO_F64) return fail("hcv_fft_exec: unknown precision");
+    if (c.precision == FX_F32_TO_F64 && c.op != FX_RFFT_ZIP && c.op != FX_UNZIP) return fail("hcv_fft_exec: float-to-double applies to the out-of-place rfft and unzip only");
+    const bool complex_op = c.op == FX_FFT || c.op == FX_IFFT;
+    const bool shuffle = c.op == FX_UNZIP || c.op == FX_ZIP;
+    const unsigned cap = shuffle ? 30u : (unsigned) kFxMaxComplexLog2 + (complex_op ? 0u : 1u);
+    if (c.log2n > cap) return fail("hcv_fft_exec: transform size out of range (complex log2 <= 22, real log2 <= 23)");
+    if (c.batch > 0x7fffffffull) return fail("hcv_fft_exec: batch too large");
+    if (!c.batch) return true;
+    const bool two_src = c.op != FX_RFFT_ZIP && c.op != FX_UNZIP, two_dst = c.op != FX_RIFFT_ZIP && c.op != FX_ZIP;
+    if (!c.src_a || !c.dst_a || (two_src && !c.src_b) || (two_dst && !c.dst_b)) return fail("hcv_fft_exec: null operand");
+    return true;
+}
+
+hipError_t fftx_exec(int device, const FxCall &c, hipStream_t stream, std::string *err)
+{
+    if (!fftx_valid(c, err)) return hipErrorInvalidValue;
+    if (!c.batch) return hipSuccess;
+    if (c.precision == FX_F32) return run_typed<float>(device, c, false, stream, err);
+    return run_typed<double>(device, c, c.precision == FX_F32_TO_F64, stream, err);
+}
+
+} // namespace hcv

@@ -173,6 +173,46 @@ HCV_API size_t hcv_spectral_size(size_t size1, size_t size2, int mode);
 HCV_API int hcv_spectral_convolve_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out);
 HCV_API int hcv_spectral_correlate_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out);
 
+/* ---------------------------------------------------------------- the full hisstools_* FFT surface (second "next" row)
+ * Every transform of HISSTools_FFT.h:87-369 — float and double, complex and real, in place on split data or out of
+ * place from / to interleaved samples, plus zip / unzip — as ONE batched entry point.  `op` selects the reference
+ * function, `precision` its overload:
+ *
+ *   HCV_FFT_FFT        hisstools_fft    HISSTools_FFT.h:130,142   complex forward, split (a = realp, b = imagp), 2^log2n points
+ *   HCV_FFT_IFFT       hisstools_ifft   HISSTools_FFT.h:220,232   complex inverse (unnormalised)
+ *   HCV_FFT_RFFT       hisstools_rfft   HISSTools_FFT.h:154,166   real forward on unzipped data: 2^(log2n-1) split values in,
+ *                                                                 packed half spectrum out (x2, DC/Nyquist in bin 0)
+ *   HCV_FFT_RIFFT      hisstools_rifft  HISSTools_FFT.h:244,256   real inverse, split in / split (unzipped samples) out, unnormalised
+ *   HCV_FFT_RFFT_ZIP   hisstools_rfft   HISSTools_FFT.h:180,194,208  in_length samples (src_a), zero padded to 2^log2n -> packed spectrum
+ *   HCV_FFT_RIFFT_ZIP  hisstools_rifft  HISSTools_FFT.h:269,282   packed spectrum -> 2^log2n samples (dst_a)
+ *   HCV_FFT_UNZIP      hisstools_unzip / hisstools_unzip_zero  HISSTools_FFT.h:295-345  (in_length = 2^log2n for plain unzip)
+ *   HCV_FFT_ZIP        hisstools_zip    HISSTools_FFT.h:357,369
+ *
+ * Sizes: complex log2n 0..22, real log2n 0..23 (the reference's FFT_Tester sweeps 0..21), zip/unzip up to 2^30.  `batch`
+ * transforms are processed per call; consecutive transforms lie src_stride / dst_stride ELEMENTS apart (0 = densely
+ * packed).  Operands may alias exactly (in place) or not at all.  The forward and inverse transforms are the
+ * reference's: unnormalised, real spectra doubled, so rifft(rfft(x)) = 2N x and ifft(fft(z)) = N z.
+ * Unlike the reference the out-of-place rifft leaves its input spectrum untouched.
+ *
+ * hcv_fft_exec takes host pointers (one upload, the kernels, one download); hcv_fft_exec_dev takes device pointers on
+ * the default device and enqueues on `stream` (a hipStream_t, NULL = the default stream), waiting only if sync != 0.
+ * Returns 0 ok, -1 on a bad descriptor or a device failure (hcv_last_error). */
+enum { HCV_FFT_FFT = 0, HCV_FFT_IFFT = 1, HCV_FFT_RFFT = 2, HCV_FFT_RIFFT = 3, HCV_FFT_RFFT_ZIP = 4, HCV_FFT_RIFFT_ZIP = 5,
+       HCV_FFT_UNZIP = 6, HCV_FFT_ZIP = 7 };
+enum { HCV_FFT_F32 = 0, HCV_FFT_F64 = 1, HCV_FFT_F32_TO_F64 = 2 /* float samples in, double split out: RFFT_ZIP and UNZIP only */ };
+typedef struct hcv_fft_call
+{
+    int op, precision;
+    unsigned log2n;
+    size_t batch;
+    const void *src_a, *src_b;          /* split: realp / imagp; samples: src_a only */
+    void *dst_a, *dst_b;
+    size_t src_stride, dst_stride;
+    size_t in_length;                   /* RFFT_ZIP / UNZIP: valid samples per transform */
+} hcv_fft_call;
+HCV_API int hcv_fft_exec(const hcv_fft_call *call);
+HCV_API int hcv_fft_exec_dev(const hcv_fft_call *call, void *stream, int sync);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,27 @@
 #undef FN
 
 /* ------------------------------------------------------------------------------------------------
+ * float samples -> double split (HISSTools_FFT.h:208,321; the converting unzip_complex, Core.h:1199-1210)
+ * ---------------------------------------------------------------------------------------------- */
+
+void hcvo_unzip_zero_f32_f64(const float *in, double *re, double *im, size_t in_len, unsigned log2n)
+{
+    size_t n = (size_t) 1 << log2n, half = n >> 1;
+    if (in_len > n) in_len = n;
+    for (size_t k = 0; k < half; k++)
+    {
+        re[k] = (2 * k < in_len) ? (double) in[2 * k] : 0.0;
+        im[k] = (2 * k + 1 < in_len) ? (double) in[2 * k + 1] : 0.0;
+    }
+}
+
+void hcvo_rfft_f32_f64(const float *in, size_t in_len, unsigned log2n, double *realp, double *imagp)
+{
+    hcvo_unzip_zero_f32_f64(in, realp, imagp, in_len, log2n);
+    hcvo_rfft_inplace_f64(realp, imagp, log2n);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * NToMonoConvolve  (NToMonoConvolve.cpp)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -44,6 +44,19 @@ void hcvo_fft_f32(float *realp, float *imagp, unsigned log2n, int inverse);
 void hcvo_rfft_f64(const double *in, size_t in_len, unsigned log2n, double *realp, double *imagp);
 void hcvo_rifft_f64(const double *realp, const double *imagp, unsigned log2n, double *out);
 void hcvo_fft_f64(double *realp, double *imagp, unsigned log2n, int inverse);
+/* the rest of the hisstools_* surface (HISSTools_FFT.h:87-369): in-place real transforms, zip / unzip, float -> double */
+void hcvo_rfft_inplace_f32(float *re, float *im, unsigned log2n);
+void hcvo_rifft_inplace_f32(float *re, float *im, unsigned log2n);
+void hcvo_rfft_inplace_f64(double *re, double *im, unsigned log2n);
+void hcvo_rifft_inplace_f64(double *re, double *im, unsigned log2n);
+void hcvo_unzip_f32(const float *in, float *re, float *im, unsigned log2n);
+void hcvo_unzip_f64(const double *in, double *re, double *im, unsigned log2n);
+void hcvo_unzip_zero_f32(const float *in, float *re, float *im, size_t in_len, unsigned log2n);
+void hcvo_unzip_zero_f64(const double *in, double *re, double *im, size_t in_len, unsigned log2n);
+void hcvo_unzip_zero_f32_f64(const float *in, double *re, double *im, size_t in_len, unsigned log2n);
+void hcvo_zip_f32(const float *re, const float *im, float *out, unsigned log2n);
+void hcvo_zip_f64(const double *re, const double *im, double *out, unsigned log2n);
+void hcvo_rfft_f32_f64(const float *in, size_t in_len, unsigned log2n, double *realp, double *imagp);
 
 /* The class-level API is declared opaque; tests bind it through ctypes (oracle/oracle.py).
  * f32 entry points: hcvo_part_*, hcvo_td_*, hcvo_mono_*, hcvo_n2m_*, hcvo_conv_* (suffix _f32);

@@ -201,6 +201,100 @@ def fft(re, im, log2n: int, inverse: bool = False, backend: str = "port"):
     return re, im
 
 
+# --------------------------------------------------------------------------------------- the full hisstools_* FFT surface
+
+FFT_OPS = ("fft", "ifft", "rfft", "rifft", "rfft_zip", "rifft_zip", "unzip", "zip")
+FFT_PRECISIONS = ("f32", "f64", "f32_to_f64")
+_surface = {}
+
+
+def _surface_lib(backend):
+    """Bind the FFT-surface entry points of the port / the compiled reference (same call shapes for both)."""
+    if backend in _surface:
+        return _surface[backend]
+    L = lib(backend).cdll
+    u = C.c_uint if backend == "port" else _sz
+    f = {}
+    for sfx, fp in (("f32", _f32p), ("f64", _f64p)):
+        if backend == "port":
+            f["fft_" + sfx] = _decl(L, "hcvo_fft_" + sfx, None, fp, fp, u, C.c_int)
+            rf = _decl(L, "hcvo_rfft_inplace_" + sfx, None, fp, fp, u)
+            ri = _decl(L, "hcvo_rifft_inplace_" + sfx, None, fp, fp, u)
+            f["rfft_inplace_" + sfx] = (lambda rf, ri: (lambda re, im, l2, inv: (ri if inv else rf)(re, im, l2)))(rf, ri)
+            f["rfft_" + sfx] = _decl(L, "hcvo_rfft_" + sfx, None, fp, _sz, u, fp, fp)
+            f["rifft_" + sfx] = _decl(L, "hcvo_rifft_" + sfx, None, fp, fp, u, fp)
+            f["unzip_zero_" + sfx] = _decl(L, "hcvo_unzip_zero_" + sfx, None, fp, fp, fp, _sz, u)
+            f["unzip_" + sfx] = _decl(L, "hcvo_unzip_" + sfx, None, fp, fp, fp, u)
+            f["zip_" + sfx] = _decl(L, "hcvo_zip_" + sfx, None, fp, fp, fp, u)
+        else:
+            f["fft_" + sfx] = _decl(L, "ref_fft_" + sfx, None, fp, fp, u, C.c_int)
+            f["rfft_inplace_" + sfx] = _decl(L, "ref_rfft_inplace_" + sfx, None, fp, fp, u, C.c_int)
+            f["rfft_" + sfx] = _decl(L, "ref_rfft_" + sfx, None, fp, _sz, u, fp, fp)
+            f["rifft_" + sfx] = _decl(L, "ref_rifft_" + sfx, None, fp, fp, u, fp)
+            f["unzip_zero_" + sfx] = _decl(L, "ref_unzip_zero_" + sfx, None, fp, fp, fp, _sz, u)
+            f["unzip_" + sfx] = _decl(L, "ref_unzip_" + sfx, None, fp, fp, fp, u)
+            f["zip_" + sfx] = _decl(L, "ref_zip_" + sfx, None, fp, fp, fp, u)
+    pre = "hcvo_" if backend == "port" else "ref_"
+    f["rfft_f32_to_f64"] = _decl(L, pre + "rfft_f32_f64", None, _f32p, _sz, u, _f64p, _f64p)
+    f["unzip_zero_f32_to_f64"] = _decl(L, pre + "unzip_zero_f32_f64", None, _f32p, _f64p, _f64p, _sz, u)
+    _surface[backend] = f
+    return f
+
+
+def fft_surface(op: str, precision: str, log2n: int, a, b=None, in_length=None, backend: str = "port"):
+    """One transform of the hisstools_* surface (HISSTools_FFT.h:87-369) on the CPU oracle.
+
+    op / operands / result:
+      fft, ifft          (realp, imagp) of 2^log2n values        -> (realp, imagp)
+      rfft, rifft        (realp, imagp) of 2^(log2n-1) values    -> (realp, imagp)      in-place real transforms
+      rfft_zip           samples a (in_length of them)           -> (realp, imagp)
+      rifft_zip          (realp, imagp)                          -> 2^log2n samples
+      unzip              samples a (in_length, default 2^log2n)  -> (realp, imagp)      unzip / unzip_zero
+      zip                (realp, imagp)                          -> samples
+    precision: "f32", "f64" or "f32_to_f64" (float samples in, double split out; rfft_zip and unzip only).
+    """
+    f = _surface_lib(backend)
+    n = 1 << log2n
+    half = n >> 1
+    dt = np.float32 if precision == "f32" else np.float64
+    sfx = "f32" if precision == "f32" else "f64"
+    ptr = (lambda v: v.ctypes.data_as(_f32p)) if dt == np.float32 else (lambda v: v.ctypes.data_as(_f64p))
+    if op in ("fft", "ifft"):
+        re, im = np.array(a, dt).copy(), np.array(b, dt).copy()
+        if log2n >= 1:
+            f["fft_" + sfx](ptr(re), ptr(im), log2n, int(op == "ifft"))
+        return re, im
+    if op in ("rfft", "rifft"):
+        re, im = np.array(a, dt).copy(), np.array(b, dt).copy()
+        if log2n >= 1:
+            f["rfft_inplace_" + sfx](ptr(re), ptr(im), log2n, int(op == "rifft"))
+        return re, im
+    if op in ("rfft_zip", "unzip"):
+        src_dt = np.float32 if precision in ("f32", "f32_to_f64") else np.float64
+        x = np.ascontiguousarray(a, src_dt)
+        in_length = x.size if in_length is None else in_length
+        re, im = np.zeros(max(half, 1), dt), np.zeros(max(half, 1), dt)
+        xp = x.ctypes.data_as(_f32p if src_dt == np.float32 else _f64p)
+        if half and in_length:
+            if op == "rfft_zip":
+                name = "rfft_f32_to_f64" if precision == "f32_to_f64" else "rfft_" + sfx
+                f[name](xp, in_length, log2n, ptr(re), ptr(im))
+            else:
+                name = "unzip_zero_f32_to_f64" if precision == "f32_to_f64" else "unzip_zero_" + sfx
+                f[name](xp, ptr(re), ptr(im), in_length, log2n)
+        return re[:half], im[:half]
+    if op in ("rifft_zip", "zip"):
+        re, im = np.array(a, dt).copy(), np.array(b, dt).copy()
+        out = np.zeros(max(n, 2), dt)
+        if half:
+            if op == "zip":
+                f["zip_" + sfx](ptr(re), ptr(im), ptr(out), log2n)
+            else:
+                f["rifft_" + sfx](ptr(re), ptr(im), log2n, ptr(out))
+        return out[:n] if half else out[:0]
+    raise ValueError(op)
+
+
 # --------------------------------------------------------------------------------------- synthetic data
 
 def synth_audio(ch: int, n: int) -> np.ndarray:

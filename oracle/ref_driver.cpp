@@ -139,6 +139,66 @@ extern "C"
         hisstools_unzip_zero(in, &s, in_len, log2n);
     }
 
+    // in-place real transforms on split data (HISSTools_FFT.h:154,166,244,256); buffers are copied to aligned memory so
+    // the reference takes its SIMD path exactly as a host using ALIGNED_MALLOC would
+    void ref_rfft_inplace_f32(float *re, float *im, uintptr_t log2n, int inverse)
+    {
+        FFT_SETUP_F setup;
+        hisstools_create_setup(&setup, log2n);
+        uintptr_t half = (uintptr_t(1) << log2n) >> 1;
+        float *buf = aalloc(2 * half + 8);
+        std::memcpy(buf, re, half * sizeof(float));
+        std::memcpy(buf + half, im, half * sizeof(float));
+        FFT_SPLIT_COMPLEX_F s(buf, buf + half);
+        if (inverse) hisstools_rifft(setup, &s, log2n); else hisstools_rfft(setup, &s, log2n);
+        std::memcpy(re, buf, half * sizeof(float));
+        std::memcpy(im, buf + half, half * sizeof(float));
+        free(buf);
+        hisstools_destroy_setup(setup);
+    }
+
+    void ref_rfft_inplace_f64(double *re, double *im, uintptr_t log2n, int inverse)
+    {
+        FFT_SETUP_D setup;
+        hisstools_create_setup(&setup, log2n);
+        FFT_SPLIT_COMPLEX_D s(re, im);
+        if (inverse) hisstools_rifft(setup, &s, log2n); else hisstools_rfft(setup, &s, log2n);
+        hisstools_destroy_setup(setup);
+    }
+
+    void ref_rfft_f32_f64(const float *in, uintptr_t in_len, uintptr_t log2n, double *realp, double *imagp)
+    {
+        FFT_SETUP_D setup;
+        hisstools_create_setup(&setup, log2n);
+        FFT_SPLIT_COMPLEX_D s(realp, imagp);
+        hisstools_rfft(setup, in, &s, in_len, log2n);
+        hisstools_destroy_setup(setup);
+    }
+
+    void ref_unzip_f64(const double *in, double *realp, double *imagp, uintptr_t log2n)
+    {
+        FFT_SPLIT_COMPLEX_D s(realp, imagp);
+        hisstools_unzip(in, &s, log2n);
+    }
+
+    void ref_zip_f64(const double *realp, const double *imagp, double *out, uintptr_t log2n)
+    {
+        FFT_SPLIT_COMPLEX_D s(const_cast<double *>(realp), const_cast<double *>(imagp));
+        hisstools_zip(&s, out, log2n);
+    }
+
+    void ref_unzip_zero_f64(const double *in, double *realp, double *imagp, uintptr_t in_len, uintptr_t log2n)
+    {
+        FFT_SPLIT_COMPLEX_D s(realp, imagp);
+        hisstools_unzip_zero(in, &s, in_len, log2n);
+    }
+
+    void ref_unzip_zero_f32_f64(const float *in, double *realp, double *imagp, uintptr_t in_len, uintptr_t log2n)
+    {
+        FFT_SPLIT_COMPLEX_D s(realp, imagp);
+        hisstools_unzip_zero(in, &s, in_len, log2n);
+    }
+
     // ---------------------------------------------------------------- PartitionedConvolve
 
     void *ref_part_new(uintptr_t maxFFTSize, uintptr_t maxLength, uintptr_t offset, uintptr_t length)

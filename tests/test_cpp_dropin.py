@@ -12,9 +12,13 @@ EXE = os.path.join(OUT_DIR, "dropin_smoke")
 LIBDIR = os.path.join(ROOT, "hisstools_library_amd")
 
 
-def build():
+FFT_SRC = os.path.join(ROOT, "tests", "cpp", "fft_tester.cpp")
+FFT_EXE = os.path.join(OUT_DIR, "fft_tester")
+
+
+def build(src=SRC, exe=EXE):
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", SRC, "-o", EXE, f"-L{LIBDIR}", "-lhisstools_amd",
+    cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", src, "-o", exe, f"-L{LIBDIR}", "-lhisstools_amd",
            f"-Wl,-rpath,{LIBDIR}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
 
@@ -30,3 +34,18 @@ def test_dropin_convolver_runs_on_gpu():
     build()
     out = subprocess.run([EXE], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_fft_header_compiles_and_links():
+    """Every overload of HISSTools_FFT.h:87-369 resolves against the drop-in header."""
+    build(FFT_SRC, FFT_EXE)
+    assert subprocess.call([FFT_EXE]) in (0, 2)
+
+
+@pytest.mark.gpu
+def test_fft_tester_programme_runs_on_gpu():
+    """The FFT_Tester-style programme: zip round trips log2 1..23, fft/ifft/rfft/rifft log2 0..21, double and float."""
+    build(FFT_SRC, FFT_EXE)
+    out = subprocess.run([FFT_EXE], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Finished Running" in out.stdout

@@ -88,17 +88,17 @@ __global__ __launch_bounds__(256) void big_cols_kernel(const float2 *__restrict_
     for (int e = threadIdx.x; e < BIG_COLS * M1; e += 256)
     {
         const int c = e % BIG_COLS, n1 = e / BIG_COLS;
-        lds[c * M1 + n1] = zin[(long long) n1 * M2 + col0 + c];
+        LdsBuf<float2>{ lds + c * lds_padded(M1) }[n1] = zin[(long long) n1 * M2 + col0 + c];
     }
     __syncthreads();
     const int g = threadIdx.x / TG, t = threadIdx.x % TG;
-    for (int c0 = 0; c0 < BIG_COLS; c0 += G) LdsFFT<L1, TG>::run(lds + (c0 + g) * M1, t, tw1);
+    for (int c0 = 0; c0 < BIG_COLS; c0 += G) LdsFFT<L1, TG>::run(LdsBuf<float2>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
     for (int e = threadIdx.x; e < BIG_COLS * M1; e += 256)
     {
         const int c = e % BIG_COLS, k1 = e / BIG_COLS;
         const int n2 = col0 + c;
         const float2 w = root_rt(twN, 2 * n2 * k1, M);             // W_M^(n2 k1) = (N-th root)^(2 n2 k1)
-        tout[(long long) k1 * M2 + n2] = cmul(lds[c * M1 + k1], w);
+        tout[(long long) k1 * M2 + n2] = cmul(LdsBuf<float2>{ lds + c * lds_padded(M1) }[k1], w);
     }
 }
 
@@ -115,18 +115,18 @@ __global__ __launch_bounds__(256) void big_rows_kernel(const float2 *__restrict_
     const float2 *tin = Tin + (long long) blockIdx.y * M + (long long) row0 * M2;
     float2 *zout = Zout + (long long) blockIdx.y * M;
 
-    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += 256) lds[e] = tin[e];
+    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += 256) LdsBuf<float2>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = tin[e];
     __syncthreads();
     const int g = threadIdx.x / TG, t = threadIdx.x % TG;
     for (int r0 = 0; r0 < BIG_ROWS; r0 += G)
     {
         // G may exceed BIG_ROWS for short rows: the surplus groups transform rows of the same tile again
-        LdsFFT<L2, TG>::run(lds + ((r0 + g) % BIG_ROWS) * M2, t, tw2);
+        LdsFFT<L2, TG>::run(LdsBuf<float2>{ lds + ((r0 + g) % BIG_ROWS) * lds_padded(M2) }, t, tw2);
     }
     for (int e = threadIdx.x; e < BIG_ROWS * M2; e += 256)
     {
         const int r = e % BIG_ROWS, k2 = e / BIG_ROWS;
-        zout[(long long) (row0 + r) + (long long) M1 * k2] = lds[r * M2 + k2];
+        zout[(long long) (row0 + r) + (long long) M1 * k2] = LdsBuf<float2>{ lds + r * lds_padded(M2) }[k2];
     }
 }
 
@@ -230,7 +230,7 @@ static hipError_t big_cfft(int log2n, float2 *a, float2 *b, int batch, const Big
     int l1, l2;
     big_fft_split(log2n, l1, l2);
     const int M = 1 << (log2n - 1), M1 = 1 << l1, M2 = 1 << l2;
-    const size_t lds1 = sizeof(float2) * BIG_COLS * M1, lds2 = sizeof(float2) * BIG_ROWS * M2;
+    const size_t lds1 = sizeof(float2) * BIG_COLS * lds_padded(M1), lds2 = sizeof(float2) * BIG_ROWS * lds_padded(M2);
     dim3 gc(M2 / BIG_COLS, batch), gr(M1 / BIG_ROWS, batch);
 #define HCV_BIG_COLS(L)                                                                                                \
     case L:                                                                                                            \

@@ -41,104 +41,289 @@ __device__ __forceinline__ C root(const C *__restrict__ tw, int m)
 
 // ------------------------------------------------------------------------------------------------
 // In-LDS complex FFT of M = 2^LOG2M points, forward sign, unnormalised, natural order in and out.
-// Stockham autosort, radix-4 passes plus one radix-2 pass when LOG2M is odd.  TG threads cooperate on one
-// transform; every pass is "read my butterflies into registers / barrier / write results / barrier", so a
-// single M-point LDS buffer suffices (64 KiB at N = 16384 in float).
+// Stockham autosort: radix-16 passes (two radix-4 layers fused in registers, so the data crosses LDS once per FOUR
+// butterfly levels), then one radix-4 and / or radix-2 pass for the remaining levels.  TG threads cooperate on one
+// transform; every pass is "read my butterflies into registers / barrier / write results / barrier", so a single
+// M-point LDS buffer (LdsBuf, padded) suffices (68 KiB at N = 16384 in float).  Twiddles come from the table: a radix-16 butterfly
+// needs six loads (w, w^2, w^3 and w^4, w^8, w^12) and none in the first pass, where every twiddle is 1.
 // ------------------------------------------------------------------------------------------------
+
+// LDS buffer of one transform with one spare element after every 16: the radix-16 passes touch LDS at element strides
+// of 16 * p, which would land 64 lanes on two banks; the skew spreads them over all of them (<= 2-way conflicts).
+__host__ __device__ constexpr int lds_padded(int points) { return points + (points >> 4); }
+
+template <class C> struct LdsBuf
+{
+    C *base;
+    __device__ __forceinline__ C &operator[](int i) const { return base[i + (i >> 4)]; }
+};
+
+template <class C> __device__ __forceinline__ void radix4(C &x0, C &x1, C &x2, C &x3)
+{
+    const C a = C(x0.x + x2.x, x0.y + x2.y);
+    const C c = C(x0.x - x2.x, x0.y - x2.y);
+    const C e = C(x1.x + x3.x, x1.y + x3.y);
+    const C d = C(x1.y - x3.y, x3.x - x1.x);                 // -i * (x1 - x3)
+    x0 = C(a.x + e.x, a.y + e.y);
+    x1 = C(c.x + d.x, c.y + d.y);
+    x2 = C(a.x - e.x, a.y - e.y);
+    x3 = C(c.x - d.x, c.y - d.y);
+}
+
+// v * (cr + i ci) for a compile-time-known constant
+template <class C, class R> __device__ __forceinline__ C mulk(C v, R cr, R ci)
+{
+    return C(v.x * cr - v.y * ci, v.x * ci + v.y * cr);
+}
+
+// 16-point DFT of u[0..15] in place: on return u[q] holds bin q.  Input index r = 4a + b, bin q = q1 + 4 q2:
+// radix-4 over a, twiddle W16^(b q1), radix-4 over b.  wb (b = 1..3) are extra per-column factors folded into the
+// middle twiddle (the Stockham pass twiddle w^b); pass nullptr-like ones via ONES = true to skip them.
+template <bool ONES, class C> __device__ __forceinline__ void dft16(C *u, C w1, C w2, C w3)
+{
+    typedef decltype(u[0].x) R;
+    const R c1 = (R) 0.92387953251128675613, s1 = (R) 0.38268343236508977173, h = (R) 0.70710678118654752440;
+#pragma unroll
+    for (int b = 0; b < 4; b++) radix4(u[b], u[4 + b], u[8 + b], u[12 + b]);          // u[4 q1 + b] = T_b[q1]
+    if (!ONES)
+    {
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++)
+        {
+            u[4 * q1 + 1] = cmul(u[4 * q1 + 1], w1);
+            u[4 * q1 + 2] = cmul(u[4 * q1 + 2], w2);
+            u[4 * q1 + 3] = cmul(u[4 * q1 + 3], w3);
+        }
+    }
+    // W16^(b q1), W16 = exp(-2 pi i / 16)
+    u[4 + 1] = mulk(u[4 + 1], c1, -s1);                       // b q1 = 1
+    u[4 + 2] = mulk(u[4 + 2], h, -h);                         // 2
+    u[4 + 3] = mulk(u[4 + 3], s1, -c1);                       // 3
+    u[8 + 1] = mulk(u[8 + 1], h, -h);                         // 2
+    u[8 + 2] = C(u[8 + 2].y, -u[8 + 2].x);                    // 4: -i
+    u[8 + 3] = mulk(u[8 + 3], -h, -h);                        // 6
+    u[12 + 1] = mulk(u[12 + 1], s1, -c1);                     // 3
+    u[12 + 2] = mulk(u[12 + 2], -h, -h);                      // 6
+    u[12 + 3] = mulk(u[12 + 3], -c1, s1);                     // 9
+#pragma unroll
+    for (int q1 = 0; q1 < 4; q1++) radix4(u[4 * q1], u[4 * q1 + 1], u[4 * q1 + 2], u[4 * q1 + 3]);   // u[4 q1 + q2] = X[q1 + 4 q2]
+}
+
+// Where a pass takes its inputs from / puts its outputs: the LDS buffer itself ...
+template <class C> struct LdsIO
+{
+    static constexpr bool is_lds = true;
+    LdsBuf<C> s;
+    __device__ __forceinline__ C operator()(int n) const { return s[n]; }
+    __device__ __forceinline__ void operator()(int k, C v) const { s[k] = v; }
+};
+// ... or any functor with `static constexpr bool is_lds = false`, `C operator()(int n)` (element n of the input) or
+// `void operator()(int k, C v)` (bin k of the result): the first pass then reads HBM straight into its butterfly
+// registers (all of a thread's loads in flight at once) and the last one writes its results without touching LDS.
 
 template <int LOG2M, int TG, class C = float2>
 struct LdsFFT
 {
     static constexpr int M = 1 << LOG2M;
-    static constexpr int NB4 = M / 4;
+    static constexpr int N16 = LOG2M / 4;                    // radix-16 passes
+    static constexpr int REM = LOG2M % 4;                    // 2, 3: one radix-4 pass; odd: one radix-2 pass
+    static constexpr int NB16 = M / 16 > 0 ? M / 16 : 1;
+    static constexpr int BPT16 = (NB16 + TG - 1) / TG;
+    static constexpr int NB4 = M / 4 > 0 ? M / 4 : 1;
     static constexpr int BPT4 = (NB4 + TG - 1) / TG;
-    static constexpr int NB2 = M / 2;
+    static constexpr int NB2 = M / 2 > 0 ? M / 2 : 1;
     static constexpr int BPT2 = (NB2 + TG - 1) / TG;
 
-    __device__ static __forceinline__ void run(C *s, int tid, const C *__restrict__ tw)
+    template <bool FIRST, class Src, class Dst>
+    __device__ static __forceinline__ void pass16(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
     {
+        C u[BPT16][16];
+#pragma unroll
+        for (int b = 0; b < BPT16; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB16 % TG == 0 || i < NB16)
+            {
+#pragma unroll
+                for (int r = 0; r < 16; r++) u[b][r] = src(i + r * NB16);
+            }
+        }
+        if (Src::is_lds && Dst::is_lds) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BPT16; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB16 % TG == 0 || i < NB16)
+            {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 4) + k;
+                if (FIRST)
+                    dft16<true>(u[b], C(), C(), C());
+                else
+                {
+                    // pass twiddle w^r, w = exp(-2 pi i k / (16 p)) = root(k * 2M / (16 p)); r = 4a + b: w^(4a) here, w^b inside
+                    const int step = k * ((2 * M) / (16 * p));
+                    const C w4 = root<LOG2M>(tw, 4 * step), w8 = root<LOG2M>(tw, 8 * step), w12 = root<LOG2M>(tw, 12 * step);
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                    {
+                        u[b][4 + c] = cmul(u[b][4 + c], w4);
+                        u[b][8 + c] = cmul(u[b][8 + c], w8);
+                        u[b][12 + c] = cmul(u[b][12 + c], w12);
+                    }
+                    dft16<false>(u[b], root<LOG2M>(tw, step), root<LOG2M>(tw, 2 * step), root<LOG2M>(tw, 3 * step));
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) dst(j + (q1 + 4 * q2) * p, u[b][4 * q1 + q2]);
+            }
+        }
+        if (Dst::is_lds) __syncthreads();
+    }
+
+    template <class Src, class Dst>
+    __device__ static __forceinline__ void pass4(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
+    {
+        C u[BPT4][4];
+#pragma unroll
+        for (int b = 0; b < BPT4; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB4 % TG == 0 || i < NB4)
+            {
+#pragma unroll
+                for (int r = 0; r < 4; r++) u[b][r] = src(i + r * NB4);
+            }
+        }
+        if (Src::is_lds && Dst::is_lds) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BPT4; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB4 % TG == 0 || i < NB4)
+            {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 2) + k;
+                // twiddle exp(-2 pi i k r / (4p)) = root(k * r * (2M / 4p))
+                const int step = k * ((2 * M) / (4 * p));
+                u[b][1] = cmul(u[b][1], root<LOG2M>(tw, step));
+                u[b][2] = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
+                u[b][3] = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
+                radix4(u[b][0], u[b][1], u[b][2], u[b][3]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst(j + r * p, u[b][r]);
+            }
+        }
+        if (Dst::is_lds) __syncthreads();
+    }
+
+    template <class Src, class Dst>
+    __device__ static __forceinline__ void pass2(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
+    {
+        C u[BPT2][2];
+#pragma unroll
+        for (int b = 0; b < BPT2; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB2 % TG == 0 || i < NB2)
+            {
+                u[b][0] = src(i);
+                u[b][1] = src(i + NB2);
+            }
+        }
+        if (Src::is_lds && Dst::is_lds) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BPT2; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB2 % TG == 0 || i < NB2)
+            {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 1) + k;
+                const C u0 = u[b][0];
+                const C u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
+                dst(j, C(u0.x + u1.x, u0.y + u1.y));
+                dst(j + p, C(u0.x - u1.x, u0.y - u1.y));
+            }
+        }
+        if (Dst::is_lds) __syncthreads();
+    }
+
+    // Transform with the input taken from `ld` and the result handed to `st`; s is the scratch between the passes.
+    // If ld reads LDS (LdsIO or a functor over it) the caller has already synchronised after filling it.
+    template <class Ld, class St>
+    __device__ static __forceinline__ void run(const Ld &ld, const St &st, LdsBuf<C> s, int tid, const C *__restrict__ tw)
+    {
+        const LdsIO<C> io = { s };
+        constexpr bool TAIL4 = REM >= 2, TAIL2 = (REM & 1) != 0;
         int p = 1;
+        if constexpr (N16 > 0)
+        {
+            if constexpr (N16 == 1 && !TAIL4 && !TAIL2)
+            {
+                pass16<true>(ld, st, tid, tw, 1);
+                return;
+            }
+            else
+            {
+                pass16<true>(ld, io, tid, tw, 1);
+                p = 16;
+                constexpr int INNER = (TAIL4 || TAIL2) ? N16 - 1 : N16 - 2;     // LDS -> LDS radix-16 passes
 #pragma unroll 1
-        for (int pass = 0; pass < LOG2M / 2; pass++, p <<= 2)
-        {
-            C u[BPT4][4];
-#pragma unroll
-            for (int b = 0; b < BPT4; b++)
-            {
-                int i = tid + b * TG;
-                if (NB4 % TG == 0 || i < NB4)
+                for (int pass = 0; pass < INNER; pass++, p <<= 4) pass16<false>(io, io, tid, tw, p);
+                if constexpr (!TAIL4 && !TAIL2)
                 {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) u[b][r] = s[i + r * NB4];
+                    pass16<false>(io, st, tid, tw, p);
+                    return;
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < BPT4; b++)
-            {
-                int i = tid + b * TG;
-                if (NB4 % TG == 0 || i < NB4)
-                {
-                    int k = i & (p - 1);
-                    int j = ((i - k) << 2) + k;
-                    // twiddle exp(-2 pi i k r / (4p)) = root(k * r * (2M / 4p))
-                    int step = k * ((2 * M) / (4 * p));
-                    C u0 = u[b][0];
-                    C u1 = cmul(u[b][1], root<LOG2M>(tw, step));
-                    C u2 = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
-                    C u3 = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
-                    C a = C(u0.x + u2.x, u0.y + u2.y);
-                    C c = C(u0.x - u2.x, u0.y - u2.y);
-                    C e = C(u1.x + u3.x, u1.y + u3.y);
-                    C d = C(u1.y - u3.y, u3.x - u1.x);     // -i * (u1 - u3)
-                    s[j] = C(a.x + e.x, a.y + e.y);
-                    s[j + p] = C(c.x + d.x, c.y + d.y);
-                    s[j + 2 * p] = C(a.x - e.x, a.y - e.y);
-                    s[j + 3 * p] = C(c.x - d.x, c.y - d.y);
-                }
-            }
-            __syncthreads();
         }
-        if (LOG2M & 1)
+        if constexpr (TAIL4)
         {
-            C u[BPT2][2];
-#pragma unroll
-            for (int b = 0; b < BPT2; b++)
+            if constexpr (N16 == 0)
             {
-                int i = tid + b * TG;
-                if (NB2 % TG == 0 || i < NB2)
-                {
-                    u[b][0] = s[i];
-                    u[b][1] = s[i + NB2];
-                }
+                if constexpr (TAIL2) pass4(ld, io, tid, tw, p); else pass4(ld, st, tid, tw, p);
             }
-            __syncthreads();
-#pragma unroll
-            for (int b = 0; b < BPT2; b++)
+            else
             {
-                int i = tid + b * TG;
-                if (NB2 % TG == 0 || i < NB2)
-                {
-                    int k = i & (p - 1);
-                    int j = ((i - k) << 1) + k;
-                    C u0 = u[b][0];
-                    C u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
-                    s[j] = C(u0.x + u1.x, u0.y + u1.y);
-                    s[j + p] = C(u0.x - u1.x, u0.y - u1.y);
-                }
+                if constexpr (TAIL2) pass4(io, io, tid, tw, p); else pass4(io, st, tid, tw, p);
             }
-            __syncthreads();
+            p <<= 2;
         }
+        if constexpr (TAIL2)
+        {
+            if constexpr (N16 == 0 && !TAIL4) pass2(ld, st, tid, tw, p); else pass2(io, st, tid, tw, p);
+        }
+    }
+
+    // in place on data already in LDS (and synchronised); leaves the result in LDS, synchronised
+    __device__ static __forceinline__ void run(LdsBuf<C> s, int tid, const C *__restrict__ tw)
+    {
+        const LdsIO<C> io = { s };
+        run(io, io, s, tid, tw);
     }
 };
 
-// threads cooperating on one transform and transforms per 256-thread workgroup
-template <int LOG2M> struct FFTGeom
+// Threads cooperating on one transform and transforms per workgroup.  Long transforms get one radix-16 butterfly per
+// thread, up to 1024 threads (16 waves keep enough loads in flight when a single 8192- or 16384-point transform owns the
+// CU's LDS); short ones (M <= HCV_FFT_SMALL) get M / HCV_FFT_DIV_SMALL threads, which shortens the tail passes.
+#ifndef HCV_FFT_SMALL
+#define HCV_FFT_SMALL 0
+#endif
+#ifndef HCV_FFT_DIV_SMALL
+#define HCV_FFT_DIV_SMALL 16
+#endif
+#ifndef HCV_FFT_WG
+#define HCV_FFT_WG 256
+#endif
+template <int LOG2M, int WG = HCV_FFT_WG> struct FFTGeom
 {
     static constexpr int M = 1 << LOG2M;
-    static constexpr int TG = (M / 4) < 256 ? (M / 4) : 256;
-    static constexpr int G = 256 / TG;
-    static constexpr int THREADS = TG * G;
+    static constexpr int DIV = M <= HCV_FFT_SMALL ? HCV_FFT_DIV_SMALL : 16;
+    static constexpr int TG = (M / DIV) < 1 ? 1 : ((M / DIV) < 1024 ? (M / DIV) : 1024);
+    static constexpr int THREADS = TG > WG ? TG : WG;
+    static constexpr int G = THREADS / TG;
 };
 
 

@@ -24,6 +24,10 @@
 #include <mutex>
 #include <vector>
 
+#ifndef FX_WG
+#define FX_WG 256
+#endif
+
 namespace hcv
 {
 
@@ -129,34 +133,65 @@ namespace
         im[m] = u2 - i4;
     }
 
-    // -------------------------------------------------------------------------------------------- LDS-resident transforms
-
-    template <class T, int LOG2M>
-    __global__ __launch_bounds__(256) void fx_lds_kernel(FxK<T> a, const typename Cx<T>::type *__restrict__ tw)
+    // first-pass source / last-pass sink of the LDS-resident kernel: HBM <-> butterfly registers
+    template <class T, int M> struct FxLoad
     {
         typedef typename Cx<T>::type C;
-        typedef FFTGeom<LOG2M> Gm;
+        static constexpr bool is_lds = false;
+        const FxK<T> &a;
+        long long q;
+        const C *__restrict__ tw;
+        bool live;
+        __device__ __forceinline__ C operator()(int n) const { return live ? fx_load<T, C>(a, q, n, M, tw) : C(0, 0); }
+    };
+
+    template <class T> struct FxStore
+    {
+        typedef typename Cx<T>::type C;
+        static constexpr bool is_lds = false;
+        const FxK<T> &a;
+        long long q;
+        bool live;
+        __device__ __forceinline__ void operator()(int k, C v) const
+        {
+            if (live) fx_store<T, C>(a, q, k, v);
+        }
+    };
+
+    // -------------------------------------------------------------------------------------------- LDS-resident transforms
+
+    // minimum workgroup size (threads) of the LDS-resident kernel
+    template <class T, int LOG2M> __host__ __device__ constexpr int fx_wg() { return FX_WG; }
+
+    // second launch bound = waves per SIMD the register budget must allow (HIP semantics): 4 -> 128 VGPRs in float
+    template <class T, int LOG2M>
+    __global__ __launch_bounds__((FFTGeom<LOG2M, fx_wg<T, LOG2M>()>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a, const typename Cx<T>::type *__restrict__ tw)
+    {
+        typedef typename Cx<T>::type C;
+        typedef FFTGeom<LOG2M, fx_wg<T, LOG2M>()> Gm;
         constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
         extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
         C *lds = reinterpret_cast<C *>(fx_raw);
 
-        const int g = threadIdx.x / TG, t = threadIdx.x % TG;
+        // groups of whole waves are wave-uniform: keeps the per-transform pointers scalar and the lane addresses 32-bit
+        const int g = (TG % 64 == 0) ? __builtin_amdgcn_readfirstlane((int) (threadIdx.x / TG)) : (int) (threadIdx.x / TG), t = threadIdx.x % TG;
         const long long q = (long long) blockIdx.x * G + g;
         const bool live = q < a.batch;
-        C *s = lds + g * M;
-        if (live)
-            for (int n = t; n < M; n += TG) s[n] = fx_load<T, C>(a, q, n, M, tw);
-        __syncthreads();
-        LdsFFT<LOG2M, TG, C>::run(s, t, tw);
-        if (!live) return;
+        const LdsBuf<C> s = { lds + g * lds_padded(M) };
+        const FxLoad<T, M> ld = { a, q, tw, live };
+#ifdef FX_SKIP_FFT
+        for (int n = t; n < M; n += TG) if (live) fx_store<T, C>(a, q, n, ld(n));
+        return;
+#endif
         if (a.store == S_POST)
         {
-            for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, q, k, M, s[k], s[(M - k) & (M - 1)], tw);
+            // the real post pass pairs bin k with bin M-k: finish in LDS, then combine
+            LdsFFT<LOG2M, TG, C>::run(ld, LdsIO<C>{ s }, s, t, tw);
+            if (live)
+                for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, q, k, M, s[k], s[(M - k) & (M - 1)], tw);
         }
         else
-        {
-            for (int k = t; k < M; k += TG) fx_store<T, C>(a, q, k, s[k]);
-        }
+            LdsFFT<LOG2M, TG, C>::run(ld, FxStore<T>{ a, q, live }, s, t, tw);
     }
 
     // -------------------------------------------------------------------------------------------- tiny transforms (M <= 2)
@@ -224,9 +259,15 @@ namespace
 
     // -------------------------------------------------------------------------------------------- four-step passes
 
+    // threads per sub-transform and sub-transforms per 256-thread workgroup
+    __host__ __device__ constexpr int fx_tg(int points) { return points / 16 < 256 ? points / 16 : 256; }
+
+    // adjacent columns / rows per workgroup: `want` for coalescing, at most 128 KiB of LDS, at least one per thread group
     __host__ __device__ constexpr int fx_tile(int points, int elem_bytes, int want)
     {
-        return (128 * 1024 / (points * elem_bytes)) < want ? (128 * 1024 / (points * elem_bytes)) : want;
+        const int cap = 128 * 1024 / (points * elem_bytes)   /* + 1/16 padding: 136 KiB of the 160 KiB */, groups = 256 / fx_tg(points);
+        const int t = cap < want ? cap : want;
+        return t < groups ? groups : t;
     }
 
     template <class C>
@@ -243,7 +284,7 @@ namespace
     {
         typedef typename Cx<T>::type C;
         constexpr int M1 = 1 << L1;
-        constexpr int TG = (M1 / 4) < 256 ? (M1 / 4) : 256;
+        constexpr int TG = fx_tg(M1);
         constexpr int G = 256 / TG;
         constexpr int COLS = fx_tile(M1, (int) sizeof(C), 128 / (int) sizeof(C));
         static_assert(G <= COLS, "one thread group per column");
@@ -255,17 +296,17 @@ namespace
         for (int e = threadIdx.x; e < COLS * M1; e += 256)
         {
             const int c = e % COLS, n1 = e / COLS;
-            lds[c * M1 + n1] = fx_load<T, C>(a, q, n1 * M2 + col0 + c, M, twN);
+            LdsBuf<C>{ lds + c * lds_padded(M1) }[n1] = fx_load<T, C>(a, q, n1 * M2 + col0 + c, M, twN);
         }
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
-        for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(lds + (c0 + g) * M1, t, tw1);
+        for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(LdsBuf<C>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
         C *out = work + (long long) blockIdx.y * M;
         for (int e = threadIdx.x; e < COLS * M1; e += 256)
         {
             const int c = e % COLS, k1 = e / COLS;
             const int n2 = col0 + c;
-            out[(long long) k1 * M2 + n2] = cmul(lds[c * M1 + k1], fx_root_rt(twN, 2 * n2 * k1, M));
+            out[(long long) k1 * M2 + n2] = cmul(LdsBuf<C>{ lds + c * lds_padded(M1) }[k1], fx_root_rt(twN, 2 * n2 * k1, M));
         }
     }
 
@@ -276,7 +317,7 @@ namespace
     {
         typedef typename Cx<T>::type C;
         constexpr int M2 = 1 << L2;
-        constexpr int TG = (M2 / 4) < 256 ? (M2 / 4) : 256;
+        constexpr int TG = fx_tg(M2);
         constexpr int G = 256 / TG;
         constexpr int ROWS = fx_tile(M2, (int) sizeof(C), 8);
         static_assert(G <= ROWS, "one thread group per row");
@@ -285,16 +326,16 @@ namespace
 
         const int row0 = blockIdx.x * ROWS;
         const C *in = work + (long long) blockIdx.y * M + (long long) row0 * M2;
-        for (int e = threadIdx.x; e < ROWS * M2; e += 256) lds[e] = in[e];
+        for (int e = threadIdx.x; e < ROWS * M2; e += 256) LdsBuf<C>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = in[e];
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
-        for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(lds + (r0 + g) * M2, t, tw2);
+        for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(LdsBuf<C>{ lds + (r0 + g) * lds_padded(M2) }, t, tw2);
         const long long q = q0 + blockIdx.y;
         for (int e = threadIdx.x; e < ROWS * M2; e += 256)
         {
             const int r = e % ROWS, k2 = e / ROWS;
             const int k = row0 + r + M1 * k2;
-            const C v = lds[r * M2 + k2];
+            const C v = LdsBuf<C>{ lds + r * lds_padded(M2) }[k2];
             if (a.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
             else fx_store<T, C>(a, q, k, v);
         }
@@ -420,8 +461,8 @@ namespace
     template <class T, int L> hipError_t launch_lds(const FxK<T> &k, const typename Cx<T>::type *tw, hipStream_t st)
     {
         typedef typename Cx<T>::type C;
-        typedef FFTGeom<L> Gm;
-        const size_t lds = sizeof(C) * Gm::M * Gm::G;
+        typedef FFTGeom<L, fx_wg<T, L>()> Gm;
+        const size_t lds = sizeof(C) * lds_padded(Gm::M) * Gm::G;
         hipError_t e = allow_big_lds(fx_lds_kernel<T, L>, lds);
         if (e != hipSuccess) return e;
         const long long grid = (k.batch + Gm::G - 1) / Gm::G;
@@ -448,7 +489,7 @@ namespace
     {
         typedef typename Cx<T>::type C;
         constexpr int COLS = fx_tile(1 << L1, (int) sizeof(C), 128 / (int) sizeof(C));
-        const size_t lds = sizeof(C) * COLS * (size_t(1) << L1);
+        const size_t lds = sizeof(C) * COLS * (size_t) lds_padded(1 << L1);
         hipError_t e = allow_big_lds(fx_cols_kernel<T, L1>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / COLS, nb), dim3(256), lds, st, k, work, M2, M, q0, tw1, twN);
@@ -460,7 +501,7 @@ namespace
     {
         typedef typename Cx<T>::type C;
         constexpr int ROWS = fx_tile(1 << L2, (int) sizeof(C), 8);
-        const size_t lds = sizeof(C) * ROWS * (size_t(1) << L2);
+        const size_t lds = sizeof(C) * ROWS * (size_t) lds_padded(1 << L2);
         hipError_t e = allow_big_lds(fx_rows_kernel<T, L2>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((fx_rows_kernel<T, L2>), dim3(M1 / ROWS, nb), dim3(256), lds, st, work, k, post, M1, M, q0, tw2);

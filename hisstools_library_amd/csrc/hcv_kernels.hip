@@ -24,11 +24,20 @@
 namespace hcv
 {
 
+// Index of the thread group (= transform) within the workgroup.  Groups of whole waves are wave-uniform: saying so
+// keeps every per-transform pointer in scalar registers and the per-lane addresses 32-bit.
+template <int TG> __device__ __forceinline__ int wave_uniform_group()
+{
+    const int g = threadIdx.x / TG;
+    if (TG % 64 == 0) return __builtin_amdgcn_readfirstlane(g);
+    return g;
+}
+
 // Real post-pass of the forward transform (the maths of pass_real_trig_table<false>,
 // HISSTools_FFT_Core.h:934-988): s holds Z = FFT_M(x_even + i x_odd); writes the packed, doubled half
 // spectrum to dst[0..M).
 template <int LOG2M, int TG>
-__device__ __forceinline__ void real_post_store(const float2 *s, int tid, const float2 *__restrict__ tw, float2 *__restrict__ dst)
+__device__ __forceinline__ void real_post_store(LdsBuf<float2> s, int tid, const float2 *__restrict__ tw, float2 *__restrict__ dst)
 {
     constexpr int M = 1 << LOG2M;
     for (int k = tid; k <= M / 2; k += TG)
@@ -60,8 +69,21 @@ __device__ __forceinline__ void real_post_store(const float2 *s, int tid, const 
 //   out: X[(i * R + (h mod R)) * M + k]
 // ------------------------------------------------------------------------------------------------
 
+struct FrameLoad
+{
+    static constexpr bool is_lds = false;
+    const float *row;
+    long long base, mask;
+    bool live;
+    __device__ __forceinline__ float2 operator()(int k) const
+    {
+        if (!live) return make_float2(0.f, 0.f);
+        return *reinterpret_cast<const float2 *>(row + ((base + 2LL * k) & mask));
+    }
+};
+
 template <int LOG2M>
-__global__ __launch_bounds__(256) void rfft_frames_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rfft_frames_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
                                                           long long h_first, int T, int nin, float2 *__restrict__ X, int R,
                                                           const float2 *__restrict__ tw)
 {
@@ -69,22 +91,16 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(const float *__restric
     constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
 
-    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
     const int q = blockIdx.x * G + g;
     const bool live = q < T * nin;
     const int t = live ? q / nin : 0, i = live ? q % nin : 0;
     const long long h = h_first + t;
-    float2 *s = lds + g * M;
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
 
-    const float *row = hist + (long long) i * hist_stride;
-    const long long base = (h - 1) * (long long) M;      // hop = M samples, frame = 2M samples = M float2
-    for (int k = tid; k < M; k += TG)
-    {
-        long long pos = (base + 2LL * k) & hist_mask;     // even, so the float2 never straddles the wrap
-        s[k] = *reinterpret_cast<const float2 *>(row + pos);
-    }
-    __syncthreads();
-    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    // hop = M samples, frame = 2M samples = M float2; positions are even, so a float2 never straddles the ring's wrap
+    const FrameLoad ld = { hist + (long long) i * hist_stride, (h - 1) * (long long) M, hist_mask, live };
+    LdsFFT<LOG2M, TG>::run(ld, LdsIO<float2>{ s }, s, tid, tw);
     if (live)
     {
         int slot = (int) (h % R);
@@ -98,56 +114,54 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(const float *__restric
 //   dst = H spectra of that pair, [P][M] float2.  Partitions past the IR are written as zeros.
 // ------------------------------------------------------------------------------------------------
 
+// (x[2k], x[2k+1]) of a row with `valid` samples (<= 0: none), zero beyond
+struct SampleLoad
+{
+    static constexpr bool is_lds = false;
+    const float *row;
+    long long valid;
+    __device__ __forceinline__ float2 operator()(int k) const
+    {
+        const long long a = 2LL * k;
+        return make_float2(a < valid ? row[a] : 0.f, a + 1 < valid ? row[a + 1] : 0.f);
+    }
+};
+
 template <int LOG2M>
-__global__ __launch_bounds__(256) void rfft_ir_kernel(const float *__restrict__ src, long long count, int P, float2 *__restrict__ dst,
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rfft_ir_kernel(const float *__restrict__ src, long long count, int P, float2 *__restrict__ dst,
                                                       const float2 *__restrict__ tw)
 {
     using Gm = FFTGeom<LOG2M>;
     constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
 
-    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
     const int p = blockIdx.x * G + g;
     const bool live = p < P;
-    float2 *s = lds + g * M;
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
 
-    const long long first = (long long) p * M;           // first sample of this partition
-    for (int k = tid; k < M; k += TG)
-    {
-        // samples 2k, 2k+1 of the zero-padded partition; only the first M samples can be non-zero
-        long long a = first + 2LL * k;
-        float x0 = (live && 2 * k < M && a < count) ? src[a] : 0.f;
-        float x1 = (live && 2 * k + 1 < M && a + 1 < count) ? src[a + 1] : 0.f;
-        s[k] = make_float2(x0, x1);
-    }
-    __syncthreads();
-    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    // samples 2k, 2k+1 of the zero-padded partition; only the first M samples of the 2M can be non-zero
+    const SampleLoad ld = { src + (long long) p * M, live ? std::min<long long>(M, count - (long long) p * M) : 0 };
+    LdsFFT<LOG2M, TG>::run(ld, LdsIO<float2>{ s }, s, tid, tw);
     if (live) real_post_store<LOG2M, TG>(s, tid, tw, dst + (long long) p * M);
 }
 
 // Generic real FFT of `batch` independent rows (plumbing for the hisstools_rfft surface): row b has
 // in_len valid samples at src + b * src_stride, zero padded to 2M; dst row stride M float2.
 template <int LOG2M>
-__global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict__ src, long long src_stride, long long in_len, int batch,
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rfft_rows_kernel(const float *__restrict__ src, long long src_stride, long long in_len, int batch,
                                                         float2 *__restrict__ dst, const float2 *__restrict__ tw)
 {
     using Gm = FFTGeom<LOG2M>;
     constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
 
-    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
     const int b = blockIdx.x * G + g;
     const bool live = b < batch;
-    float2 *s = lds + g * M;
-    const float *row = src + (long long) (live ? b : 0) * src_stride;
-    for (int k = tid; k < M; k += TG)
-    {
-        float x0 = (live && 2LL * k < in_len) ? row[2 * k] : 0.f;
-        float x1 = (live && 2LL * k + 1 < in_len) ? row[2 * k + 1] : 0.f;
-        s[k] = make_float2(x0, x1);
-    }
-    __syncthreads();
-    LdsFFT<LOG2M, TG>::run(s, tid, tw);
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
+    const SampleLoad ld = { src + (long long) (live ? b : 0) * src_stride, live ? std::min<long long>(in_len, 2LL * M) : 0 };
+    LdsFFT<LOG2M, TG>::run(ld, LdsIO<float2>{ s }, s, tid, tw);
     if (live) real_post_store<LOG2M, TG>(s, tid, tw, dst + (long long) b * M);
 }
 
@@ -157,30 +171,68 @@ __global__ __launch_bounds__(256) void rfft_rows_kernel(const float *__restrict_
 // trick of HISSTools_FFT_Core.h:1341-1346).  Unnormalised, as hisstools_rifft.
 // ------------------------------------------------------------------------------------------------
 
-template <int LOG2M, int TG>
-__device__ __forceinline__ void real_pre_inverse(float2 *s, int tid, const float2 *__restrict__ tw)
+// First-pass source of the inverse transforms: element n of the exchanged-re/im complex input, computed on the fly from
+// the packed spectrum held in LDS (pass_real_trig_table<true>, HISSTools_FFT_Core.h:934-988).
+template <int LOG2M>
+struct PreLoad
 {
-    constexpr int M = 1 << LOG2M;
-    // every thread reads its pairs, barrier, then writes (k and M-k are owned by the same thread)
-    for (int k = tid; k <= M / 2; k += TG)
+    static constexpr bool is_lds = true;
+    LdsBuf<float2> s;
+    const float2 *__restrict__ tw;
+    __device__ __forceinline__ float2 operator()(int n) const
     {
-        if (k == 0)
+        constexpr int M = 1 << LOG2M;
+        if (n == 0)
         {
-            float2 z = s[0];
-            s[0] = make_float2(z.x - z.y, z.x + z.y);    // stored swapped (im, re): re = t1 = x+y, im = t2 = x-y
+            const float2 z = s[0];
+            return make_float2(z.x - z.y, z.x + z.y);         // (im, re): re = x + y, im = x - y
         }
-        else
+        const bool lo = n <= M / 2;
+        const int k = lo ? n : M - n, m = M - k;
+        const float2 w = tw[k];
+        const float c = -w.x, sn = w.y;
+        const float2 z1 = s[k], z2 = s[m];
+        const float r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+        const float u1 = (c * i3) + (sn * r4);
+        const float u2 = (sn * i3) - (c * r4);
+        return lo ? make_float2(u2 + i4, r3 + u1) : make_float2(u2 - i4, r3 - u1);
+    }
+};
+
+// Packed spectrum (the sum of `ksplit` partials) of one transform into LDS: every thread first issues all of its loads,
+// then adds and stores — under a saturated HBM a load costs microseconds, so they must not queue behind one another.
+template <int LOG2M, int TG>
+__device__ __forceinline__ void stage_spectrum(LdsBuf<float2> s, int tid, const float2 *__restrict__ src, int ksplit, long long ks_stride, bool live)
+{
+    constexpr int M = 1 << LOG2M, EPT = (M + TG - 1) / TG;
+    float2 v[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+    {
+        const int k = tid + e * TG;
+        v[e] = (live && (M % TG == 0 || k < M)) ? src[k] : make_float2(0.f, 0.f);
+    }
+    for (int ks = 1; ks < ksplit; ks++)
+    {
+        float2 b[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
         {
-            int m = M - k;
-            float2 w = tw[k];
-            float c = -w.x, sn = w.y;
-            float2 z1 = s[k], z2 = s[m];
-            float r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
-            float u1 = (c * i3) + (sn * r4);
-            float u2 = (sn * i3) - (c * r4);
-            s[k] = make_float2(u2 + i4, r3 + u1);         // (im, re)
-            s[m] = make_float2(u2 - i4, r3 - u1);
+            const int k = tid + e * TG;
+            b[e] = (live && (M % TG == 0 || k < M)) ? src[ks * ks_stride + k] : make_float2(0.f, 0.f);
         }
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+        {
+            v[e].x += b[e].x;
+            v[e].y += b[e].y;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+    {
+        const int k = tid + e * TG;
+        if (M % TG == 0 || k < M) s[k] = v[e];
     }
     __syncthreads();
 }
@@ -191,8 +243,29 @@ __device__ __forceinline__ void real_pre_inverse(float2 *s, int tid, const float
 //   Y: [ksplit][T][nout][M] float2 partial sums (summed here)
 // ------------------------------------------------------------------------------------------------
 
+// last-pass sink: result k = (x[2k+1], x[2k]); the second half of the frame is added to the timeline ring
+struct OverlapAddStore
+{
+    static constexpr bool is_lds = false;
+    float *row;
+    long long base, mask;
+    float scale;
+    int first;
+    bool live;
+    __device__ __forceinline__ void operator()(int k, float2 v) const
+    {
+        if (!live || k < first) return;
+        // The timeline has one writer per sample at a time, so the add needs no atomicity — but a plain load / add / store
+        // would chain the eight updates of a thread (the compiler must assume they alias), each a round trip to an HBM
+        // that the tail MAC keeps saturated.  No-return hardware float atomics are fire-and-forget.
+        float *d = row + ((base + 2LL * k) & mask);
+        unsafeAtomicAdd(d, v.y * scale);
+        unsafeAtomicAdd(d + 1, v.x * scale);
+    }
+};
+
 template <int LOG2M>
-__global__ __launch_bounds__(256) void rifft_overlap_add_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, long long h_first,
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_overlap_add_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, long long h_first,
                                                                 int T, int nout, float *__restrict__ timeline, long long tl_stride,
                                                                 long long tl_mask, const float2 *__restrict__ tw)
 {
@@ -200,74 +273,44 @@ __global__ __launch_bounds__(256) void rifft_overlap_add_kernel(const float2 *__
     constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
 
-    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
     const int q = blockIdx.x * G + g;
     const bool live = q < T * nout;
     const int t = live ? q / nout : 0, o = live ? q % nout : 0;
-    float2 *s = lds + g * M;
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
 
-    const float2 *src = Y + ((long long) t * nout + o) * M;
-    for (int k = tid; k < M; k += TG)
-    {
-        float2 a = src[k];
-        for (int ks = 1; ks < ksplit; ks++)
-        {
-            float2 b = src[ks * ks_stride + k];
-            a.x += b.x;
-            a.y += b.y;
-        }
-        s[k] = a;
-    }
-    __syncthreads();
-    real_pre_inverse<LOG2M, TG>(s, tid, tw);
-    LdsFFT<LOG2M, TG>::run(s, tid, tw);
-
-    if (live)
-    {
-        const float scale = 1.f / (float) (8 * M);        // 1 / (4N), N = 2M  (scaleStore, PartitionedConvolve.cpp:232-241)
-        const long long h = h_first + t;
-        float *row = timeline + (long long) o * tl_stride;
-        const long long base = (h + 1) * (long long) M;
-        // valid samples are e in [M, 2M): float2 index k in [M/2, M)
-        for (int k = M / 2 + tid; k < M; k += TG)
-        {
-            float2 v = s[k];                               // (x[2k+1], x[2k])
-            long long pos = (base + 2LL * k - M) & tl_mask;
-            float2 *d = reinterpret_cast<float2 *>(row + pos);
-            float2 cur = *d;
-            cur.x += v.y * scale;
-            cur.y += v.x * scale;
-            *d = cur;
-        }
-    }
+    stage_spectrum<LOG2M, TG>(s, tid, Y + ((long long) t * nout + o) * M, ksplit, ks_stride, live);
+    // valid samples are e in [M, 2M): float2 index k in [M/2, M); scale 1 / (4N), N = 2M  (scaleStore, PartitionedConvolve.cpp:232-241)
+    const OverlapAddStore st = { timeline + (long long) o * tl_stride, (h_first + t + 1) * (long long) M - M, tl_mask, 1.f / (float) (8 * M), M / 2, live };
+    LdsFFT<LOG2M, TG>::run(PreLoad<LOG2M>{ s, tw }, st, s, tid, tw);
 }
+
+struct SwapStore
+{
+    static constexpr bool is_lds = false;
+    float2 *d;
+    bool live;
+    __device__ __forceinline__ void operator()(int k, float2 v) const
+    {
+        if (live) d[k] = make_float2(v.y, v.x);
+    }
+};
 
 // plain inverse for the hisstools_rifft plumbing surface: src rows of M float2 -> dst rows of 2M floats
 template <int LOG2M>
-__global__ __launch_bounds__(256) void rifft_rows_kernel(const float2 *__restrict__ src, int batch, float *__restrict__ dst,
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_rows_kernel(const float2 *__restrict__ src, int batch, float *__restrict__ dst,
                                                          const float2 *__restrict__ tw)
 {
     using Gm = FFTGeom<LOG2M>;
     constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int g = threadIdx.x / TG, tid = threadIdx.x % TG;
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
     const int b = blockIdx.x * G + g;
     const bool live = b < batch;
-    float2 *s = lds + g * M;
-    const float2 *row = src + (long long) (live ? b : 0) * M;
-    for (int k = tid; k < M; k += TG) s[k] = row[k];
-    __syncthreads();
-    real_pre_inverse<LOG2M, TG>(s, tid, tw);
-    LdsFFT<LOG2M, TG>::run(s, tid, tw);
-    if (live)
-    {
-        float2 *d = reinterpret_cast<float2 *>(dst + (long long) b * 2 * M);
-        for (int k = tid; k < M; k += TG)
-        {
-            float2 v = s[k];
-            d[k] = make_float2(v.y, v.x);
-        }
-    }
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
+    stage_spectrum<LOG2M, TG>(s, tid, src + (long long) (live ? b : 0) * M, 1, 0, live);
+    const SwapStore st = { reinterpret_cast<float2 *>(dst + (long long) (live ? b : 0) * 2 * M), live };
+    LdsFFT<LOG2M, TG>::run(PreLoad<LOG2M>{ s, tw }, st, s, tid, tw);
 }
 
 // Split-K epilogue: Y[0][e] = sum_ks Y[ks][e].  One float4 per thread, the ksplit strided loads of a thread are
@@ -525,7 +568,7 @@ __global__ void segment_op_kernel(float *__restrict__ out, const float *__restri
         default: return hipErrorInvalidValue;                                                                          \
     }
 
-template <int L> static inline size_t fft_lds_bytes() { return sizeof(float2) * FFTGeom<L>::M * FFTGeom<L>::G; }
+template <int L> static inline size_t fft_lds_bytes() { return sizeof(float2) * lds_padded(FFTGeom<L>::M) * FFTGeom<L>::G; }
 
 template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
 {

@@ -106,12 +106,15 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="a handful of complex sizes only (kernel tuning)")
     args = ap.parse_args()
     rows = []
     plan = [("fft", "f32", l) for l in (4, 6, 8, 10, 12, 14, 15, 16, 18, 20, 22)]
     plan += [("fft", "f64", l) for l in (4, 6, 8, 10, 12, 13, 14, 16, 18, 20, 22)]
     plan += [("rfft", "f32", l) for l in (8, 12, 15, 16, 20)] + [("rifft", "f32", l) for l in (8, 12, 15, 16, 20)]
     plan += [("rfft_zip", "f32", l) for l in (10, 14)] + [("rifft_zip", "f32", l) for l in (10, 14)] + [("rfft", "f64", l) for l in (12, 14, 18)]
+    if args.quick:
+        plan = [("fft", "f32", l) for l in (6, 8, 10, 12, 13, 14)] + [("fft", "f64", l) for l in (10, 12, 13)] + [("fft", "f32", 16), ("fft", "f32", 20)]
     for op, prec, l2 in plan:
         r = run_case(op, prec, l2, args.gib, args.reps)
         if args.cpu and op in ("fft", "rfft", "rifft") and l2 <= 20:

@@ -52,31 +52,42 @@ namespace
 
     // -------------------------------------------------------------------------------------------- element access
 
-    // element n of the M-point complex input of transform q
+    // the same descriptor with its pointers advanced to transform q (cheap scalar arithmetic when q is wave-uniform)
+    template <class T> __device__ __forceinline__ FxK<T> fx_at(FxK<T> a, long long q)
+    {
+        const long long so = q * a.sstride, dof = q * a.dstride;
+        a.sa = a.src_f32 ? static_cast<const void *>(static_cast<const float *>(a.sa) + so) : static_cast<const void *>(static_cast<const T *>(a.sa) + so);
+        if (a.sb) a.sb += so;
+        a.da += dof;
+        if (a.db) a.db += dof;
+        return a;
+    }
+
+    // element n of the M-point complex input of the transform that starts `off` elements after the descriptor's pointers
+    // (off = transform-within-workgroup * stride: 32-bit lane arithmetic on top of scalar base pointers)
     template <class T, class C>
-    __device__ __forceinline__ C fx_load(const FxK<T> &a, long long q, int n, int M, const C *__restrict__ twN)
+    __device__ __forceinline__ C fx_load(const FxK<T> &a, int off, int n, int M, const C *__restrict__ twN)
     {
         if (a.load == L_SPLIT)
         {
-            const T *re = static_cast<const T *>(a.sa) + q * a.sstride;
-            const T *im = a.sb + q * a.sstride;
-            return C(re[n], im[n]);
+            const T *re = static_cast<const T *>(a.sa), *im = a.sb;
+            return C(re[off + n], im[off + n]);
         }
         if (a.load == L_ZIP)
         {
-            const long long i0 = 2LL * n;
+            const int i0 = 2 * n;
             if (a.src_f32)
             {
-                const float *x = static_cast<const float *>(a.sa) + q * a.sstride;
-                return C(i0 < a.in_len ? (T) x[i0] : (T) 0, i0 + 1 < a.in_len ? (T) x[i0 + 1] : (T) 0);
+                const float *x = static_cast<const float *>(a.sa);
+                return C(i0 < a.in_len ? (T) x[off + i0] : (T) 0, i0 + 1 < a.in_len ? (T) x[off + i0 + 1] : (T) 0);
             }
-            const T *x = static_cast<const T *>(a.sa) + q * a.sstride;
-            return C(i0 < a.in_len ? x[i0] : (T) 0, i0 + 1 < a.in_len ? x[i0 + 1] : (T) 0);
+            const T *x = static_cast<const T *>(a.sa);
+            return C(i0 < a.in_len ? x[off + i0] : (T) 0, i0 + 1 < a.in_len ? x[off + i0 + 1] : (T) 0);
         }
         // L_PRE: pass_real_trig_table<true> (Core.h:934-988), delivered with re/im exchanged so that the forward
         // transform that follows acts as the inverse (Core.h:1341-1346)
-        const T *re = static_cast<const T *>(a.sa) + q * a.sstride;
-        const T *im = a.sb + q * a.sstride;
+        const T *re = static_cast<const T *>(a.sa) + off;
+        const T *im = a.sb + off;
         if (n == 0)
         {
             const T r = re[0], i = im[0];
@@ -94,27 +105,26 @@ namespace
     }
 
     template <class T, class C>
-    __device__ __forceinline__ void fx_store(const FxK<T> &a, long long q, int k, C v)
+    __device__ __forceinline__ void fx_store(const FxK<T> &a, int off, int k, C v)
     {
         if (a.swap_out) v = C(v.y, v.x);
         if (a.store == S_SPLIT)
         {
-            a.da[q * a.dstride + k] = v.x;
-            a.db[q * a.dstride + k] = v.y;
+            a.da[off + k] = v.x;
+            a.db[off + k] = v.y;
         }
         else
         {
-            T *o = a.da + q * a.dstride + 2LL * k;
-            o[0] = v.x;
-            o[1] = v.y;
+            a.da[off + 2 * k] = v.x;
+            a.da[off + 2 * k + 1] = v.y;
         }
     }
 
     // pass_real_trig_table<false> for the bin pair (k, M-k), k in [0, M/2]
     template <class T, class C>
-    __device__ __forceinline__ void fx_post(const FxK<T> &a, long long q, int k, int M, C z1, C z2, const C *__restrict__ twN)
+    __device__ __forceinline__ void fx_post(const FxK<T> &a, int off, int k, int M, C z1, C z2, const C *__restrict__ twN)
     {
-        T *re = a.da + q * a.dstride, *im = a.db + q * a.dstride;
+        T *re = a.da + off, *im = a.db + off;
         if (k == 0)
         {
             const T t1 = z1.x + z1.y, t2 = z1.x - z1.y;
@@ -139,10 +149,10 @@ namespace
         typedef typename Cx<T>::type C;
         static constexpr bool is_lds = false;
         const FxK<T> &a;
-        long long q;
+        int off;
         const C *__restrict__ tw;
         bool live;
-        __device__ __forceinline__ C operator()(int n) const { return live ? fx_load<T, C>(a, q, n, M, tw) : C(0, 0); }
+        __device__ __forceinline__ C operator()(int n) const { return live ? fx_load<T, C>(a, off, n, M, tw) : C(0, 0); }
     };
 
     template <class T> struct FxStore
@@ -150,11 +160,11 @@ namespace
         typedef typename Cx<T>::type C;
         static constexpr bool is_lds = false;
         const FxK<T> &a;
-        long long q;
+        int off;
         bool live;
         __device__ __forceinline__ void operator()(int k, C v) const
         {
-            if (live) fx_store<T, C>(a, q, k, v);
+            if (live) fx_store<T, C>(a, off, k, v);
         }
     };
 
@@ -165,7 +175,7 @@ namespace
 
     // second launch bound = waves per SIMD the register budget must allow (HIP semantics): 4 -> 128 VGPRs in float
     template <class T, int LOG2M>
-    __global__ __launch_bounds__((FFTGeom<LOG2M, fx_wg<T, LOG2M>()>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a, const typename Cx<T>::type *__restrict__ tw)
+    __global__ __launch_bounds__((FFTGeom<LOG2M, fx_wg<T, LOG2M>()>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a0, const typename Cx<T>::type *__restrict__ tw)
     {
         typedef typename Cx<T>::type C;
         typedef FFTGeom<LOG2M, fx_wg<T, LOG2M>()> Gm;
@@ -175,12 +185,17 @@ namespace
 
         // groups of whole waves are wave-uniform: keeps the per-transform pointers scalar and the lane addresses 32-bit
         const int g = (TG % 64 == 0) ? __builtin_amdgcn_readfirstlane((int) (threadIdx.x / TG)) : (int) (threadIdx.x / TG), t = threadIdx.x % TG;
-        const long long q = (long long) blockIdx.x * G + g;
-        const bool live = q < a.batch;
+        const long long q0 = (long long) blockIdx.x * G;
+        const bool live = q0 + g < a0.batch;
+        // scalar pointers: to this thread group's transform when the group is wave-uniform, else to the workgroup's first
+        // transform with 32-bit lane offsets on top
+        constexpr bool UNI = TG % 64 == 0;
+        const FxK<T> a = fx_at(a0, UNI ? q0 + g : q0);
+        const int soff = UNI ? 0 : g * (int) a.sstride, doff = UNI ? 0 : g * (int) a.dstride;
         const LdsBuf<C> s = { lds + g * lds_padded(M) };
-        const FxLoad<T, M> ld = { a, q, tw, live };
+        const FxLoad<T, M> ld = { a, soff, tw, live };
 #ifdef FX_SKIP_FFT
-        for (int n = t; n < M; n += TG) if (live) fx_store<T, C>(a, q, n, ld(n));
+        for (int n = t; n < M; n += TG) if (live) fx_store<T, C>(a, doff, n, ld(n));
         return;
 #endif
         if (a.store == S_POST)
@@ -188,10 +203,10 @@ namespace
             // the real post pass pairs bin k with bin M-k: finish in LDS, then combine
             LdsFFT<LOG2M, TG, C>::run(ld, LdsIO<C>{ s }, s, t, tw);
             if (live)
-                for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, q, k, M, s[k], s[(M - k) & (M - 1)], tw);
+                for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, doff, k, M, s[k], s[(M - k) & (M - 1)], tw);
         }
         else
-            LdsFFT<LOG2M, TG, C>::run(ld, FxStore<T>{ a, q, live }, s, t, tw);
+            LdsFFT<LOG2M, TG, C>::run(ld, FxStore<T>{ a, doff, live }, s, t, tw);
     }
 
     // -------------------------------------------------------------------------------------------- tiny transforms (M <= 2)
@@ -206,12 +221,12 @@ namespace
         const int M = kind == 0 ? (1 << log2n) : ((1 << log2n) >> 1);
         if (M == 0) return;
         // the pre pass does not apply at these sizes: read the packed spectrum as plain split data
-        FxK<T> ld = a;
+        FxK<T> ld = fx_at(a, q);
         if (ld.load == L_PRE) ld.load = L_SPLIT;
         T re[2], im[2];
         for (int n = 0; n < M; n++)
         {
-            const C v = fx_load<T, C>(ld, q, n, M, nullptr);
+            const C v = fx_load<T, C>(ld, 0, n, M, nullptr);
             re[n] = v.x;
             im[n] = v.y;
         }
@@ -251,24 +266,27 @@ namespace
                 re[0] = r1 + r2; re[1] = r1 - r2; im[0] = r3 - r4; im[1] = r3 + r4;
             }
         }
-        FxK<T> sv = a;
+        FxK<T> sv = fx_at(a, q);
         sv.swap_out = 0;                                            // the explicit formulas above already give (re, im)
         if (sv.store == S_POST) sv.store = S_SPLIT;
-        for (int k = 0; k < M; k++) fx_store<T, C>(sv, q, k, C(re[k], im[k]));
+        for (int k = 0; k < M; k++) fx_store<T, C>(sv, 0, k, C(re[k], im[k]));
     }
 
     // -------------------------------------------------------------------------------------------- four-step passes
 
-    // threads per sub-transform and sub-transforms per 256-thread workgroup
-    __host__ __device__ constexpr int fx_tg(int points) { return points / 16 < 256 ? points / 16 : 256; }
-
-    // adjacent columns / rows per workgroup: `want` for coalescing, at most 128 KiB of LDS, at least one per thread group
-    __host__ __device__ constexpr int fx_tile(int points, int elem_bytes, int want)
+    // Tile of one four-step workgroup: TILE adjacent columns (or rows) of P points each, all transformed at once by
+    // TILE * TG threads (at most 1024).  TILE aims at 128-byte runs in each of the split arrays, within 128 KiB of LDS
+    // (136 KiB with the bank padding).
+    template <int P, int ELEM_BYTES> struct FxTile
     {
-        const int cap = 128 * 1024 / (points * elem_bytes)   /* + 1/16 padding: 136 KiB of the 160 KiB */, groups = 256 / fx_tg(points);
-        const int t = cap < want ? cap : want;
-        return t < groups ? groups : t;
-    }
+        static constexpr int TG = P / 16 < 256 ? P / 16 : 256;
+        static constexpr int WANT = 256 / ELEM_BYTES;                       // complex elements: 128 bytes per split array
+        static constexpr int CAP = 128 * 1024 / (P * ELEM_BYTES);
+        static constexpr int TILE = CAP < WANT ? CAP : WANT;
+        static constexpr int THREADS = TILE * TG < 1024 ? TILE * TG : 1024;
+        static constexpr int G = THREADS / TG;                              // sub-transforms in flight
+        static_assert(TILE % G == 0 && THREADS % 64 == 0, "tile geometry");
+    };
 
     template <class C>
     __device__ __forceinline__ C fx_root_rt(const C *__restrict__ tw, int idx, int M)
@@ -279,30 +297,28 @@ namespace
 
     // M = M1 * M2, n = M2*n1 + n2, k = k1 + M1*k2.   cols: for every n2 an M1-point transform over n1, times W_M^(n2 k1)
     template <class T, int L1>
-    __global__ __launch_bounds__(256) void fx_cols_kernel(FxK<T> a, typename Cx<T>::type *__restrict__ work, int M2, int M, long long q0,
+    __global__ __launch_bounds__((FxTile<(1 << L1), (int) sizeof(typename Cx<T>::type)>::THREADS)) void fx_cols_kernel(FxK<T> a0, typename Cx<T>::type *__restrict__ work, int M2, int M, long long q0,
                                                           const typename Cx<T>::type *__restrict__ tw1, const typename Cx<T>::type *__restrict__ twN)
     {
         typedef typename Cx<T>::type C;
         constexpr int M1 = 1 << L1;
-        constexpr int TG = fx_tg(M1);
-        constexpr int G = 256 / TG;
-        constexpr int COLS = fx_tile(M1, (int) sizeof(C), 128 / (int) sizeof(C));
-        static_assert(G <= COLS, "one thread group per column");
+        typedef FxTile<M1, (int) sizeof(C)> Tile;
+        constexpr int TG = Tile::TG, G = Tile::G, COLS = Tile::TILE, NT = Tile::THREADS;
         extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
         C *lds = reinterpret_cast<C *>(fx_raw);                                // [COLS][M1]
 
         const int col0 = blockIdx.x * COLS;
-        const long long q = q0 + blockIdx.y;
-        for (int e = threadIdx.x; e < COLS * M1; e += 256)
+        const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
+        for (int e = threadIdx.x; e < COLS * M1; e += NT)
         {
             const int c = e % COLS, n1 = e / COLS;
-            LdsBuf<C>{ lds + c * lds_padded(M1) }[n1] = fx_load<T, C>(a, q, n1 * M2 + col0 + c, M, twN);
+            LdsBuf<C>{ lds + c * lds_padded(M1) }[n1] = fx_load<T, C>(a, 0, n1 * M2 + col0 + c, M, twN);
         }
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
         for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(LdsBuf<C>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
         C *out = work + (long long) blockIdx.y * M;
-        for (int e = threadIdx.x; e < COLS * M1; e += 256)
+        for (int e = threadIdx.x; e < COLS * M1; e += NT)
         {
             const int c = e % COLS, k1 = e / COLS;
             const int n2 = col0 + c;
@@ -312,32 +328,30 @@ namespace
 
     // rows: for every k1 an M2-point transform over n2; element k2 of row k1 is bin k1 + M1*k2
     template <class T, int L2>
-    __global__ __launch_bounds__(256) void fx_rows_kernel(const typename Cx<T>::type *__restrict__ work, FxK<T> a, typename Cx<T>::type *__restrict__ post,
+    __global__ __launch_bounds__((FxTile<(1 << L2), (int) sizeof(typename Cx<T>::type)>::THREADS)) void fx_rows_kernel(const typename Cx<T>::type *__restrict__ work, FxK<T> a0, typename Cx<T>::type *__restrict__ post,
                                                           int M1, int M, long long q0, const typename Cx<T>::type *__restrict__ tw2)
     {
         typedef typename Cx<T>::type C;
         constexpr int M2 = 1 << L2;
-        constexpr int TG = fx_tg(M2);
-        constexpr int G = 256 / TG;
-        constexpr int ROWS = fx_tile(M2, (int) sizeof(C), 8);
-        static_assert(G <= ROWS, "one thread group per row");
+        typedef FxTile<M2, (int) sizeof(C)> Tile;
+        constexpr int TG = Tile::TG, G = Tile::G, ROWS = Tile::TILE, NT = Tile::THREADS;
         extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
         C *lds = reinterpret_cast<C *>(fx_raw);                                // [ROWS][M2]
 
         const int row0 = blockIdx.x * ROWS;
         const C *in = work + (long long) blockIdx.y * M + (long long) row0 * M2;
-        for (int e = threadIdx.x; e < ROWS * M2; e += 256) LdsBuf<C>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = in[e];
+        for (int e = threadIdx.x; e < ROWS * M2; e += NT) LdsBuf<C>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = in[e];
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
         for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(LdsBuf<C>{ lds + (r0 + g) * lds_padded(M2) }, t, tw2);
-        const long long q = q0 + blockIdx.y;
-        for (int e = threadIdx.x; e < ROWS * M2; e += 256)
+        const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
+        for (int e = threadIdx.x; e < ROWS * M2; e += NT)
         {
             const int r = e % ROWS, k2 = e / ROWS;
             const int k = row0 + r + M1 * k2;
             const C v = LdsBuf<C>{ lds + r * lds_padded(M2) }[k2];
-            if (a.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
-            else fx_store<T, C>(a, q, k, v);
+            if (a0.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
+            else fx_store<T, C>(a, 0, k, v);
         }
     }
 
@@ -348,7 +362,7 @@ namespace
         const int k = blockIdx.x * blockDim.x + threadIdx.x;
         if (k > M / 2) return;
         const C *z = Z + (long long) blockIdx.y * M;
-        fx_post<T, C>(a, q0 + blockIdx.y, k, M, z[k], z[(M - k) & (M - 1)], twN);
+        fx_post<T, C>(fx_at(a, q0 + blockIdx.y), 0, k, M, z[k], z[(M - k) & (M - 1)], twN);
     }
 
     // -------------------------------------------------------------------------------------------- zip / unzip
@@ -465,6 +479,23 @@ namespace
         const size_t lds = sizeof(C) * lds_padded(Gm::M) * Gm::G;
         hipError_t e = allow_big_lds(fx_lds_kernel<T, L>, lds);
         if (e != hipSuccess) return e;
+        // lane addressing is 32-bit relative to the workgroup's first transform: absurd strides go one transform per launch
+        const long long reach = (long long) (Gm::G - 1) * std::max(k.sstride, k.dstride) + 4LL * Gm::M;
+        if (Gm::G > 1 && reach >= (1LL << 31))
+        {
+            for (long long q = 0; q < k.batch; q++)
+            {
+                FxK<T> one = k;
+                const long long so = q * k.sstride, dof = q * k.dstride;
+                one.sa = k.src_f32 ? static_cast<const void *>(static_cast<const float *>(k.sa) + so) : static_cast<const void *>(static_cast<const T *>(k.sa) + so);
+                if (one.sb) one.sb += so;
+                one.da += dof;
+                if (one.db) one.db += dof;
+                one.batch = 1;
+                hipLaunchKernelGGL((fx_lds_kernel<T, L>), dim3(1), dim3(Gm::THREADS), lds, st, one, tw);
+            }
+            return hipGetLastError();
+        }
         const long long grid = (k.batch + Gm::G - 1) / Gm::G;
         hipLaunchKernelGGL((fx_lds_kernel<T, L>), dim3((unsigned) grid), dim3(Gm::THREADS), lds, st, k, tw);
         return hipGetLastError();
@@ -488,11 +519,11 @@ namespace
                                                       const typename Cx<T>::type *tw1, const typename Cx<T>::type *twN, hipStream_t st)
     {
         typedef typename Cx<T>::type C;
-        constexpr int COLS = fx_tile(1 << L1, (int) sizeof(C), 128 / (int) sizeof(C));
-        const size_t lds = sizeof(C) * COLS * (size_t) lds_padded(1 << L1);
+        typedef FxTile<(1 << L1), (int) sizeof(C)> Tile;
+        const size_t lds = sizeof(C) * Tile::TILE * (size_t) lds_padded(1 << L1);
         hipError_t e = allow_big_lds(fx_cols_kernel<T, L1>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / COLS, nb), dim3(256), lds, st, k, work, M2, M, q0, tw1, twN);
+        hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / Tile::TILE, nb), dim3(Tile::THREADS), lds, st, k, work, M2, M, q0, tw1, twN);
         return hipGetLastError();
     }
 
@@ -500,11 +531,11 @@ namespace
                                                       long long q0, int nb, const typename Cx<T>::type *tw2, hipStream_t st)
     {
         typedef typename Cx<T>::type C;
-        constexpr int ROWS = fx_tile(1 << L2, (int) sizeof(C), 8);
-        const size_t lds = sizeof(C) * ROWS * (size_t) lds_padded(1 << L2);
+        typedef FxTile<(1 << L2), (int) sizeof(C)> Tile;
+        const size_t lds = sizeof(C) * Tile::TILE * (size_t) lds_padded(1 << L2);
         hipError_t e = allow_big_lds(fx_rows_kernel<T, L2>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fx_rows_kernel<T, L2>), dim3(M1 / ROWS, nb), dim3(256), lds, st, work, k, post, M1, M, q0, tw2);
+        hipLaunchKernelGGL((fx_rows_kernel<T, L2>), dim3(M1 / Tile::TILE, nb), dim3(Tile::THREADS), lds, st, work, k, post, M1, M, q0, tw2);
         return hipGetLastError();
     }
 

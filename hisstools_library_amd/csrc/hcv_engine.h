@@ -151,6 +151,7 @@ namespace hcv
         std::vector<uint8_t> mPending, mLoaded;
         long long mN = 0;                   // samples since the last global reset
         bool mProfiling = false;
+        bool mOneStream = false;            // every kernel on mStream (small engines: dependency hops cost more than overlap gains)
         std::vector<EventPair *> mEvents;
     };
 

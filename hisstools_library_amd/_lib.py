@@ -33,6 +33,12 @@ class FFTCall(C.Structure):          # hcv_fft_call
                 ("src_stride", usz), ("dst_stride", usz), ("in_length", usz)]
 
 
+class IRCall(C.Structure):           # hcv_ir_call
+    _fields_ = [("op", C.c_int), ("precision", C.c_int), ("log2n", C.c_uint), ("batch", usz),
+                ("src_re", vp), ("src_im", vp), ("dst_re", vp), ("dst_im", vp),
+                ("src_stride", usz), ("dst_stride", usz), ("value", C.c_double), ("zero_center", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/hisstools_amd.h declares
 SIGNATURES = {
     "hcv_version": (C.c_char_p, []),
@@ -100,6 +106,11 @@ SIGNATURES = {
     "hcv_spectral_correlate_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
     "hcv_fft_exec": (C.c_int, [C.POINTER(FFTCall)]),
     "hcv_fft_exec_dev": (C.c_int, [C.POINTER(FFTCall), vp, C.c_int]),
+    "hcv_ir_exec": (C.c_int, [C.POINTER(IRCall)]),
+    "hcv_ir_exec_dev": (C.c_int, [C.POINTER(IRCall), vp, C.c_int]),
+    "hcv_spectral_phase_size": (usz, [usz, C.c_double]),
+    "hcv_spectral_change_phase_f32": (C.c_int, [f32p, usz, C.c_double, C.c_double, f32p]),
+    "hcv_spectral_change_phase_f64": (C.c_int, [f64p, usz, C.c_double, C.c_double, f64p]),
 }
 
 _lib = None

@@ -144,6 +144,23 @@ class spectral_processor:
     def correlate(self, in1, in2, mode=EdgeMode.Linear):
         return self._run(self.L.hcv_spectral_correlate_f32, in1, in2, mode, "spectral_processor.correlate")
 
+    def change_phase(self, x, phase: float, time_multiplier: float = 1.0):
+        """spectral_processor<T>::change_phase (SpectralProcessor.hpp:188-208); float32 or float64 by the input's dtype.
+        Returns the fft_size output samples (fft_size = the power of two covering round(size * time_multiplier))."""
+        x = np.ascontiguousarray(x)
+        if x.dtype != np.float64:
+            x = x.astype(np.float32, copy=False)
+        n = self.L.hcv_spectral_phase_size(x.size, float(time_multiplier))
+        if not n:
+            raise ValueError("spectral_processor.change_phase: size out of range")
+        out = np.zeros(n, x.dtype)
+        if x.dtype == np.float32:
+            rc = self.L.hcv_spectral_change_phase_f32(_fp(x), x.size, float(phase), float(time_multiplier), _fp(out))
+        else:
+            rc = self.L.hcv_spectral_change_phase_f64(x.ctypes.data_as(f64p), x.size, float(phase), float(time_multiplier), out.ctypes.data_as(f64p))
+        _check(rc, "spectral_processor.change_phase")
+        return out
+
 
 # ------------------------------------------------------------------------------------------- classes
 

@@ -7,6 +7,7 @@
 #include "../../include/hisstools_amd.h"
 #include "hcv_engine.h"
 #include "hcv_fftx.h"
+#include "hcv_irx.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1271,4 +1272,190 @@ extern "C" int hcv_fft_exec(const hcv_fft_call *call)
     if (d[0]) (void) hipFree(d[0]);
     if (d[1]) (void) hipFree(d[1]);
     return ok ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------ spectral IR functions (next row 4)
+//
+// SpectralFunctions.hpp:365-413 on batches of packed half spectra; kernels in hcv_irx.hip.  The host variants only move bytes.
+
+namespace
+{
+    hcv::IrCall to_ir(const hcv_ir_call &c)
+    {
+        hcv::IrCall r;
+        r.op = c.op; r.precision = c.precision; r.log2n = c.log2n; r.batch = c.batch;
+        r.src_re = c.src_re; r.src_im = c.src_im; r.dst_re = c.dst_re; r.dst_im = c.dst_im;
+        r.src_stride = c.src_stride; r.dst_stride = c.dst_stride; r.value = c.value; r.zero_center = c.zero_center;
+        return r;
+    }
+
+    // device buffer helper for the host-pointer entries
+    struct DevBuf
+    {
+        void *p = nullptr;
+        ~DevBuf() { if (p) (void) hipFree(p); }
+        bool alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(16, bytes)) == hipSuccess; }
+    };
+}
+
+extern "C" int hcv_ir_exec_dev(const hcv_ir_call *call, void *stream, int sync)
+{
+    if (!call)
+    {
+        set_error("hcv_ir_exec_dev: null descriptor");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    std::string err;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hcv::irx_exec(dev, to_ir(*call), st, &err);
+    if (e == hipSuccess && sync) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+    {
+        set_error(err.empty() ? std::string("hcv_ir_exec_dev: ") + hipGetErrorString(e) : err);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int hcv_ir_exec(const hcv_ir_call *call)
+{
+    if (!call)
+    {
+        set_error("hcv_ir_exec: null descriptor");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    hcv::IrCall c = to_ir(*call);
+    std::string err;
+    if (!hcv::irx_valid(c, &err))
+    {
+        set_error(err);
+        return -1;
+    }
+    if (!c.batch) return 0;
+    const size_t half = (size_t(1) << c.log2n) >> 1, elem = c.precision == hcv::FX_F32 ? 4 : 8;
+    if (!c.src_stride) c.src_stride = half;
+    if (!c.dst_stride) c.dst_stride = half;
+    const size_t src_extent = (c.batch - 1) * c.src_stride + half, dst_extent = (c.batch - 1) * c.dst_stride + half;
+    const bool has_src = c.op != hcv::IR_SPIKE;
+    const bool in_place = has_src && call->src_re == call->dst_re && call->src_im == call->dst_im && c.src_stride == c.dst_stride;
+    DevBuf sr, si, dr, di;
+    bool ok = true;
+    if (has_src)
+    {
+        ok = sr.alloc(src_extent * elem) && si.alloc(src_extent * elem);
+        if (ok) HCV_API_TRY(hipMemcpy(sr.p, call->src_re, src_extent * elem, hipMemcpyHostToDevice));
+        if (ok) HCV_API_TRY(hipMemcpy(si.p, call->src_im, src_extent * elem, hipMemcpyHostToDevice));
+    }
+    if (ok && !in_place)
+    {
+        ok = dr.alloc(dst_extent * elem) && di.alloc(dst_extent * elem);
+        const bool gaps = c.dst_stride != half && c.batch > 1;
+        if (ok && gaps) HCV_API_TRY(hipMemcpy(dr.p, call->dst_re, dst_extent * elem, hipMemcpyHostToDevice));
+        if (ok && gaps) HCV_API_TRY(hipMemcpy(di.p, call->dst_im, dst_extent * elem, hipMemcpyHostToDevice));
+    }
+    if (!ok)
+    {
+        if (tlsError.empty()) set_error("hcv_ir_exec: device allocation failed");
+        return -1;
+    }
+    c.src_re = sr.p; c.src_im = si.p;
+    c.dst_re = in_place ? sr.p : dr.p;
+    c.dst_im = in_place ? si.p : di.p;
+    hipError_t e = hcv::irx_exec(dev, c, nullptr, &err);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess)
+    {
+        set_error(err.empty() ? std::string("hcv_ir_exec: ") + hipGetErrorString(e) : err);
+        return -1;
+    }
+    HCV_API_TRY(hipMemcpy(call->dst_re, c.dst_re, dst_extent * elem, hipMemcpyDeviceToHost));
+    if (ok) HCV_API_TRY(hipMemcpy(call->dst_im, c.dst_im, dst_extent * elem, hipMemcpyDeviceToHost));
+    return ok ? 0 : -1;
+}
+
+// spectral_processor::calc_fft_size_log2 (SpectralProcessor.hpp:231-242) of round(size * time_multiplier)
+static unsigned phase_fft_log2(size_t size, double time_multiplier)
+{
+    const size_t want = (size_t) std::llround((double) size * time_multiplier);
+    unsigned count = 0;
+    while (count < 63 && (want >> count)) count++;
+    if (count && want == (size_t(1) << (count - 1))) return count - 1;
+    return count;
+}
+
+extern "C" size_t hcv_spectral_phase_size(size_t size, double time_multiplier)
+{
+    if (size == 1) return 1;
+    const unsigned l2 = phase_fft_log2(size, time_multiplier);
+    return l2 > (unsigned) hcv::kFxMaxComplexLog2 + 1 ? 0 : size_t(1) << l2;
+}
+
+template <class T> static int change_phase(const T *in, size_t size, double phase, double time_multiplier, T *out)
+{
+    if (!in || !out || !size)
+    {
+        set_error("hcv_spectral_change_phase: null or empty input");
+        return -1;
+    }
+    if (size == 1)                                             // SpectralProcessor.hpp:195-199
+    {
+        out[0] = in[0];
+        return 0;
+    }
+    const unsigned log2n = phase_fft_log2(size, time_multiplier);
+    if (log2n < 3 || log2n > (unsigned) hcv::kFxMaxComplexLog2 + 1)
+    {
+        set_error("hcv_spectral_change_phase: fft size out of range (8 .. 2^23)");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    const size_t n = size_t(1) << log2n, half = n >> 1, take = std::min(size, n);
+    const int prec = sizeof(T) == 4 ? hcv::FX_F32 : hcv::FX_F64;
+    DevBuf x, re, im, y;
+    bool ok = x.alloc(sizeof(T) * n) && re.alloc(sizeof(T) * half) && im.alloc(sizeof(T) * half) && y.alloc(sizeof(T) * n);
+    if (!ok)
+    {
+        set_error("hcv_spectral_change_phase: device allocation failed");
+        return -1;
+    }
+    HCV_API_TRY(hipMemcpy(x.p, in, sizeof(T) * take, hipMemcpyHostToDevice));
+    std::string err;
+    hipError_t e = hipSuccess;
+    if (ok)
+    {
+        hcv::FxCall f;
+        f.precision = prec; f.log2n = log2n; f.batch = 1;
+        f.op = hcv::FX_RFFT_ZIP; f.src_a = x.p; f.dst_a = re.p; f.dst_b = im.p; f.in_length = take; f.src_stride = n; f.dst_stride = half;
+        e = hcv::fftx_exec(dev, f, nullptr, &err);
+        hcv::IrCall c;
+        c.op = hcv::IR_PHASE; c.precision = prec; c.log2n = log2n; c.batch = 1; c.value = phase; c.zero_center = 0;
+        c.src_re = c.dst_re = re.p; c.src_im = c.dst_im = im.p;
+        if (e == hipSuccess) e = hcv::irx_exec(dev, c, nullptr, &err);
+        f.op = hcv::FX_RIFFT_ZIP; f.src_a = re.p; f.src_b = im.p; f.dst_a = y.p; f.dst_b = nullptr; f.src_stride = half; f.dst_stride = n;
+        if (e == hipSuccess) e = hcv::fftx_exec(dev, f, nullptr, &err);
+        if (e == hipSuccess) e = hcv::launch_scale(static_cast<T *>(y.p), (long long) n, (T) 0.5 / (T) n, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess)
+        {
+            set_error(err.empty() ? std::string("hcv_spectral_change_phase: ") + hipGetErrorString(e) : err);
+            return -1;
+        }
+    }
+    if (ok) HCV_API_TRY(hipMemcpy(out, y.p, sizeof(T) * n, hipMemcpyDeviceToHost));
+    return ok ? 0 : -1;
+}
+
+extern "C" int hcv_spectral_change_phase_f32(const float *in, size_t size, double phase, double time_multiplier, float *out)
+{
+    return change_phase<float>(in, size, phase, time_multiplier, out);
+}
+
+extern "C" int hcv_spectral_change_phase_f64(const double *in, size_t size, double phase, double time_multiplier, double *out)
+{
+    return change_phase<double>(in, size, phase, time_multiplier, out);
 }

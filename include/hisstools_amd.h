@@ -213,6 +213,40 @@ typedef struct hcv_fft_call
 HCV_API int hcv_fft_exec(const hcv_fft_call *call);
 HCV_API int hcv_fft_exec_dev(const hcv_fft_call *call, void *stream, int sync);
 
+/* ---------------------------------------------------------------- spectral IR functions (fourth "next" row)
+ * IR pre-processing in the spectral domain on batches of packed half spectra (fft_size = 2^log2n real samples,
+ * fft_size / 2 values per array, bin 0 = (DC, Nyquist)) — SpectralFunctions.hpp:365-413:
+ *
+ *   HCV_IR_COPY          ir_copy          :365-369
+ *   HCV_IR_SPIKE         ir_spike         :371-375   value = spike position in samples (src unused)
+ *   HCV_IR_DELAY         ir_delay         :377-384   value = delay in samples (fractional allowed; circular)
+ *   HCV_IR_TIME_REVERSE  ir_time_reverse  :386-390
+ *   HCV_IR_PHASE         ir_phase         :392-413   value = phase, 0 minimum .. 0.5 linear .. 1 maximum; zero_center as the reference
+ *
+ * precision: HCV_FFT_F32 or HCV_FFT_F64.  src may equal dst.  Strides in elements, 0 = dense.  hcv_ir_exec takes host
+ * pointers, hcv_ir_exec_dev device pointers + a hipStream_t.  Returns 0 ok, -1 failure (hcv_last_error).
+ *
+ * hcv_spectral_change_phase_* = spectral_processor<T>::change_phase (SpectralProcessor.hpp:188-208): real FFT of `size`
+ * samples at the size hcv_spectral_phase_size(size, time_multiplier) returns, ir_phase, inverse FFT, scale 0.5 / fft_size;
+ * `out` receives that many samples (1 for a single-sample input, which is copied). */
+enum { HCV_IR_COPY = 0, HCV_IR_SPIKE = 1, HCV_IR_DELAY = 2, HCV_IR_TIME_REVERSE = 3, HCV_IR_PHASE = 4 };
+typedef struct hcv_ir_call
+{
+    int op, precision;
+    unsigned log2n;
+    size_t batch;
+    const void *src_re, *src_im;
+    void *dst_re, *dst_im;
+    size_t src_stride, dst_stride;
+    double value;
+    int zero_center;
+} hcv_ir_call;
+HCV_API int hcv_ir_exec(const hcv_ir_call *call);
+HCV_API int hcv_ir_exec_dev(const hcv_ir_call *call, void *stream, int sync);
+HCV_API size_t hcv_spectral_phase_size(size_t size, double time_multiplier);
+HCV_API int hcv_spectral_change_phase_f32(const float *in, size_t size, double phase, double time_multiplier, float *out);
+HCV_API int hcv_spectral_change_phase_f64(const double *in, size_t size, double phase, double time_multiplier, double *out);
+
 #ifdef __cplusplus
 }
 #endif

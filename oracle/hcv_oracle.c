@@ -5,6 +5,7 @@
  * product path.
  */
 #define _POSIX_C_SOURCE 200809L
+#define _DEFAULT_SOURCE          /* M_PI */
 #include "hcv_oracle.h"
 
 #include <math.h>
@@ -14,15 +15,19 @@
 
 #define REAL float
 #define FN(x) x##_f32
+#define RM(x) x##f                 /* libm function of REAL's precision */
 #include "hcv_oracle_body.inc"
 #undef REAL
 #undef FN
+#undef RM
 
 #define REAL double
 #define FN(x) x##_f64
+#define RM(x) x
 #include "hcv_oracle_body.inc"
 #undef REAL
 #undef FN
+#undef RM
 
 /* ------------------------------------------------------------------------------------------------
  * float samples -> double split (HISSTools_FFT.h:208,321; the converting unzip_complex, Core.h:1199-1210)

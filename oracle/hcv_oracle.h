@@ -58,6 +58,21 @@ void hcvo_zip_f32(const float *re, const float *im, float *out, unsigned log2n);
 void hcvo_zip_f64(const double *re, const double *im, double *out, unsigned log2n);
 void hcvo_rfft_f32_f64(const float *in, size_t in_len, unsigned log2n, double *realp, double *imagp);
 
+/* Spectral IR functions (SpectralFunctions.hpp:284-410) on packed half spectra of fft_size real samples, and
+ * spectral_processor::change_phase (SpectralProcessor.hpp:188-208).  _f64 variants take double. */
+void hcvo_ir_copy_f32(float *ro, float *io, const float *ri, const float *ii, size_t fft_size);
+void hcvo_ir_time_reverse_f32(float *ro, float *io, const float *ri, const float *ii, size_t fft_size);
+void hcvo_ir_spike_f32(float *ro, float *io, size_t fft_size, double position);
+void hcvo_ir_delay_f32(float *ro, float *io, const float *ri, const float *ii, size_t fft_size, double delay);
+void hcvo_ir_phase_f32(float *ro, float *io, const float *ri, const float *ii, size_t fft_size, double phase, int zero_center);
+size_t hcvo_change_phase_f32(const float *in, size_t size, double phase, double time_multiplier, float *out);
+void hcvo_ir_copy_f64(double *ro, double *io, const double *ri, const double *ii, size_t fft_size);
+void hcvo_ir_time_reverse_f64(double *ro, double *io, const double *ri, const double *ii, size_t fft_size);
+void hcvo_ir_spike_f64(double *ro, double *io, size_t fft_size, double position);
+void hcvo_ir_delay_f64(double *ro, double *io, const double *ri, const double *ii, size_t fft_size, double delay);
+void hcvo_ir_phase_f64(double *ro, double *io, const double *ri, const double *ii, size_t fft_size, double phase, int zero_center);
+size_t hcvo_change_phase_f64(const double *in, size_t size, double phase, double time_multiplier, double *out);
+
 /* The class-level API is declared opaque; tests bind it through ctypes (oracle/oracle.py).
  * f32 entry points: hcvo_part_*, hcvo_td_*, hcvo_mono_*, hcvo_n2m_*, hcvo_conv_* (suffix _f32);
  * f64 ground-truth variants exist for part/td/mono (suffix _f64). */

@@ -604,3 +604,81 @@ def spectral_convolve(in1, in2, mode, backend="port", correlate=False):
 
 def spectral_correlate(in1, in2, mode, backend="port"):
     return spectral_convolve(in1, in2, mode, backend, correlate=True)
+
+
+# --------------------------------------------------------------------------------------- spectral IR functions (fourth "next" row)
+
+IR_OPS = ("copy", "spike", "delay", "time_reverse", "phase")
+_ir = {}
+
+
+def _ir_lib(backend):
+    if backend in _ir:
+        return _ir[backend]
+    f = {}
+    if backend == "port":
+        L = lib("port").cdll
+        for sfx, fp in (("f32", _f32p), ("f64", _f64p)):
+            f["copy_" + sfx] = _decl(L, "hcvo_ir_copy_" + sfx, None, fp, fp, fp, fp, _sz)
+            f["time_reverse_" + sfx] = _decl(L, "hcvo_ir_time_reverse_" + sfx, None, fp, fp, fp, fp, _sz)
+            f["spike_" + sfx] = _decl(L, "hcvo_ir_spike_" + sfx, None, fp, fp, _sz, C.c_double)
+            f["delay_" + sfx] = _decl(L, "hcvo_ir_delay_" + sfx, None, fp, fp, fp, fp, _sz, C.c_double)
+            f["phase_" + sfx] = _decl(L, "hcvo_ir_phase_" + sfx, None, fp, fp, fp, fp, _sz, C.c_double, C.c_int)
+            f["change_phase_" + sfx] = _decl(L, "hcvo_change_phase_" + sfx, _sz, fp, _sz, C.c_double, C.c_double, fp)
+    else:
+        if not have_ref_spectral():
+            raise FileNotFoundError(REF_SPECTRAL_PATH)
+        L = C.CDLL(REF_SPECTRAL_PATH)
+        for sfx, fp in (("f32", _f32p), ("f64", _f64p)):
+            f["ir_" + sfx] = _decl(L, "ref_ir_" + sfx, None, C.c_int, fp, fp, fp, fp, _sz, C.c_double, C.c_int)
+            f["change_phase_" + sfx] = _decl(L, "ref_change_phase_" + sfx, _sz, fp, _sz, C.c_double, C.c_double, fp)
+    _ir[backend] = f
+    return f
+
+
+def ir_op(op: str, realp, imagp, fft_size: int, value: float = 0.0, zero_center: bool = False, precision: str = "f32", backend: str = "port"):
+    """ir_copy / ir_spike / ir_delay / ir_time_reverse / ir_phase (SpectralFunctions.hpp:365-413) on one packed half
+    spectrum of fft_size/2 values per array.  Returns (realp, imagp).  spike ignores the inputs."""
+    f = _ir_lib(backend)
+    dt = np.float32 if precision == "f32" else np.float64
+    half = fft_size >> 1
+    ptr = (lambda v: v.ctypes.data_as(_f32p)) if dt == np.float32 else (lambda v: v.ctypes.data_as(_f64p))
+    ri = np.zeros(half, dt) if realp is None else np.ascontiguousarray(realp, dt).copy()
+    ii = np.zeros(half, dt) if imagp is None else np.ascontiguousarray(imagp, dt).copy()
+    ro, io = np.zeros(half, dt), np.zeros(half, dt)
+    if backend == "ref":
+        if op == "phase":                       # the reference's callers run it in place (SpectralProcessor.hpp:204)
+            f["ir_" + precision](4, ptr(ri), ptr(ii), ptr(ri), ptr(ii), fft_size, value, int(zero_center))
+            return ri, ii
+        f["ir_" + precision](IR_OPS.index(op), ptr(ro), ptr(io), ptr(ri), ptr(ii), fft_size, value, int(zero_center))
+        return ro, io
+    if op == "copy":
+        f["copy_" + precision](ptr(ro), ptr(io), ptr(ri), ptr(ii), fft_size)
+    elif op == "time_reverse":
+        f["time_reverse_" + precision](ptr(ro), ptr(io), ptr(ri), ptr(ii), fft_size)
+    elif op == "spike":
+        f["spike_" + precision](ptr(ro), ptr(io), fft_size, value)
+    elif op == "delay":
+        f["delay_" + precision](ptr(ro), ptr(io), ptr(ri), ptr(ii), fft_size, value)
+    elif op == "phase":
+        f["phase_" + precision](ptr(ro), ptr(io), ptr(ri), ptr(ii), fft_size, value, int(zero_center))
+    else:
+        raise ValueError(op)
+    return ro, io
+
+
+def change_phase(x, phase: float, time_multiplier: float = 1.0, precision: str = "f32", backend: str = "port"):
+    """spectral_processor<T>::change_phase (SpectralProcessor.hpp:188-208): returns the fft_size output samples."""
+    f = _ir_lib(backend)
+    dt = np.float32 if precision == "f32" else np.float64
+    x = np.ascontiguousarray(x, dt)
+    want = int(round(x.size * time_multiplier))
+    log2n = 0
+    while want >> log2n:
+        log2n += 1
+    if log2n and want == 1 << (log2n - 1):
+        log2n -= 1
+    out = np.zeros(max(1 << log2n, 1), dt)
+    ptr = (lambda v: v.ctypes.data_as(_f32p)) if dt == np.float32 else (lambda v: v.ctypes.data_as(_f64p))
+    n = f["change_phase_" + precision](ptr(x), x.size, phase, time_multiplier, ptr(out))
+    return out[:n]

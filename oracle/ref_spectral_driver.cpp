@@ -9,6 +9,7 @@
 #include "HISSTools_FFT/HISSTools_FFT.h"
 #include "SpectralProcessor.hpp"
 
+#include <cmath>
 #include <cstdint>
 
 // FFT setup large enough for every edge mode of these sizes (fold modes need up to ~2x the linear size); building the
@@ -40,4 +41,36 @@ extern "C"
         spectral_processor<float> sp(table_size(n1, n2));
         sp.correlate(out, { in1, n1 }, { in2, n2 }, static_cast<spectral_processor<float>::EdgeMode>(mode));
     }
+
+    // ---------------------------------------------------------------- spectral IR functions (SpectralFunctions.hpp:365-413) and
+    // spectral_processor::change_phase (SpectralProcessor.hpp:188-208): fourth "next" row.  op: 0 copy, 1 spike, 2 delay,
+    // 3 time_reverse, 4 phase.  In-place calls (out == in) are what the reference's own callers make.
+#define REF_IR(SFX, T, SPLIT, SETUP)                                                                                     \
+    void ref_ir_##SFX(int op, T *ro, T *io, const T *ri, const T *ii, uintptr_t fft_size, double value, int zero_center)   \
+    {                                                                                                                    \
+        SPLIT out(ro, io), in(const_cast<T *>(ri), const_cast<T *>(ii));                                                 \
+        if (op == 0) ir_copy(&out, &in, fft_size);                                                                       \
+        else if (op == 1) ir_spike(&out, fft_size, value);                                                               \
+        else if (op == 2) ir_delay(&out, &in, fft_size, value);                                                          \
+        else if (op == 3) ir_time_reverse(&out, &in, fft_size);                                                          \
+        else                                                                                                             \
+        {                                                                                                                \
+            uintptr_t log2n = 0;                                                                                         \
+            while ((uintptr_t(1) << log2n) < fft_size) log2n++;                                                          \
+            SETUP setup;                                                                                                 \
+            hisstools_create_setup(&setup, log2n);                                                                       \
+            ir_phase(setup, &out, &in, fft_size, value, zero_center != 0);                                               \
+            hisstools_destroy_setup(setup);                                                                              \
+        }                                                                                                                \
+    }                                                                                                                    \
+    uintptr_t ref_change_phase_##SFX(const T *in, uintptr_t size, double phase, double time_multiplier, T *out)          \
+    {                                                                                                                    \
+        uintptr_t log2n = spectral_processor<T>::calc_fft_size_log2((uintptr_t) std::round(size * time_multiplier));     \
+        spectral_processor<T> sp(uintptr_t(1) << (log2n > 5 ? log2n : 5));                                               \
+        sp.change_phase(out, in, size, phase, time_multiplier);                                                          \
+        return size == 1 ? 1 : uintptr_t(1) << log2n;                                                                    \
+    }
+    REF_IR(f32, float, FFT_SPLIT_COMPLEX_F, FFT_SETUP_F)
+    REF_IR(f64, double, FFT_SPLIT_COMPLEX_D, FFT_SETUP_D)
+#undef REF_IR
 }

@@ -4,6 +4,7 @@ The package holds only what the hot path needs:
   csrc/          HIP kernels (gfx950), the device engine and the C ABI (include/hisstools_amd.h)
   _lib.py        ctypes loader of the in-tree shared library (no CPU fallback)
   convolver.py   Python mirror of the reference classes over the C ABI
+  fft.py, spectral_functions.py   Python mirror of the hisstools_* FFT functions and the spectral IR functions
   sharded.py     one-process-per-GPU output-row sharding (torch.distributed plumbing)
 """
 from ._lib import LIB_PATH, load, last_error  # noqa: F401

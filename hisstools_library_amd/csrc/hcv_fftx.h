@@ -49,4 +49,5 @@ namespace hcv
     // the stream, so concurrent use of the big-size path from several streams is serialised by the caller).
     hipError_t fftx_exec(int device, const FxCall &call, hipStream_t stream, std::string *err);
     bool fftx_valid(const FxCall &call, std::string *err);
+    const double2 *fftx_twiddles_f64(int device, int log2n, std::string *err);    // exp(-2 pi i m / 2^log2n), m < 2^(log2n-1), cached per device
 }

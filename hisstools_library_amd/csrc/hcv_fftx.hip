@@ -661,6 +661,8 @@ namespace
     }
 }
 
+const double2 *fftx_twiddles_f64(int device, int log2n, std::string *err) { return twiddles_f64(device, log2n, err); }
+
 bool fftx_valid(const FxCall &c, std::string *err)
 {
     auto fail = [&](const char *m) { if (err) *err = m; return false; };

@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 
 namespace hcv
 {
@@ -131,24 +133,53 @@ namespace
             ir_apply<T>(k, i, a, b, inv_n, ro, io);
     }
 
-    template <class T>
+    // VEC consecutive bins per thread (16-byte loads and stores when VEC > 1; the host picks VEC = 1 unless the pointers,
+    // strides and length allow it)
+    template <class T, int VEC>
     __global__ __launch_bounds__(256) void ir_elementwise_kernel(IrK<T> k)
     {
-        const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i >= k.half) return;
+        const int i0 = (blockIdx.x * 256 + threadIdx.x) * VEC;
+        if (i0 >= k.half) return;
         const double inv_n = 0.5 / (double) k.half;
+        typedef T VT __attribute__((ext_vector_type(VEC)));
         for (long long q = blockIdx.y; q < k.batch; q += gridDim.y)
         {
-            T a = (T) 0, b = (T) 0;
+            T a[VEC], b[VEC], ro[VEC], io[VEC];
             if (k.mode != E_SPIKE)
             {
-                a = k.sr[q * k.sstride + i];
-                b = k.si[q * k.sstride + i];
+                if (VEC > 1)
+                {
+                    const VT va = *reinterpret_cast<const VT *>(k.sr + q * k.sstride + i0);
+                    const VT vb = *reinterpret_cast<const VT *>(k.si + q * k.sstride + i0);
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) { a[v] = va[v]; b[v] = vb[v]; }
+                }
+                else
+                {
+                    a[0] = k.sr[q * k.sstride + i0];
+                    b[0] = k.si[q * k.sstride + i0];
+                }
             }
-            T ro, io;
-            ir_bin<T>(k, i, a, b, inv_n, &ro, &io);
-            k.dr[q * k.dstride + i] = ro;
-            k.di[q * k.dstride + i] = io;
+            else
+            {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) a[v] = b[v] = (T) 0;
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) ir_bin<T>(k, i0 + v, a[v], b[v], inv_n, &ro[v], &io[v]);
+            if (VEC > 1)
+            {
+                VT vr, vi;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) { vr[v] = ro[v]; vi[v] = io[v]; }
+                *reinterpret_cast<VT *>(k.dr + q * k.dstride + i0) = vr;
+                *reinterpret_cast<VT *>(k.di + q * k.dstride + i0) = vi;
+            }
+            else
+            {
+                k.dr[q * k.dstride + i0] = ro[0];
+                k.di[q * k.dstride + i0] = io[0];
+            }
         }
     }
 
@@ -178,13 +209,185 @@ namespace
         }
     }
 
+    // -------------------------------------------------------------------------------------------- fused minimum-phase path
+    //
+    // One thread group per spectrum, everything between the load and the store in LDS / registers:
+    //   load + log power -> [real pre-pass on the fly] inverse FFT -> [causal window on the fly] forward FFT -> real
+    //   post-pass + exponential -> store.
+
+    template <class T> struct Cx2;
+    template <> struct Cx2<float> { typedef float2 type; };
+    template <> struct Cx2<double> { typedef double2 type; };
+
+    // first-pass source of the inverse transform: pass_real_trig_table<true> (HISSTools_FFT_Core.h:934-988) of the packed
+    // log spectrum in LDS, with re/im exchanged so that the forward kernel acts as the inverse (Core.h:1341-1346)
+    template <class T, int LOG2M> struct LogPreLoad
+    {
+        typedef typename Cx2<T>::type C;
+        static constexpr bool is_lds = true;
+        LdsBuf<C> s;
+        const C *__restrict__ tw;
+        __device__ __forceinline__ C operator()(int n) const
+        {
+            constexpr int M = 1 << LOG2M;
+            if (n == 0)
+            {
+                const C z = s[0];
+                return C(z.x - z.y, z.x + z.y);
+            }
+            const bool lo = n <= M / 2;
+            const int k = lo ? n : M - n, m = M - k;
+            const C w = tw[k];
+            const T c = -w.x, sn = w.y;
+            const C z1 = s[k], z2 = s[m];
+            const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+            const T u1 = (c * i3) + (sn * r4);
+            const T u2 = (sn * i3) - (c * r4);
+            return lo ? C(u2 + i4, r3 + u1) : C(u2 - i4, r3 - u1);
+        }
+    };
+
+    // first-pass source of the forward transform: the inverse left (x[2n+1], x[2n]) in LDS; window the cepstrum on the way
+    template <class T, int LOG2M> struct WindowLoad
+    {
+        typedef typename Cx2<T>::type C;
+        static constexpr bool is_lds = true;
+        LdsBuf<C> s;
+        __device__ __forceinline__ C operator()(int n) const
+        {
+            const C v = s[n];
+            T r = v.y, m = v.x;
+            cepstral_window<T>(n, 1 << LOG2M, &r, &m);
+            return C(r, m);
+        }
+    };
+
+    template <class T, int LOG2M>
+    __global__ __launch_bounds__((FFTGeom<LOG2M>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void ir_minphase_kernel(IrK<T> k, const typename Cx2<T>::type *__restrict__ tw)
+    {
+        typedef typename Cx2<T>::type C;
+        typedef FFTGeom<LOG2M> Gm;
+        constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G, EPT = (M + TG - 1) / TG;
+        extern __shared__ __attribute__((aligned(16))) unsigned char ir_raw[];
+        C *lds = reinterpret_cast<C *>(ir_raw);
+
+        const int g = (TG % 64 == 0) ? __builtin_amdgcn_readfirstlane((int) (threadIdx.x / TG)) : (int) (threadIdx.x / TG), t = threadIdx.x % TG;
+        const long long q = (long long) blockIdx.x * G + g;
+        const bool live = q < k.batch;
+        const LdsBuf<C> s = { lds + g * lds_padded(M) };
+        const double inv_n = 0.5 / (double) M;
+
+        // load (all of a thread's loads in flight) + log power spectrum, DC / Nyquist packed in bin 0
+        {
+            const T *sr = k.sr + (live ? q : 0) * k.sstride, *si = k.si + (live ? q : 0) * k.sstride;
+            IrK<T> lp = k;
+            lp.mode = E_LOG_POWER;
+            T a[EPT], b[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++)
+            {
+                const int n = t + e * TG;
+                const bool in = live && (M % TG == 0 || n < M);
+                a[e] = in ? sr[n] : (T) 1;
+                b[e] = in ? si[n] : (T) 0;
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; e++)
+            {
+                const int n = t + e * TG;
+                if (M % TG == 0 || n < M)
+                {
+                    T ro, io;
+                    ir_bin<T>(lp, n, a[e], b[e], inv_n, &ro, &io);
+                    s[n] = C(ro, io);
+                }
+            }
+        }
+        __syncthreads();
+        const LdsIO<C> io = { s };
+        LdsFFT<LOG2M, TG, C>::run(LogPreLoad<T, LOG2M>{ s, tw }, io, s, t, tw);          // real cepstrum, as (odd, even) pairs
+        LdsFFT<LOG2M, TG, C>::run(WindowLoad<T, LOG2M>{ s }, io, s, t, tw);               // windowed, transformed forward
+        if (!live) return;
+        // pass_real_trig_table<false> (Core.h:934-988) for the bin pair (j, M-j), then the exponential of each bin
+        T *dr = k.dr + q * k.dstride, *di = k.di + q * k.dstride;
+        for (int j = t; j <= M / 2; j += TG)
+        {
+            T ro, io2;
+            if (j == 0)
+            {
+                const C z = s[0];
+                const T t1 = z.x + z.y, t2 = z.x - z.y;
+                ir_bin<T>(k, 0, t1 + t1, t2 + t2, inv_n, &ro, &io2);
+                dr[0] = ro;
+                di[0] = io2;
+                continue;
+            }
+            const int m = M - j;
+            const C w = tw[j];
+            const C z1 = s[j], z2 = s[m];
+            const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+            const T u1 = (w.x * i3) + (w.y * r4);
+            const T u2 = (w.y * i3) - (w.x * r4);
+            if (m != j)
+            {
+                ir_bin<T>(k, j, r3 + u1, u2 + i4, inv_n, &ro, &io2);
+                dr[j] = ro;
+                di[j] = io2;
+            }
+            ir_bin<T>(k, m, r3 - u1, u2 - i4, inv_n, &ro, &io2);
+            dr[m] = ro;
+            di[m] = io2;
+        }
+    }
+
+    template <class T> constexpr int ir_max_lds_log2m() { return sizeof(T) == 4 ? 14 : 13; }
+
+    template <class T, int L> hipError_t launch_minphase(const IrK<T> &k, const typename Cx2<T>::type *tw, hipStream_t st)
+    {
+        typedef typename Cx2<T>::type C;
+        typedef FFTGeom<L> Gm;
+        const size_t lds = sizeof(C) * lds_padded(Gm::M) * Gm::G;
+        if (lds > 64 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ir_minphase_kernel<T, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            if (e != hipSuccess) return e;
+        }
+        const long long grid = (k.batch + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL((ir_minphase_kernel<T, L>), dim3((unsigned) grid), dim3(Gm::THREADS), lds, st, k, tw);
+        return hipGetLastError();
+    }
+
+    template <class T> hipError_t dispatch_minphase(int lm, const IrK<T> &k, const typename Cx2<T>::type *tw, hipStream_t st)
+    {
+        switch (lm)
+        {
+#define IR_CASE(L) case L: return launch_minphase<T, L>(k, tw, st);
+            IR_CASE(2) IR_CASE(3) IR_CASE(4) IR_CASE(5) IR_CASE(6) IR_CASE(7) IR_CASE(8) IR_CASE(9) IR_CASE(10) IR_CASE(11) IR_CASE(12) IR_CASE(13)
+#undef IR_CASE
+            case 14:
+                if constexpr (sizeof(T) == 4) return launch_minphase<T, 14>(k, tw, st);
+                return hipErrorInvalidValue;
+            default: return hipErrorInvalidValue;
+        }
+    }
+
     template <class T> hipError_t launch_elementwise(const IrK<T> &k, hipStream_t st)
     {
         if (!k.half || !k.batch) return hipSuccess;
-        dim3 grid((unsigned) ((k.half + 255) / 256), (unsigned) std::min<long long>(k.batch, 65535));
-        hipLaunchKernelGGL(ir_elementwise_kernel<T>, grid, dim3(256), 0, st, k);
+        constexpr int VEC = 16 / (int) sizeof(T);
+        auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool vec = k.half % VEC == 0 && k.sstride % VEC == 0 && k.dstride % VEC == 0 && aligned(k.dr) && aligned(k.di) &&
+                         (k.mode == E_SPIKE || (aligned(k.sr) && aligned(k.si)));
+        const int per = vec ? VEC : 1;
+        dim3 grid((unsigned) ((k.half / per + 255) / 256), (unsigned) std::min<long long>(k.batch, 65535));
+        if (vec) hipLaunchKernelGGL((ir_elementwise_kernel<T, VEC>), grid, dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((ir_elementwise_kernel<T, 1>), grid, dim3(256), 0, st, k);
         return hipGetLastError();
     }
+
+    template <class T> const typename Cx2<T>::type *ir_twiddles(int device, int log2n, std::string *err);
+    template <> const float2 *ir_twiddles<float>(int device, int log2n, std::string *err) { return twiddles(device, log2n, err); }
+    template <> const double2 *ir_twiddles<double>(int device, int log2n, std::string *err) { return fftx_twiddles_f64(device, log2n, err); }
 
     template <class T> hipError_t run_typed(int device, const IrCall &c, hipStream_t st, std::string *err)
     {
@@ -215,7 +418,33 @@ namespace
             k.mode = c.zero_center ? E_AMP : E_AMP_LINEAR;
             return launch_elementwise(k, st);
         }
-        // minimum_phase_components into dst, then the exponential in place on dst
+        // the exponential that follows minimum_phase_components
+        int exp_mode = E_INTERP;
+        double min_factor = 0.0, lin_factor = 0.0;
+        if (phase == 1.0 && c.zero_center) exp_mode = E_EXP_CONJ;
+        else if (phase == 0.0) exp_mode = E_EXP;
+        else
+        {
+            // phase_interpolate, :212-224 (N.B. a delay of -1 sample for anything over linear, to avoid wraparound)
+            const double delay_factor = (phase <= 0.5) ? 0.0 : 1.0 / (double) n;
+            const double ph = std::max(0.0, std::min(1.0, phase));
+            min_factor = 1.0 - (2.0 * ph);
+            lin_factor = c.zero_center ? 0.0 : (-2.0 * M_PI * (ph - delay_factor));
+        }
+        const int lm = (int) c.log2n - 1;
+        static const bool allow_fused = !(std::getenv("HCV_IR_FUSED") && std::atoi(std::getenv("HCV_IR_FUSED")) == 0);
+        if (allow_fused && lm <= ir_max_lds_log2m<T>())
+        {
+            // one kernel: HBM is read once and written once
+            const typename Cx2<T>::type *tw = ir_twiddles<T>(device, lm + 1, err);
+            if (!tw) return hipErrorOutOfMemory;
+            IrK<T> f = k;
+            f.mode = exp_mode;
+            f.min_factor = min_factor;
+            f.lin_factor = lin_factor;
+            return dispatch_minphase<T>(lm, f, tw, st);
+        }
+        // longer spectra: minimum_phase_components into dst with the four-step transforms, then the exponential in place
         k.mode = E_LOG_POWER;
         hipError_t e = launch_elementwise(k, st);
         if (e != hipSuccess) return e;
@@ -240,17 +469,9 @@ namespace
         x.sr = k.dr;
         x.si = k.di;
         x.sstride = k.dstride;
-        if (phase == 1.0 && c.zero_center) x.mode = E_EXP_CONJ;
-        else if (phase == 0.0) x.mode = E_EXP;
-        else
-        {
-            // phase_interpolate, :212-224 (N.B. a delay of -1 sample for anything over linear, to avoid wraparound)
-            const double delay_factor = (phase <= 0.5) ? 0.0 : 1.0 / (double) n;
-            const double ph = std::max(0.0, std::min(1.0, phase));
-            x.mode = E_INTERP;
-            x.min_factor = 1.0 - (2.0 * ph);
-            x.lin_factor = c.zero_center ? 0.0 : (-2.0 * M_PI * (ph - delay_factor));
-        }
+        x.mode = exp_mode;
+        x.min_factor = min_factor;
+        x.lin_factor = lin_factor;
         return launch_elementwise(x, st);
     }
 }

@@ -4,6 +4,8 @@
 // tester only times them): small sizes against a direct O(N^2) DFT in double, all sizes by the inverse round trip.
 // Exit code: 0 pass, 1 numerical failure, 2 no GPU (compile / link check only).
 #include "hisstools_amd/HISSTools_FFT.h"
+#include "hisstools_amd/SpectralFunctions.h"
+#include "hisstools_amd/SpectralProcessor.h"
 
 #include <chrono>
 #include <cmath>
@@ -158,6 +160,72 @@ namespace
         return ok;
     }
 
+    // IR_Manipulation_Tester-style: ir_phase in its eight modes on a 2^14-point spectrum, plus spike / delay / reverse identities
+    template <class T> bool ir_functions()
+    {
+        const int log2n = 14;
+        const uintptr_t n = uintptr_t(1) << log2n, half = n >> 1;
+        typename Kit<T>::setup setup;
+        hisstools_create_setup(&setup, log2n);
+        std::vector<T> x(n), re(half), im(half), r2(half), i2(half), r3(half), i3(half);
+        for (uintptr_t j = 0; j < n; j++) x[j] = (T) (noise() * std::exp(-(double) j / 500.0));
+        typename Kit<T>::split spec(re.data(), im.data()), out(r2.data(), i2.data()), tmp(r3.data(), i3.data());
+        hisstools_rfft(setup, x.data(), &spec, n, log2n);
+        bool ok = true;
+        const double tol = Kit<T>::tol() * 8;
+        double peak = 0.0;
+        for (uintptr_t j = 1; j < half; j++) peak = std::fmax(peak, std::hypot((double) re[j], (double) im[j]));
+        const struct { double phase; bool zero; } modes[] = { { 0.1, true }, { 0.9, false }, { 0.0, true }, { 0.0, false }, { 1.0, true }, { 1.0, false }, { 0.5, true }, { 0.5, false } };
+        for (const auto &m : modes)
+        {
+            ir_phase(setup, &out, &spec, n, m.phase, m.zero);
+            for (uintptr_t j = 1; j < half && ok; j++)               // every phase setting keeps the magnitude response
+            {
+                const double a = std::hypot((double) re[j], (double) im[j]), b = std::hypot((double) r2[j], (double) i2[j]);
+                if (std::fabs(a - b) > 40 * tol * peak) { std::printf("ir_phase(%g, %d) changed the magnitude at bin %lu\n", m.phase, (int) m.zero, (unsigned long) j); ok = false; }
+            }
+        }
+        // delay by d then by -d is the identity; two time reversals are the identity; a spike delayed is a spike elsewhere
+        // (a fractional delay keeps only the real part of the Nyquist bin, so that one slot is not recoverable)
+        ir_delay(&out, &spec, n, 17.5);
+        ir_delay(&tmp, &out, n, -17.5);
+        bool part = std::fabs(r3[0] - re[0]) <= 8 * tol * peak;
+        for (uintptr_t j = 1; j < half; j++) part = part && std::fabs(r3[j] - re[j]) <= 8 * tol * peak && std::fabs(i3[j] - im[j]) <= 8 * tol * peak;
+        if (!part) std::printf("delay(+d) then delay(-d) is not the identity\n");
+        ok = ok && part;
+        ir_time_reverse(&out, &spec, n);
+        ir_time_reverse(&tmp, &out, n);
+        part = true;
+        for (uintptr_t j = 0; j < half; j++) part = part && r3[j] == re[j] && i3[j] == im[j];
+        if (!part) std::printf("two time reversals are not the identity\n");
+        ok = ok && part;
+        ir_spike(&out, n, 3.0);
+        ir_delay(&tmp, &out, n, 4.0);
+        ir_spike(&out, n, 7.0);
+        part = true;
+        for (uintptr_t j = 0; j < half; j++) part = part && std::fabs(r3[j] - r2[j]) <= 8 * tol && std::fabs(i3[j] - i2[j]) <= 8 * tol;
+        if (!part) std::printf("a delayed spike is not the spike at the later position\n");
+        ok = ok && part;
+        ir_copy(&tmp, &spec, n);
+        part = true;
+        for (uintptr_t j = 0; j < half; j++) part = part && r3[j] == re[j] && i3[j] == im[j];
+        if (!part) std::printf("ir_copy differs\n");
+        ok = ok && part;
+        // change_phase: the linear-phase version of x is symmetric about the centre of the frame
+        spectral_processor<T> sp;
+        std::vector<T> y(n);
+        sp.change_phase(y.data(), x.data(), n, 0.5);
+        double ypk = 0.0;
+        for (uintptr_t j = 0; j < n; j++) ypk = std::fmax(ypk, std::fabs((double) y[j]));
+        part = true;
+        for (uintptr_t j = 1; j < n / 2; j++) part = part && std::fabs((double) y[n / 2 + j] - (double) y[n / 2 - j]) <= 200 * tol * ypk;
+        if (!part) std::printf("change_phase(0.5) is not symmetric about the centre\n");
+        ok = ok && part;
+        if (!ok) std::printf("IR function check failed (%s)\n", Kit<T>::name());
+        hisstools_destroy_setup(setup);
+        return ok;
+    }
+
     template <class T> bool run(int sweep_max)
     {
         std::printf("****** %s ******\n", Kit<T>::name());
@@ -181,6 +249,8 @@ int main(int argc, char **argv)
     bool ok = run<double>(sweep_max);
     ok = run<float>(sweep_max) && ok;
     ok = out_of_place() && ok;
+    ok = ir_functions<double>() && ok;
+    ok = ir_functions<float>() && ok;
     std::printf(ok ? "Finished Running\n" : "Errors - did not complete tests\n");
     return ok ? 0 : 1;
 }

@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--batched-block", type=int, default=65536, help="also time offline-style calls of this many samples (0 = skip)")
     ap.add_argument("--tail-ratio", type=int, default=0, help="run the HEADLINE on the extended far-tail ladder (0 = reference partitioning)")
     ap.add_argument("--extended-ratio", type=int, default=8, help="also measure the extended far-tail ladder with this ratio (0 = skip)")
+    ap.add_argument("--ir-file", default="", help="WAVE / AIFF / AIFC file with real impulse responses instead of the synthetic ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores CPU leg")
     args = ap.parse_args()
@@ -211,6 +212,15 @@ def main():
     xs = torch.rand((nin, nring * B), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0     # same audio on every rank
     ys = torch.zeros((nout, nring * B), device=dev, dtype=torch.float32)
 
+    file_irs = None
+    if args.ir_file:
+        from hisstools_library_amd.audiofile import load_impulse_responses
+        data, file_rate = load_impulse_responses(args.ir_file)
+        buf = torch.zeros((data.shape[0], L), device=dev, dtype=torch.float32)
+        take = min(L, data.shape[1])
+        buf[:, :take] = torch.from_numpy(data[:, :take]).to(dev)
+        file_irs = buf
+
     def run(tail_ratio, steps, warmup, batched_block):
         """Build an engine (reference partitioning, or the extended far-tail ladder), load the synthetic IRs straight
         into HBM (decaying noise, unit L2 norm), reach steady state, then time `steps` process calls of B samples."""
@@ -219,9 +229,14 @@ def main():
         t_load = time.perf_counter()
         for o in range(nout):
             for i in range(nin):
-                g.manual_seed(1000 * i + (rank * nout + o) + 1)
-                h = (torch.rand(L, generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0) * decay
-                h = h / torch.linalg.vector_norm(h)
+                if file_irs is not None:
+                    # real impulse responses (--ir-file): pair (i, o) takes channel (i * nout + o) mod channels, cut or
+                    # zero-padded to the workload's IR length
+                    h = file_irs[(i * nout + rank * nout + o) % file_irs.shape[0]]
+                else:
+                    g.manual_seed(1000 * i + (rank * nout + o) + 1)
+                    h = (torch.rand(L, generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0) * decay
+                    h = h / torch.linalg.vector_norm(h)
                 torch.cuda.synchronize()
                 rc = conv.set_dev(i, o, h.data_ptr(), L, True)
                 if rc != 0:
@@ -341,7 +356,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.ir_file else "synthetic audio, impulse responses from " + os.path.basename(args.ir_file),
             "config": {
                 "workload": f"{args.workload}: Convolver {nin}x{nout} per GPU ({nin}x{total_out} over {world} GPU), IR {L} samples @ {fs} Hz, "
                             f"stages {stages}, process block {B} samples, audio + spectra resident in HBM",

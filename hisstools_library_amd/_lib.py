@@ -39,6 +39,12 @@ class IRCall(C.Structure):           # hcv_ir_call
                 ("src_stride", usz), ("dst_stride", usz), ("value", C.c_double), ("zero_center", C.c_int)]
 
 
+class AudioFileInfo(C.Structure):    # hcv_audiofile_info
+    _fields_ = [("file_type", C.c_int), ("pcm_format", C.c_int), ("header_endianness", C.c_int), ("audio_endianness", C.c_int),
+                ("sampling_rate", C.c_double), ("channels", C.c_uint), ("frames", C.c_uint), ("bit_depth", C.c_uint),
+                ("error_flags", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/hisstools_amd.h declares
 SIGNATURES = {
     "hcv_version": (C.c_char_p, []),
@@ -111,6 +117,23 @@ SIGNATURES = {
     "hcv_spectral_phase_size": (usz, [usz, C.c_double]),
     "hcv_spectral_change_phase_f32": (C.c_int, [f32p, usz, C.c_double, C.c_double, f32p]),
     "hcv_spectral_change_phase_f64": (C.c_int, [f64p, usz, C.c_double, C.c_double, f64p]),
+    "hcv_iaudiofile_open": (vp, [C.c_char_p]),
+    "hcv_oaudiofile_open": (vp, [C.c_char_p, C.c_int, C.c_int, C.c_uint, C.c_double, C.c_int]),
+    "hcv_audiofile_close": (None, [vp]),
+    "hcv_audiofile_is_open": (C.c_int, [vp]),
+    "hcv_audiofile_get_info": (C.c_int, [vp, C.POINTER(AudioFileInfo)]),
+    "hcv_audiofile_seek": (None, [vp, u32]),
+    "hcv_audiofile_position": (u32, [vp]),
+    "hcv_iaudiofile_read_raw": (None, [vp, vp, u32]),
+    "hcv_iaudiofile_read_interleaved_f32": (None, [vp, f32p, u32]),
+    "hcv_iaudiofile_read_interleaved_f64": (None, [vp, f64p, u32]),
+    "hcv_iaudiofile_read_channel_f32": (None, [vp, f32p, u32, C.c_uint]),
+    "hcv_iaudiofile_read_channel_f64": (None, [vp, f64p, u32, C.c_uint]),
+    "hcv_oaudiofile_write_raw": (None, [vp, vp, u32]),
+    "hcv_oaudiofile_write_interleaved_f32": (None, [vp, f32p, u32]),
+    "hcv_oaudiofile_write_interleaved_f64": (None, [vp, f64p, u32]),
+    "hcv_oaudiofile_write_channel_f32": (None, [vp, f32p, u32, C.c_uint]),
+    "hcv_oaudiofile_write_channel_f64": (None, [vp, f64p, u32, C.c_uint]),
 }
 
 _lib = None

@@ -247,6 +247,45 @@ HCV_API size_t hcv_spectral_phase_size(size_t size, double time_multiplier);
 HCV_API int hcv_spectral_change_phase_f32(const float *in, size_t size, double phase, double time_multiplier, float *out);
 HCV_API int hcv_spectral_change_phase_f64(const double *in, size_t size, double phase, double time_multiplier, double *out);
 
+/* ---------------------------------------------------------------- audio files (third "next" row; host-side only)
+ * HISSTools::IAudioFile / OAudioFile (AudioFile/IAudioFile.h:37-54, OAudioFile.h:14-37, BaseAudioFile.h:18-98): WAVE
+ * (RIFF / RIFX), AIFF and AIFC reading; WAVE and AIFC writing (an AIFF request writes AIFC, as the reference); PCM int
+ * 8 / 16 / 24 / 32 and float 32 / 64.  Enumerations keep the reference's values:
+ *   file type   0 none, 1 AIFF, 2 AIFC, 3 WAVE                      (BaseAudioFile.h:20-26)
+ *   pcm format  0 int8, 1 int16, 2 int24, 3 int32, 4 float32, 5 float64   (:27-35)
+ *   endianness  0 little, 1 big                                     (:36-40)
+ *   error flags BaseAudioFile::Error bits                           (:47-66)
+ * An open that fails still returns an object (never NULL): query hcv_audiofile_is_open / error_flags, as with the
+ * reference's constructors.  Sample conversion and quantisation are the reference's (integers scaled by 2^(bits-1),
+ * no clipping on write except WAVE 8-bit).  Differences: reads past the end deliver zeros, AIFC "fl64" is read as 64-bit
+ * floats. */
+typedef struct hcv_audiofile hcv_audiofile;
+typedef struct hcv_audiofile_info
+{
+    int file_type, pcm_format, header_endianness, audio_endianness;
+    double sampling_rate;
+    unsigned channels, frames, bit_depth;
+    int error_flags;
+} hcv_audiofile_info;
+HCV_API hcv_audiofile *hcv_iaudiofile_open(const char *path);                                       /* IAudioFile.cpp:23-50 */
+HCV_API hcv_audiofile *hcv_oaudiofile_open(const char *path, int type, int format, unsigned channels, double sampling_rate,
+                                           int endianness /* -1 = the type's default */);           /* OAudioFile.cpp:43-77 */
+HCV_API void hcv_audiofile_close(hcv_audiofile *h);
+HCV_API int hcv_audiofile_is_open(const hcv_audiofile *h);
+HCV_API int hcv_audiofile_get_info(const hcv_audiofile *h, hcv_audiofile_info *out);
+HCV_API void hcv_audiofile_seek(hcv_audiofile *h, uint32_t frame);                                   /* IAudioFile.cpp:70-73, OAudioFile.cpp:92-96 */
+HCV_API uint32_t hcv_audiofile_position(hcv_audiofile *h);
+HCV_API void hcv_iaudiofile_read_raw(hcv_audiofile *h, void *out, uint32_t frames);                  /* IAudioFile.cpp:85-88 */
+HCV_API void hcv_iaudiofile_read_interleaved_f32(hcv_audiofile *h, float *out, uint32_t frames);     /* :95-98 */
+HCV_API void hcv_iaudiofile_read_interleaved_f64(hcv_audiofile *h, double *out, uint32_t frames);    /* :90-93 */
+HCV_API void hcv_iaudiofile_read_channel_f32(hcv_audiofile *h, float *out, uint32_t frames, unsigned channel);   /* :105-108 */
+HCV_API void hcv_iaudiofile_read_channel_f64(hcv_audiofile *h, double *out, uint32_t frames, unsigned channel);  /* :100-103 */
+HCV_API void hcv_oaudiofile_write_raw(hcv_audiofile *h, const void *in, uint32_t frames);            /* OAudioFile.h:29 */
+HCV_API void hcv_oaudiofile_write_interleaved_f32(hcv_audiofile *h, const float *in, uint32_t frames);   /* OAudioFile.cpp:106-114 */
+HCV_API void hcv_oaudiofile_write_interleaved_f64(hcv_audiofile *h, const double *in, uint32_t frames);
+HCV_API void hcv_oaudiofile_write_channel_f32(hcv_audiofile *h, const float *in, uint32_t frames, unsigned channel);   /* :116-124 */
+HCV_API void hcv_oaudiofile_write_channel_f64(hcv_audiofile *h, const double *in, uint32_t frames, unsigned channel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -682,3 +682,51 @@ def change_phase(x, phase: float, time_multiplier: float = 1.0, precision: str =
     ptr = (lambda v: v.ctypes.data_as(_f32p)) if dt == np.float32 else (lambda v: v.ctypes.data_as(_f64p))
     n = f["change_phase_" + precision](ptr(x), x.size, phase, time_multiplier, ptr(out))
     return out[:n]
+
+
+# --------------------------------------------------------------------------------------- audio files (third "next" row): the reference itself
+
+REF_AUDIO_PATH = os.path.join(_HERE, "_ref", "libhisstools_ref_audio.so")
+_audio = {}
+
+
+class RefAudioInfo(C.Structure):
+    _fields_ = [("file_type", C.c_int), ("pcm_format", C.c_int), ("header_endianness", C.c_int), ("audio_endianness", C.c_int),
+                ("sampling_rate", C.c_double), ("channels", C.c_uint), ("frames", C.c_uint), ("bit_depth", C.c_uint), ("error_flags", C.c_int)]
+
+
+def have_ref_audio() -> bool:
+    return os.path.exists(REF_AUDIO_PATH)
+
+
+def _audio_lib():
+    if "L" not in _audio:
+        L = C.CDLL(REF_AUDIO_PATH)
+        _audio["write"] = _decl(L, "ref_audio_write", C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_uint, C.c_double, C.c_int, _f64p, C.c_uint, C.c_int, C.c_int)
+        _audio["info"] = _decl(L, "ref_audio_info", C.c_int, C.c_char_p, C.POINTER(RefAudioInfo))
+        _audio["read64"] = _decl(L, "ref_audio_read_f64", C.c_int, C.c_char_p, _f64p, C.c_uint, C.c_uint, C.c_int)
+        _audio["read32"] = _decl(L, "ref_audio_read_f32", C.c_int, C.c_char_p, _f32p, C.c_uint, C.c_uint, C.c_int)
+        _audio["L"] = L
+    return _audio
+
+
+def ref_audio_write(path, file_type, pcm_format, data, rate, endianness=-1, mode=0, as_float=False):
+    """Write [frames][channels] float64 data with the reference's OAudioFile.  mode 0 interleaved, 1 per channel, 2 two calls."""
+    a = np.ascontiguousarray(data, np.float64)
+    frames, channels = a.shape
+    return _audio_lib()["write"](str(path).encode(), int(file_type), int(pcm_format), channels, float(rate), int(endianness),
+                                 a.ctypes.data_as(_f64p), frames, int(mode), int(as_float))
+
+
+def ref_audio_info(path):
+    info = RefAudioInfo()
+    rc = _audio_lib()["info"](str(path).encode(), C.byref(info))
+    return rc, {k: getattr(info, k) for k, _ in RefAudioInfo._fields_}
+
+
+def ref_audio_read(path, frames, channels, first=0, channel=-1, dtype=np.float64):
+    out = np.zeros((frames, channels) if channel < 0 else frames, dtype)
+    fn = _audio_lib()["read64" if out.dtype == np.float64 else "read32"]
+    ptr = out.ctypes.data_as(_f64p if out.dtype == np.float64 else _f32p)
+    rc = fn(str(path).encode(), ptr, first, frames, channel)
+    return rc, out

@@ -49,3 +49,21 @@ def test_fft_tester_programme_runs_on_gpu():
     out = subprocess.run([FFT_EXE], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Finished Running" in out.stdout
+
+
+AUDIO_SRC = os.path.join(ROOT, "tests", "cpp", "audiofile_smoke.cpp")
+AUDIO_EXE = os.path.join(OUT_DIR, "audiofile_smoke")
+
+
+def test_audiofile_header_round_trip(tmp_path):
+    """HISSTools::IAudioFile / OAudioFile drop-ins: per-channel 24-bit AIFC write, read back (needs no GPU)."""
+    build(AUDIO_SRC, AUDIO_EXE)
+    out = subprocess.run([AUDIO_EXE, str(tmp_path / "smoke.aifc")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_audiofile_loads_an_ir_into_the_convolver(tmp_path):
+    build(AUDIO_SRC, AUDIO_EXE)
+    out = subprocess.run([AUDIO_EXE, str(tmp_path / "smoke.aifc")], capture_output=True, text=True)
+    assert out.returncode == 0 and "convolver load ok" in out.stdout, out.stdout + out.stderr

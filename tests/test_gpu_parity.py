@@ -543,6 +543,37 @@ def _sparse_matrix_case(H, nin, nout, L, S, block, latency, seed):
         assert rel_err(y[o], t) < TOL_SUM, (o, rel_err(y[o], t))
 
 
+def test_long_stream_wraps_every_ring_many_times(H, oracle):
+    """Six million samples through a zero-latency MonoConvolve and a 2x2 Convolver in ragged calls: the input history,
+    the input-spectrum rings and the stage timelines (a few blocks deep) wrap hundreds of times; the end of the stream
+    must be as accurate as its start."""
+    S = 6_000_000
+    L = 5000
+    h = oracle.synth_ir(2, 1, L)
+    x = oracle.synth_audio(12, S)
+    ref = oracle.MonoConvolve(L, 0)
+    ref.setResetOffset(0)
+    assert ref.set(h, True) == 0
+    y_ref = ref.run(x, 2048)
+    gpu = H.MonoConvolve(L, 0)
+    assert gpu.set(h, True) == 0
+    y = gpu.run(x, [64, 1000, 4096, 333, 8192, 5, 20000, 32768, 40001])
+    for a, b in ((0, 100_000), (S // 2, S // 2 + 100_000), (S - 100_000, S)):
+        assert rel_err(y[a:b], y_ref[a:b]) < TOL, (a, b)
+    assert rel_err(y, y_ref) < TOL
+
+    S2 = 1_500_000
+    irs = [[oracle.synth_ir(i, o, 3000 + 500 * (i + o)) for o in range(2)] for i in range(2)]
+    xs = np.stack([oracle.synth_audio(30 + i, S2) for i in range(2)])
+    cref, cgpu = oracle.Convolver(2, 2, 0), H.Convolver(2, 2, 0)
+    for i in range(2):
+        for o in range(2):
+            assert cref.set(i, o, irs[i][o], True) == 0 and cgpu.set(i, o, irs[i][o], True) == 0
+    yr, yg = cref.run(xs, 2, 2048), cgpu.run(xs, 2, [4096, 100, 65536, 7])
+    for o in range(2):
+        assert rel_err(yg[o][-200_000:], yr[o][-200_000:]) < TOL_SUM
+
+
 @pytest.mark.parametrize("ratio,latency_zero", [(8, True), (4, True), (8, False)])
 def test_extended_tail_ladder_matches_reference_layout(H, oracle, ratio, latency_zero):
     """MI355X extension: past the reference's largest FFT the far tail is served by `ratio` times larger FFTs per

@@ -721,6 +721,35 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
     EmitSources src;
     src.count = 0;
+    // Tail gate: when this block carries a hop of a long, bandwidth-bound tail stage, the shorter stages' MACs are held
+    // until the tail's spectral_mac has finished.  That kernel is one wave of workgroups balanced over every CU and
+    // streams through the caches; short-stage MACs whose spectra do not fit those caches, run beside it, are evicted by
+    // it, re-read from HBM and take slots from some of its workgroups — together they take longer than one after the
+    // other (64x64 with 10 s IRs: tail alone 2.29 ms at 6.9 TB/s + short stages 0.33 ms, against 2.97 ms overlapped).
+    // When the short stages fit the caches (16x16) or the tail is short (64x64 with 2 s IRs) the overlap wins and is
+    // kept.  HCV_TAIL_GATE = 0 / 1 forces the choice (2: hold the forward FFTs too).
+    static const int tail_gate_env = std::getenv("HCV_TAIL_GATE") ? std::atoi(std::getenv("HCV_TAIL_GATE")) : -1;
+    int tail_gate = tail_gate_env;
+    if (tail_gate < 0)
+    {
+        double small_bytes = 0, small_traffic = 0, tail_bytes = 0;
+        for (size_t si = 0; si < mStages.size(); si++)
+        {
+            const Stage &sg = *mStages[si];
+            size_t live_p = 0;
+            for (uint32_t p : sg.pact) live_p += p;
+            const double bytes = (double) live_p * sg.M * sizeof(float2);
+            const double hops = (double) ((n0 + B) / sg.M - n0 / sg.M);
+            if (si + 1 == mStages.size()) tail_bytes = bytes * std::max(1.0, hops / 8.0);
+            else
+            {
+                small_bytes += bytes;
+                small_traffic += bytes * std::max(1.0, hops / 4.0);       // hop tiles of 4 share one read of the spectra
+            }
+        }
+        tail_gate = (small_bytes >= 64.0 * 1048576.0 && tail_bytes >= 12.0 * small_traffic) ? 1 : 0;
+    }
+    hipEvent_t gate = nullptr;
     // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     for (size_t sj = 0; sj < mStages.size(); sj++)
     {
@@ -750,7 +779,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         st.Y = st.Yq[q];
 
         HCV_TRY(hipStreamWaitEvent(sF, mEvInput[q], 0));
+        if (gate && tail_gate >= 2) HCV_TRY(hipStreamWaitEvent(sF, gate, 0));
         HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
+        if (gate && tail_gate == 1) HCV_TRY(hipStreamWaitEvent(sM, gate, 0));
         if (split)
         {
             HCV_TRY(hipEventRecord(st.fft_done[q], sF));
@@ -850,6 +881,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         {
             HCV_TRY(hipEventRecord(st.mac_done[q], sM));
             HCV_TRY(hipStreamWaitEvent(sI, st.mac_done[q], 0));
+        }
+        else if (tail_gate && sj == 0 && mStages.size() > 1 && !mOneStream && st.P && !defer && !have_pre)
+        {
+            HCV_TRY(hipEventRecord(st.mac_done[q], sM));
+            gate = st.mac_done[q];
         }
 
         // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream

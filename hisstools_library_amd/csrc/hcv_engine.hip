@@ -82,6 +82,8 @@ const float2 *twiddles(int device, int log2n, std::string *err)
 
 // ------------------------------------------------------------------------------------------------
 
+constexpr int kBgSlices = 16;
+
 struct Engine::Stage
 {
     StageCfg cfg;
@@ -93,11 +95,15 @@ struct Engine::Stage
     float2 *Yq[2] = { nullptr, nullptr };   // split-K partials, double-buffered so MAC(k+1) can run while block k is inverted
     size_t y_elems = 0;
     // Deferred ("time-spread") mode, the GPU form of the reference's partition scheduler (PartitionedConvolve.cpp:321-348):
-    // partitions 1..P-1 of hop h+1 only need spectra up to hop h, so they are accumulated into Ypre in the BACKGROUND
-    // right after hop h's boundary; the boundary of hop h+1 then only pays partition 0 + the inverse FFT.
-    float2 *Ypre = nullptr;             // [nout][M] sum over p >= 1 for the next hop
-    long long pre_hop = -1;             // hop index Ypre was accumulated for (-1 = none)
-    hipEvent_t bg_done = nullptr;       // recorded after the background accumulation
+    // partitions 1..P-1 of hop h+1 only need spectra up to hop h, so they are accumulated BETWEEN the boundaries of hop h
+    // and hop h+1, in up to kBgSlices short launches spread over the calls of that hop in step with the samples that
+    // have arrived (a single long launch would sit in a hardware queue that other streams share and stall them for
+    // milliseconds); the boundary of hop h+1 then only pays partition 0 + the inverse FFT.
+    float2 *Ypre = nullptr;             // [kBgSlices][nout][M]: one partial sum per slice; slot 0 receives their total
+    long long pre_hop = -1;             // hop index the slices accumulate for (-1 = no plan)
+    int bg_parts = 0;                   // partitions 1..bg_parts of that hop are to be accumulated
+    int bg_slices = 0, bg_launched = 0; // planned / already launched slices
+    hipEvent_t bg_done = nullptr;       // recorded after every background launch
     bool bg_pending = false;
     float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
     long long tl_len = 0;
@@ -292,7 +298,7 @@ bool Engine::alloc_stage(Stage &st)
     st.Y = st.Yq[0];
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
-    HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) mCfg.nout * st.M));
+    HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) kBgSlices * mCfg.nout * st.M));
     HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
     if (is_big_fft(st.log2n))
     {
@@ -750,6 +756,52 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         tail_gate = (small_bytes >= 64.0 * 1048576.0 && tail_bytes >= 12.0 * small_traffic) ? 1 : 0;
     }
     hipEvent_t gate = nullptr;
+
+    // Launch the background slices of `st` that are due: all of them at the hop's boundary, otherwise in proportion to the
+    // part of the hop's samples that has arrived with this call.  Slice s covers partitions 1 + [a, b) of hop pre_hop:
+    // a (b - a)-partition MAC at hop pre_hop - 1 - a over the spectra shifted by 1 + a partitions.
+    auto advance_background = [&](Stage &st, bool boundary) -> bool
+    {
+        if (st.pre_hop < 0 || st.bg_launched >= st.bg_slices) return true;
+        const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M;
+        int due = boundary ? st.bg_slices : (int) std::min<long long>(st.bg_slices, std::max<long long>(0, into * st.bg_slices / (long long) st.M));
+        const int per = (st.bg_parts + st.bg_slices - 1) / st.bg_slices;
+        const long long slot_elems = (long long) mCfg.nout * st.M;
+        for (; st.bg_launched < due; st.bg_launched++)
+        {
+            const int a = st.bg_launched * per, b = std::min(st.bg_parts, a + per);
+            float2 *slot = st.Ypre + (long long) st.bg_launched * slot_elems;
+            if (b <= a)
+            {
+                HCV_TRY(hipMemsetAsync(slot, 0, sizeof(float2) * slot_elems, st.stream));
+                continue;
+            }
+            MacShape sb;
+            sb.M = (int) st.M;
+            sb.R = (int) st.R;
+            sb.P = b - a;
+            sb.Pcap = (int) st.Pcap;
+            sb.nin = (int) nin_act;                                 // slices only run for the full matrix
+            sb.nin_alloc = (int) mNinAlloc;
+            sb.nout = (int) mCfg.nout;
+            sb.diag = mCfg.diag ? 1 : 0;
+            sb.T = 1;
+            sb.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) mCfg.nout * st.M));
+            sb.target_blocks = 0;
+            MacPlan pb;
+            mac_plan(sb, pb);
+            const long long hop = st.pre_hop - 1 - a;
+            const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
+            float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
+            HCV_TRY(launch_spectral_mac(sb, pb, st.X, st.Hs + (size_t) (1 + a) * st.M, scratch, st.hv, hop, bcheck, st.stream));
+            HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, st.stream));
+            HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, st.stream));
+            HCV_TRY(hipEventRecord(st.bg_done, st.stream));
+            st.bg_pending = true;
+        }
+        return true;
+    };
+
     // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     for (size_t sj = 0; sj < mStages.size(); sj++)
     {
@@ -763,7 +815,16 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         if (!st.P && !head_here) continue;
         const long long h_first = n0 / st.M;
         const int T = (int) ((n0 + B) / st.M - h_first);
-        if (T <= 0) continue;
+        const bool full_matrix = nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+        if (T <= 0)
+        {
+            if (st.pre_hop >= 0)
+            {
+                if (!full_matrix || st.pre_hop != h_first) st.pre_hop = -1;     // the plan no longer fits what is being processed
+                else if (!advance_background(st, false)) return false;
+            }
+            continue;
+        }
 
         // A large stage's forward FFTs and inverse side can run off its MAC stream so that its MACs go back to back:
         //   HCV_SPLIT=2  forward FFT on the (otherwise idle) input stream right behind the scatter, reduce + inverse FFT on
@@ -858,7 +919,10 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         {
             if (have_pre)
             {
-                // boundary of a hop whose partitions 1..P-1 were accumulated in the background: partition 0 only
+                // boundary of a hop whose partitions 1..P-1 were accumulated in the background: whatever slices are still
+                // due, their total into slot 0, then partition 0 only
+                if (!advance_background(st, true)) return false;
+                HCV_TRY(launch_reduce_partials(st.Ypre, st.bg_slices, (long long) mCfg.nout * st.M, (long long) mCfg.nout * st.M, sM));
                 MacShape s0 = sh;
                 s0.P = 1;
                 s0.max_ksplit = 1;
@@ -921,33 +985,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         st.pre_hop = -1;
         if (defer)
         {
-            // background: Ypre for hop h+1 = sum_{p>=1} X[h+1-p] H[p]  ==  a (P-1)-partition MAC at hop h over H shifted by
-            // one partition.  Queued on the MAC stream behind this block; nothing in this call waits for it.  It works in
-            // the OTHER parity's scratch (this block's is still being inverted) and only touches Ypre after that.
-            MacShape sb = sh;
-            sb.P = (int) std::min<long long>(st.P - 1, h_first + 1);    // partitions p' = p - 1 <= h that have input
-            MacPlan pb;
-            sb.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M));
-            // small footprint: there is a whole hop of real time to finish, and the calls in between need free CUs
-            static const int bg_blocks = std::getenv("HCV_BG_BLOCKS") ? std::atoi(std::getenv("HCV_BG_BLOCKS")) : 128;
-            sb.target_blocks = bg_blocks;
-            mac_plan(sb, pb);
-            float2 *scratch = st.Yq[q ^ 1];
-            ev = nullptr;
-            if (!begin_event()) return false;
-            const bool bcheck = (h_first - st.max_hv) < (long long) st.P - 1;
-            HCV_TRY(launch_spectral_mac(sb, pb, st.X, st.Hs + st.M, scratch, st.hv, h_first, bcheck, sM));
-            if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
-            st.launches++;
-            st.hops += 1;
-            st.last_ksplit = (uint32_t) pb.ksplit;
-            st.last_ot = (uint32_t) pb.ot;
-            HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, y_elems, y_elems, sM));
-            HCV_TRY(hipStreamWaitEvent(sM, st.done[q], 0));          // the inverse of this block may still be reading Ypre
-            HCV_TRY(hipMemcpyAsync(st.Ypre, scratch, sizeof(float2) * (size_t) nout_act * st.M, hipMemcpyDeviceToDevice, sM));
-            HCV_TRY(hipEventRecord(st.bg_done, sM));
-            st.bg_pending = true;
-            st.pre_hop = h_first + 1;
+            // plan the background accumulation for hop h+1: partitions 1 .. min(P-1, h+1) (those that have input), in up to
+            // kBgSlices launches that the following calls issue as the hop's samples arrive (advance_background)
+            static const int slices_env = std::getenv("HCV_BG_SLICES") ? std::atoi(std::getenv("HCV_BG_SLICES")) : kBgSlices;
+            st.bg_parts = (int) std::min<long long>(st.P - 1, h_first + 1);
+            st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
+            st.bg_launched = 0;
+            st.pre_hop = st.bg_parts > 0 ? h_first + 1 : -1;
         }
     }
 

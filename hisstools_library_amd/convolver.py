@@ -144,6 +144,12 @@ class spectral_processor:
     def correlate(self, in1, in2, mode=EdgeMode.Linear):
         return self._run(self.L.hcv_spectral_correlate_f32, in1, in2, mode, "spectral_processor.correlate")
 
+    def convolve_dev(self, in1_ptr: int, size1: int, in2_ptr: int, size2: int, out_ptr: int, mode=EdgeMode.Linear, correlate=False, stream: int = 0, sync=True):
+        """hcv_spectral_convolve_f32_dev / _correlate_f32_dev: float32 operands and result resident in HBM (device pointers as
+        integers, e.g. ``tensor.data_ptr()``); ``out`` must hold ``convolved_size(size1, size2, mode)`` floats."""
+        fn = self.L.hcv_spectral_correlate_f32_dev if correlate else self.L.hcv_spectral_convolve_f32_dev
+        _check(fn(in1_ptr, size1, in2_ptr, size2, int(mode), out_ptr, stream or None, int(sync)), "spectral_processor.convolve_dev")
+
     def change_phase(self, x, phase: float, time_multiplier: float = 1.0):
         """spectral_processor<T>::change_phase (SpectralProcessor.hpp:188-208); float32 or float64 by the input's dtype.
         Returns the fft_size output samples (fft_size = the power of two covering round(size * time_multiplier))."""

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -959,16 +960,58 @@ namespace
         return s;
     }
 
-    void copy_fold(float *dst, const float *in, size_t size, size_t fold_size, bool repeat)   // :361-377
+    // device scratch of one spectral_binary call: the folded operand, both spectra, the circular result, four-step work
+    struct SpectralWork
     {
-        const size_t off = repeat ? 0 : 1;
-        std::memcpy(dst + fold_size, in, sizeof(float) * size);
-        for (size_t i = 0; i < fold_size; i++)
+        float *fold = nullptr, *t = nullptr;
+        float2 *spec = nullptr;
+        hcv::BigFFTWork big;
+        size_t fold_elems = 0, t_elems = 0, spec_elems = 0, big_elems = 0;
+        void release()
         {
-            dst[i] = in[off + fold_size - 1 - i];
-            dst[fold_size + size + i] = in[size - off - 1 - i];
+            if (fold) (void) hipFree(fold);
+            if (t) (void) hipFree(t);
+            if (spec) (void) hipFree(spec);
+            if (big.a) (void) hipFree(big.a);
+            if (big.b) (void) hipFree(big.b);
+            *this = SpectralWork();
         }
-    }
+        // grow-only; false on allocation failure
+        bool reserve(int dev, unsigned log2n, std::string *err)
+        {
+            const size_t fft = size_t(1) << log2n, half = fft >> 1;
+            auto grow = [](auto *&p, size_t &have, size_t want)
+            {
+                if (have >= want) return true;
+                if (p) (void) hipFree(p);
+                p = nullptr;
+                have = 0;
+                if (hipMalloc(&p, sizeof(*p) * want) != hipSuccess) return false;
+                have = want;
+                return true;
+            };
+            if (!grow(fold, fold_elems, fft) || !grow(t, t_elems, fft) || !grow(spec, spec_elems, 2 * half)) return false;
+            if (hcv::is_big_fft((int) log2n))
+            {
+                int l1, l2;
+                hcv::big_fft_split((int) log2n, l1, l2);
+                big.tw1 = hcv::twiddles(dev, l1 + 1, err);
+                big.tw2 = hcv::twiddles(dev, l2 + 1, err);
+                if (!big.tw1 || !big.tw2) return false;
+                if (big_elems < half)
+                {
+                    if (big.a) (void) hipFree(big.a);
+                    if (big.b) (void) hipFree(big.b);
+                    big.a = big.b = nullptr;
+                    big_elems = 0;
+                    if (hipMalloc(&big.a, sizeof(float2) * half) != hipSuccess || hipMalloc(&big.b, sizeof(float2) * half) != hipSuccess) return false;
+                    big_elems = half;
+                }
+                big.elems = big_elems;
+            }
+            return true;
+        }
+    };
 }
 
 extern "C" size_t hcv_spectral_size(size_t size1, size_t size2, int mode)                      // calc_conv_corr_size, :549-560
@@ -979,55 +1022,42 @@ extern "C" size_t hcv_spectral_size(size_t size1, size_t size2, int mode)       
     return mode != EDGE_LINEAR ? s.mx : s.linear;
 }
 
-static int spectral_binary(const float *in1, size_t n1, const float *in2, size_t n2, int mode, bool correlate, float *out)
+// Both operands and the result are device-resident; everything is enqueued on `st`.
+static bool spectral_core(int dev, const float *d1, size_t n1, const float *d2, size_t n2, int mode, bool correlate, float *dout, SpectralWork &w,
+                          hipStream_t st)
 {
-    const size_t result = hcv_spectral_size(n1, n2, mode);
-    if (!result) return 0;                                      // the reference returns without touching `out` (:651-652)
-    if (hcv_device_count() <= 0)
-    {
-        set_error("no HIP device available (no CPU fallback)");
-        return -1;
-    }
-    if (gDefaultDevice >= 0) (void) hipSetDevice(gDefaultDevice);
-    int dev = 0;
-    (void) hipGetDevice(&dev);
-
     const OpSizes s = op_sizes(n1, n2, mode);
     // the device FFTs start at 32 points; a larger circular size is equivalent as long as every index below uses it
     const unsigned log2n = std::max(s.fft_log2, 5u);
     const size_t fft = size_t(1) << log2n, half = fft >> 1;
-
-    std::vector<float> host(2 * fft, 0.f);
-    float *h1 = host.data(), *h2 = host.data() + fft;
-    const size_t fold_size = s.mn >> 1;
-    const bool repeat = mode == EDGE_FOLD_REPEAT;
-    if (s.fold && n1 >= n2) copy_fold(h1, in1, n1, fold_size, repeat); else std::memcpy(h1, in1, sizeof(float) * n1);
-    if (s.fold && n1 < n2) copy_fold(h2, in2, n2, fold_size, repeat); else std::memcpy(h2, in2, sizeof(float) * n2);
-
     std::string err;
     const float2 *tw = hcv::twiddles(dev, (int) log2n, &err);
-    if (!tw)
+    if (!tw || !w.reserve(dev, log2n, &err))
     {
-        set_error(err);
-        return -1;
+        set_error(err.empty() ? "spectral_processor: device allocation failed" : err);
+        return false;
     }
     bool ok = true;
-    float *din = nullptr, *dt = nullptr, *dout = nullptr;
-    float2 *dspec = nullptr;
-    ScopedBigWork big(dev, log2n, 2);
-    ok = big.ok;
-    if (ok) HCV_API_TRY(hipMalloc(&din, sizeof(float) * 2 * fft));
-    if (ok) HCV_API_TRY(hipMalloc(&dspec, sizeof(float2) * 2 * half));
-    if (ok) HCV_API_TRY(hipMalloc(&dt, sizeof(float) * fft));
-    if (ok) HCV_API_TRY(hipMalloc(&dout, sizeof(float) * result));
-    if (ok) HCV_API_TRY(hipMemcpy(din, host.data(), sizeof(float) * 2 * fft, hipMemcpyHostToDevice));
-    if (ok) HCV_API_TRY(hcv::launch_rfft_rows((int) log2n, din, (long long) fft, (long long) fft, 2, dspec, tw, &big.w, nullptr));
-    if (ok) HCV_API_TRY(hcv::launch_spectral_pointwise(dspec, dspec + half, (int) half, 0.25f / (float) fft, correlate ? 1 : 0, nullptr));
-    if (ok) HCV_API_TRY(hcv::launch_rifft_rows((int) log2n, dspec, 1, dt, tw, &big.w, nullptr));
+    // operands: the longer one is mirrored at both ends in the fold modes (copy_fold, :361-377); the FFT loader zero-pads
+    const size_t fold_size = s.mn >> 1;
+    const int fold_off = mode == EDGE_FOLD_REPEAT ? 0 : 1;
+    const float *row1 = d1, *row2 = d2;
+    size_t len1 = n1, len2 = n2;
+    if (s.fold)
+    {
+        const bool first = n1 >= n2;
+        HCV_API_TRY(hcv::launch_fold_copy(w.fold, first ? d1 : d2, (long long) (first ? n1 : n2), (long long) fold_size, fold_off, st));
+        (first ? row1 : row2) = w.fold;
+        (first ? len1 : len2) += 2 * fold_size;
+    }
+    if (ok) HCV_API_TRY(hcv::launch_rfft_rows((int) log2n, row1, (long long) len1, (long long) len1, 1, w.spec, tw, &w.big, st));
+    if (ok) HCV_API_TRY(hcv::launch_rfft_rows((int) log2n, row2, (long long) len2, (long long) len2, 1, w.spec + half, tw, &w.big, st));
+    if (ok) HCV_API_TRY(hcv::launch_spectral_pointwise(w.spec, w.spec + half, (int) half, 0.25f / (float) fft, correlate ? 1 : 0, st));
+    if (ok) HCV_API_TRY(hcv::launch_rifft_rows((int) log2n, w.spec, 1, w.t, tw, &w.big, st));
 
     auto seg = [&](size_t o_off, size_t off, size_t n, int op)
     {
-        if (ok) HCV_API_TRY(hcv::launch_segment_op(dout, dt, (long long) o_off, (long long) off, (long long) n, op, nullptr));
+        if (ok) HCV_API_TRY(hcv::launch_segment_op(dout, w.t, (long long) o_off, (long long) off, (long long) n, op, st));
     };
     auto copy = [&](size_t o_off, size_t off, size_t n) { seg(o_off, off, n, 0); };
     auto wrap = [&](size_t o_off, size_t last, size_t n) { seg(o_off, last - n, n, 1); };     // adds t[last-n .. last)
@@ -1089,11 +1119,59 @@ static int spectral_binary(const float *in1, size_t n1, const float *in2, size_t
                 break;
         }
     }
+    return ok;
+}
+
+static bool spectral_ready(size_t n1, size_t n2, int mode, int &dev, size_t &result)
+{
+    result = hcv_spectral_size(n1, n2, mode);
+    if (!result) return false;                                  // the reference returns without touching `out` (:651-652)
+    if (hcv_device_count() <= 0)
+    {
+        set_error("no HIP device available (no CPU fallback)");
+        result = (size_t) -1;
+        return false;
+    }
+    if (gDefaultDevice >= 0) (void) hipSetDevice(gDefaultDevice);
+    (void) hipGetDevice(&dev);
+    return true;
+}
+
+static int spectral_binary(const float *in1, size_t n1, const float *in2, size_t n2, int mode, bool correlate, float *out)
+{
+    int dev = 0;
+    size_t result = 0;
+    if (!spectral_ready(n1, n2, mode, dev, result)) return result == (size_t) -1 ? -1 : 0;
+    bool ok = true;
+    float *d1 = nullptr, *d2 = nullptr, *dout = nullptr;
+    SpectralWork w;
+    HCV_API_TRY(hipMalloc(&d1, sizeof(float) * n1));
+    if (ok) HCV_API_TRY(hipMalloc(&d2, sizeof(float) * n2));
+    if (ok) HCV_API_TRY(hipMalloc(&dout, sizeof(float) * result));
+    if (ok) HCV_API_TRY(hipMemcpy(d1, in1, sizeof(float) * n1, hipMemcpyHostToDevice));
+    if (ok) HCV_API_TRY(hipMemcpy(d2, in2, sizeof(float) * n2, hipMemcpyHostToDevice));
+    ok = ok && spectral_core(dev, d1, n1, d2, n2, mode, correlate, dout, w, nullptr);
     if (ok) HCV_API_TRY(hipMemcpy(out, dout, sizeof(float) * result, hipMemcpyDeviceToHost));
-    if (din) (void) hipFree(din);
-    if (dspec) (void) hipFree(dspec);
-    if (dt) (void) hipFree(dt);
+    if (d1) (void) hipFree(d1);
+    if (d2) (void) hipFree(d2);
     if (dout) (void) hipFree(dout);
+    w.release();
+    return ok ? 0 : -1;
+}
+
+// HBM-resident operands: scratch is cached per device (grow-only) and the calls of one device are serialised by a mutex
+// while they enqueue; calls on different streams that overlap in time must be ordered by the caller.
+static int spectral_binary_dev(const float *d1, size_t n1, const float *d2, size_t n2, int mode, bool correlate, float *dout, void *stream, int sync)
+{
+    int dev = 0;
+    size_t result = 0;
+    if (!spectral_ready(n1, n2, mode, dev, result)) return result == (size_t) -1 ? -1 : 0;
+    static std::mutex mutex;
+    static std::map<int, SpectralWork> cache;
+    std::lock_guard<std::mutex> g(mutex);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    bool ok = spectral_core(dev, d1, n1, d2, n2, mode, correlate, dout, cache[dev], st);
+    if (ok && sync) HCV_API_TRY(hipStreamSynchronize(st));
     return ok ? 0 : -1;
 }
 
@@ -1105,6 +1183,16 @@ extern "C" int hcv_spectral_convolve_f32(const float *in1, size_t size1, const f
 extern "C" int hcv_spectral_correlate_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out)
 {
     return spectral_binary(in1, size1, in2, size2, mode, true, out);
+}
+
+extern "C" int hcv_spectral_convolve_f32_dev(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out, void *stream, int sync)
+{
+    return spectral_binary_dev(in1, size1, in2, size2, mode, false, out, stream, sync);
+}
+
+extern "C" int hcv_spectral_correlate_f32_dev(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out, void *stream, int sync)
+{
+    return spectral_binary_dev(in1, size1, in2, size2, mode, true, out, stream, sync);
 }
 
 // ------------------------------------------------------------------------------------------------ the full FFT surface (next row 2)

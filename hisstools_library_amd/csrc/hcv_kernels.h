@@ -86,6 +86,7 @@ namespace hcv
     // ---- one-shot spectral convolution / correlation ----
     hipError_t launch_spectral_pointwise(float2 *a, const float2 *b, int M, float scale, int correlate, hipStream_t st);
     hipError_t launch_segment_op(float *out, const float *t, long long o_off, long long off, long long n, int op, hipStream_t st);
+    hipError_t launch_fold_copy(float *dst, const float *in, long long n, long long fold, int off, hipStream_t st);
     hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st);
     hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st);
     hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st);

@@ -559,6 +559,21 @@ __global__ void segment_op_kernel(float *__restrict__ out, const float *__restri
     }
 }
 
+// copy_fold of the fold edge modes (SpectralProcessor.hpp:361-377): dst = [mirrored head | in | mirrored tail], the mirrors
+// `fold` samples long, including the edge sample itself when off == 0 (FoldRepeat) and excluding it when off == 1 (Fold)
+__global__ void fold_copy_kernel(float *__restrict__ dst, const float *__restrict__ in, long long n, long long fold, int off)
+{
+    const long long total = n + 2 * fold;
+    for (long long i = blockIdx.x * (long long) blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+    {
+        long long src;
+        if (i < fold) src = off + fold - 1 - i;
+        else if (i < fold + n) src = i - fold;
+        else src = n - off - 1 - (i - fold - n);
+        dst[i] = in[src];
+    }
+}
+
 // ================================================================================================
 // launchers
 // ================================================================================================
@@ -740,6 +755,14 @@ hipError_t launch_segment_op(float *out, const float *t, long long o_off, long l
     if (n <= 0) return hipSuccess;
     const int grid = (int) std::min<long long>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(segment_op_kernel, dim3(grid), dim3(256), 0, st, out, t, o_off, off, n, op);
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_copy(float *dst, const float *in, long long n, long long fold, int off, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int grid = (int) std::min<long long>((n + 2 * fold + 255) / 256, 2048);
+    hipLaunchKernelGGL(fold_copy_kernel, dim3(grid), dim3(256), 0, st, dst, in, n, fold, off);
     return hipGetLastError();
 }
 

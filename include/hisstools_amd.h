@@ -172,6 +172,11 @@ HCV_API void hcv_convolver_clear_stats(hcv_convolver *h);
 HCV_API size_t hcv_spectral_size(size_t size1, size_t size2, int mode);
 HCV_API int hcv_spectral_convolve_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out);
 HCV_API int hcv_spectral_correlate_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out);
+/* the same with all three buffers resident in HBM (device pointers), enqueued on `stream` (a hipStream_t, NULL = default);
+ * `out` must hold hcv_spectral_size(...) floats.  Scratch is cached per device; overlapping calls on different streams must
+ * be ordered by the caller. */
+HCV_API int hcv_spectral_convolve_f32_dev(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out, void *stream, int sync);
+HCV_API int hcv_spectral_correlate_f32_dev(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out, void *stream, int sync);
 
 /* ---------------------------------------------------------------- the full hisstools_* FFT surface (second "next" row)
  * Every transform of HISSTools_FFT.h:87-369 — float and double, complex and real, in place on split data or out of

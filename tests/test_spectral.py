@@ -117,3 +117,26 @@ def test_gpu_sizes_and_limits(sp):
     assert sp.convolved_size(0, 4, 0) == 0
     assert sp.convolved_size(1 << 20, 2, 0) == 0                  # would need a 2^21-point FFT: beyond the engine's maximum
     assert sp.convolve(np.zeros(0, np.float32), np.ones(3, np.float32), 0).size == 0
+
+
+@pytest.mark.gpu
+def test_gpu_device_resident_operands(oracle):
+    """hcv_spectral_*_f32_dev: operands and result in HBM, on a side stream, every edge mode, sizes on both sides of the
+    LDS limit; repeated calls re-use the cached scratch."""
+    torch = pytest.importorskip("torch")
+    from hisstools_library_amd import spectral_processor
+    sp = spectral_processor()
+    rng = np.random.default_rng(4)
+    st = torch.cuda.Stream()
+    for n1, n2 in ((1000, 129), (129, 1000), (40000, 30000), (7, 7)):
+        a, b = rng.uniform(-1, 1, n1).astype(np.float32), rng.uniform(-1, 1, n2).astype(np.float32)
+        da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        for mode in range(5):
+            for corr in (False, True):
+                want = oracle.spectral_correlate(a, b, mode) if corr else oracle.spectral_convolve(a, b, mode)
+                out = torch.full((want.size,), 7.0, device="cuda")
+                torch.cuda.synchronize()
+                sp.convolve_dev(da.data_ptr(), n1, db.data_ptr(), n2, out.data_ptr(), mode, corr, st.cuda_stream, True)
+                got = out.cpu().numpy()
+                peak = float(np.abs(want).max()) or 1.0
+                assert float(np.abs(got - want).max()) / peak <= TOL * (1 if max(n1, n2) < 10000 else 4), (n1, n2, mode, corr)

@@ -305,23 +305,14 @@ struct LdsFFT
     }
 };
 
-// Threads cooperating on one transform and transforms per workgroup.  Long transforms get one radix-16 butterfly per
-// thread, up to 1024 threads (16 waves keep enough loads in flight when a single 8192- or 16384-point transform owns the
-// CU's LDS); short ones (M <= HCV_FFT_SMALL) get M / HCV_FFT_DIV_SMALL threads, which shortens the tail passes.
-#ifndef HCV_FFT_SMALL
-#define HCV_FFT_SMALL 0
-#endif
-#ifndef HCV_FFT_DIV_SMALL
-#define HCV_FFT_DIV_SMALL 16
-#endif
-#ifndef HCV_FFT_WG
-#define HCV_FFT_WG 256
-#endif
-template <int LOG2M, int WG = HCV_FFT_WG> struct FFTGeom
+// Threads cooperating on one transform and transforms per workgroup: one radix-16 butterfly per thread, up to 1024
+// threads (16 waves keep enough loads in flight when a single 8192- or 16384-point transform owns the CU's LDS), in
+// workgroups of at least WG threads.  (Measured alternatives: M/4 threads for short transforms and 64-thread workgroups —
+// equal on the engine's workloads, slower on batched transforms.)
+template <int LOG2M, int WG = 256> struct FFTGeom
 {
     static constexpr int M = 1 << LOG2M;
-    static constexpr int DIV = M <= HCV_FFT_SMALL ? HCV_FFT_DIV_SMALL : 16;
-    static constexpr int TG = (M / DIV) < 1 ? 1 : ((M / DIV) < 1024 ? (M / DIV) : 1024);
+    static constexpr int TG = (M / 16) < 1 ? 1 : ((M / 16) < 1024 ? (M / 16) : 1024);
     static constexpr int THREADS = TG > WG ? TG : WG;
     static constexpr int G = THREADS / TG;
 };

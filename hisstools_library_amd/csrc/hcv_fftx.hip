@@ -24,10 +24,6 @@
 #include <mutex>
 #include <vector>
 
-#ifndef FX_WG
-#define FX_WG 256
-#endif
-
 namespace hcv
 {
 
@@ -170,15 +166,13 @@ namespace
 
     // -------------------------------------------------------------------------------------------- LDS-resident transforms
 
-    // minimum workgroup size (threads) of the LDS-resident kernel
-    template <class T, int LOG2M> __host__ __device__ constexpr int fx_wg() { return FX_WG; }
 
     // second launch bound = waves per SIMD the register budget must allow (HIP semantics): 4 -> 128 VGPRs in float
     template <class T, int LOG2M>
-    __global__ __launch_bounds__((FFTGeom<LOG2M, fx_wg<T, LOG2M>()>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a0, const typename Cx<T>::type *__restrict__ tw)
+    __global__ __launch_bounds__((FFTGeom<LOG2M>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a0, const typename Cx<T>::type *__restrict__ tw)
     {
         typedef typename Cx<T>::type C;
-        typedef FFTGeom<LOG2M, fx_wg<T, LOG2M>()> Gm;
+        typedef FFTGeom<LOG2M> Gm;
         constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
         extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
         C *lds = reinterpret_cast<C *>(fx_raw);
@@ -194,10 +188,6 @@ namespace
         const int soff = UNI ? 0 : g * (int) a.sstride, doff = UNI ? 0 : g * (int) a.dstride;
         const LdsBuf<C> s = { lds + g * lds_padded(M) };
         const FxLoad<T, M> ld = { a, soff, tw, live };
-#ifdef FX_SKIP_FFT
-        for (int n = t; n < M; n += TG) if (live) fx_store<T, C>(a, doff, n, ld(n));
-        return;
-#endif
         if (a.store == S_POST)
         {
             // the real post pass pairs bin k with bin M-k: finish in LDS, then combine
@@ -475,7 +465,7 @@ namespace
     template <class T, int L> hipError_t launch_lds(const FxK<T> &k, const typename Cx<T>::type *tw, hipStream_t st)
     {
         typedef typename Cx<T>::type C;
-        typedef FFTGeom<L, fx_wg<T, L>()> Gm;
+        typedef FFTGeom<L> Gm;
         const size_t lds = sizeof(C) * lds_padded(Gm::M) * Gm::G;
         hipError_t e = allow_big_lds(fx_lds_kernel<T, L>, lds);
         if (e != hipSuccess) return e;

@@ -243,10 +243,6 @@ __device__ __forceinline__ void stage_spectrum(LdsBuf<float2> s, int tid, const 
 //   Y: [ksplit][T][nout][M] float2 partial sums (summed here)
 // ------------------------------------------------------------------------------------------------
 
-#ifndef HCV_OLA_ATOMIC
-#define HCV_OLA_ATOMIC 1
-#endif
-
 // last-pass sink: result k = (x[2k+1], x[2k]); the second half of the frame is added to the timeline ring
 struct OverlapAddStore
 {
@@ -263,16 +259,8 @@ struct OverlapAddStore
         // would chain the eight updates of a thread (the compiler must assume they alias), each a round trip to an HBM
         // that the tail MAC keeps saturated.  No-return hardware float atomics are fire-and-forget.
         float *d = row + ((base + 2LL * k) & mask);
-#if HCV_OLA_ATOMIC
         unsafeAtomicAdd(d, v.y * scale);
         unsafeAtomicAdd(d + 1, v.x * scale);
-#else
-        float2 *d2 = reinterpret_cast<float2 *>(d);
-        float2 cur = *d2;
-        cur.x += v.y * scale;
-        cur.y += v.x * scale;
-        *d2 = cur;
-#endif
     }
 };
 

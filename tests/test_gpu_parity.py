@@ -702,3 +702,36 @@ def test_config5_shape_16x16_60s_device_resident(H):
         assert rel_err(y[o], t) < TOL_SUM
     st = c.stage_stats()
     assert st[-1]["fft_size"] == 16384 and st[-1]["partitions"] == 703
+
+
+def test_create_destroy_cycles_do_not_leak(H, oracle):
+    """300 engines created, loaded, run and destroyed (plus capacity growth and FFT-surface scratch): device memory in use
+    must come back to where it started (within the allocator's granularity), and nothing may crash."""
+    torch = pytest.importorskip("torch")
+    import hisstools_library_amd.fft as F
+    h, x = oracle.synth_ir(1, 1, 30000), oracle.synth_audio(1, 4096)
+    xs = np.stack([x, x])
+
+    def cycle(k):
+        c = H.Convolver(2, 2, k % 3)
+        for i in range(2):
+            assert c.set(i, i, h[: 1000 + 97 * k], True) == 0
+        c.run(xs, 2, 512)
+        assert c.set(0, 1, h, True) == 0                         # grows the tail capacity
+        c.run(xs, 2, 4096)
+        del c
+        m = H.MonoConvolve(5000, 0)
+        m.set(h[:5000], True)
+        m.run(x, 256)
+        del m
+        F.hisstools_fft(np.zeros(1 << 16, np.float32), np.zeros(1 << 16, np.float32), 16)
+
+    for k in range(20):                                          # warm the caches (twiddles, FFT scratch, allocator pools)
+        cycle(k)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(300):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned after 300 create/destroy cycles"

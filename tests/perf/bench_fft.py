@@ -7,7 +7,7 @@ transformed in one call; time = HIP events on the launch stream, best of `--reps
 read + one write of the operands (in place: 2 x M complex values), so achieved GB/s = batch * bytes / time.  Four-step
 sizes move the data through HBM twice more (scratch), which the figure deliberately does not credit.
 
-    python tools/bench_fft.py [--json profiles/r01_fft_surface.json] [--gib 1.0] [--cpu]
+    python tests/perf/bench_fft.py [--json profiles/r01_fft_surface.json] [--gib 1.0] [--cpu]
 """
 import argparse
 import json
@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import hisstools_library_amd.fft as F  # noqa: E402
 

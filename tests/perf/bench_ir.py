@@ -6,7 +6,7 @@ Zero/Center x Mix/Min/Max/Lin modes), with the reference's CPU time beside it.
 A batch of spectra big enough to defeat the 256 MiB Infinity Cache (`--gib` of operands) is processed in place in one
 call; time = HIP events on the launch stream, best of --reps.  Algorithmic bytes = one read + one write of the spectra.
 
-    python tools/bench_ir.py [--json profiles/r01_ir_functions.json] [--cpu]
+    python tests/perf/bench_ir.py [--json profiles/r01_ir_functions.json] [--cpu]
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import hisstools_library_amd.spectral_functions as S  # noqa: E402
 

@@ -5,7 +5,7 @@ FFTs, one bin-wise product, one inverse FFT and the edge arrangement; algorithmi
 written once (4 bytes per sample), so the GB/s figure is small by construction — the useful numbers are milliseconds per
 call and output samples per second.
 
-    python tools/bench_spectral.py [--json profiles/r01_spectral_convolve.json] [--cpu]
+    python tests/perf/bench_spectral.py [--json profiles/r01_spectral_convolve.json] [--cpu]
 """
 import argparse
 import json
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hisstools_library_amd import spectral_processor, EdgeMode  # noqa: E402
 

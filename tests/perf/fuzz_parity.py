@@ -3,7 +3,7 @@
 latency modes, call-size patterns and mid-stream control calls.  Runs for --seconds and prints one line per case; exits 1 on
 the first mismatch (with the seed to reproduce it).
 
-    python tools/fuzz_parity.py [--seconds 120] [--seed 1]
+    python tests/perf/fuzz_parity.py [--seconds 120] [--seed 1]
 
 Control calls are restricted to those whose effect is defined independently of the reference's random FFT phases and of this
 engine's hop-granular per-pair fence: full resets, sets before streaming and clears; per-pair sets mid-stream
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401,E402  (one HIP runtime for both libraries)

@@ -1,4 +1,4 @@
-"""Randomised differential parity (tools/fuzz_parity.py): random matrices, IR lengths, latency modes, call-size patterns and
+"""Randomised differential parity (tests/perf/fuzz_parity.py): random matrices, IR lengths, latency modes, call-size patterns and
 full resets against the CPU oracle.  The tool has been run for 5000+ cases (worst relative error 1.8e-6); the suite runs a
 fixed slice of the same seeds so that a regression shows up with a seed to reproduce it."""
 import os
@@ -7,7 +7,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
 
 pytestmark = pytest.mark.gpu
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick FFT kernel tuning run on the GPU box: prints one compact line per case
-python tools/bench_fft.py --quick --reps 3 2>/dev/null | python -c "
+python tests/perf/bench_fft.py --quick --reps 3 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     try: r=json.loads(l)

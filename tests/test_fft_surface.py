@@ -286,3 +286,50 @@ def test_gpu_bad_descriptors_fail_loudly():
         F.hisstools_fft(np.zeros(1 << 23, np.float32), np.zeros(1 << 23, np.float32), 23)      # complex log2 > 22
     with pytest.raises(TypeError):
         F.hisstools_rfft(np.zeros(8, np.float64), 3, out_dtype=np.float32)
+
+
+@pytest.mark.gpu
+def test_gpu_random_batches_with_padded_rows(oracle):
+    """Random operation / precision / size / batch, rows wider than the transform (stride > length, so the strided
+    addressing of every kernel family is exercised): each row must equal the single transform of that row and the padding
+    columns must come back untouched."""
+    import hisstools_library_amd.fft as F
+    rng = np.random.default_rng(2026)
+    for case in range(120):
+        prec = "f32" if rng.random() < 0.5 else "f64"
+        dt = np.float32 if prec == "f32" else np.float64
+        op = ["fft", "ifft", "rfft", "rifft", "rifft_zip", "rfft_zip"][int(rng.integers(0, 6))]
+        l2 = int(rng.integers(1, 17))
+        n = 1 << l2
+        length = n if op in ("fft", "ifft") else n >> 1
+        if op == "rfft_zip":
+            length = int(rng.integers(1, n + 1))
+        batch = int(rng.integers(1, 40 if l2 < 12 else 4))
+        pad = int(rng.integers(0, 9))
+        a = rng.uniform(-1, 1, (batch, length + pad)).astype(dt)
+        b = rng.uniform(-1, 1, (batch, length + pad)).astype(dt)
+        if op == "fft":
+            got = F.hisstools_fft(a, b, l2)
+        elif op == "ifft":
+            got = F.hisstools_ifft(a, b, l2)
+        elif op == "rfft":
+            got = F.hisstools_rfft_split(a, b, l2)
+        elif op == "rifft":
+            got = F.hisstools_rifft_split(a, b, l2)
+        elif op == "rifft_zip":
+            got = F.hisstools_rifft(a, b, l2)
+        else:
+            got = F.hisstools_rfft(a, l2, in_length=length)
+        for r in {0, batch // 2, batch - 1}:
+            if op == "rfft_zip":
+                want = oracle.fft_surface(op, prec, l2, a[r, :length], in_length=length)
+                row = (got[0][r], got[1][r])
+            elif op == "rifft_zip":
+                want = oracle.fft_surface(op, prec, l2, a[r, :length], b[r, :length])
+                row = got[r]
+            else:
+                want = oracle.fft_surface(op, prec, l2, a[r, :length], b[r, :length])
+                row = (got[0][r, :length], got[1][r, :length])
+                if pad:
+                    assert np.array_equal(got[0][r, length:], a[r, length:]) and np.array_equal(got[1][r, length:], b[r, length:]), (case, op, "padding")
+            assert err(row, want) <= tol(prec, l2), (case, op, prec, l2, batch, pad, err(row, want))

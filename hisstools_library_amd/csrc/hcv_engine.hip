@@ -755,8 +755,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         }
         // measured only to pay when the block carries exactly one tail hop (at two hops per block the hop-tiled tail already
         // shares the chip better: ns64 at 16384-sample blocks 376 ungated vs 357 gated Msamples/s)
-        const Stage &tl = *mStages.back();
-        const bool one_tail_hop = (n0 + B) / tl.M - n0 / tl.M == 1;
+        const bool one_tail_hop = !mStages.empty() && (n0 + B) / mStages.back()->M - n0 / mStages.back()->M == 1;
         tail_gate = (one_tail_hop && small_bytes >= 64.0 * 1048576.0 && tail_bytes >= 12.0 * small_traffic) ? 1 : 0;
     }
     hipEvent_t gate = nullptr;

@@ -109,8 +109,7 @@ struct Engine::Stage
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream (the MAC stream)
-    hipStream_t streamF = nullptr, streamI = nullptr;   // forward-FFT / inverse-FFT side streams of a split (large) stage
-    hipEvent_t fft_done[2] = { nullptr, nullptr }, mac_done[2] = { nullptr, nullptr };
+    hipEvent_t mac_done[2] = { nullptr, nullptr };     // the stage's spectral_mac of a block has finished (tail gate)
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
@@ -316,16 +315,13 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
     HCV_TRY(hipMemset(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len));
     if (mOneStream)
-        st.stream = st.streamF = st.streamI = mStream;
+        st.stream = mStream;
     else
     {
         HCV_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
-        HCV_TRY(hipStreamCreateWithFlags(&st.streamF, hipStreamNonBlocking));
-        HCV_TRY(hipStreamCreateWithFlags(&st.streamI, hipStreamNonBlocking));
     }
     for (int k = 0; k < 2; k++)
     {
-        HCV_TRY(hipEventCreateWithFlags(&st.fft_done[k], hipEventDisableTiming));
         HCV_TRY(hipEventCreateWithFlags(&st.mac_done[k], hipEventDisableTiming));
     }
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&st.done[k], hipEventDisableTiming));
@@ -339,14 +335,10 @@ void Engine::free_stage(Stage &st)
     for (int k = 0; k < 2; k++)
     {
         if (st.Yq[k]) (void) hipFree(st.Yq[k]);
-        if (st.fft_done[k]) (void) hipEventDestroy(st.fft_done[k]);
         if (st.mac_done[k]) (void) hipEventDestroy(st.mac_done[k]);
         st.Yq[k] = nullptr;
-        st.fft_done[k] = st.mac_done[k] = nullptr;
+        st.mac_done[k] = nullptr;
     }
-    if (st.streamF && st.streamF != mStream) (void) hipStreamDestroy(st.streamF);
-    if (st.streamI && st.streamI != mStream) (void) hipStreamDestroy(st.streamI);
-    st.streamF = st.streamI = nullptr;
     if (st.hv) (void) hipFree(st.hv);
     if (st.timeline) (void) hipFree(st.timeline);
     if (st.Ypre) (void) hipFree(st.Ypre);
@@ -375,8 +367,6 @@ Engine::~Engine()
     for (Stage *st : mStages)
     {
         if (st->stream) (void) hipStreamSynchronize(st->stream);
-        if (st->streamF) (void) hipStreamSynchronize(st->streamF);
-        if (st->streamI) (void) hipStreamSynchronize(st->streamI);
     }
     if (mStream) (void) hipStreamSynchronize(mStream);
     for (Stage *st : mStages)
@@ -829,29 +819,15 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             continue;
         }
 
-        // A large stage's forward FFTs and inverse side can run off its MAC stream so that its MACs go back to back:
-        //   HCV_SPLIT=2  forward FFT on the (otherwise idle) input stream right behind the scatter, reduce + inverse FFT on
-        //                the main stream in front of emit — no additional streams
-        //   HCV_SPLIT=1  two dedicated side streams (measured slower: every extra active stream competes for hardware queues)
-        static const int split_mode = std::getenv("HCV_SPLIT") ? std::atoi(std::getenv("HCV_SPLIT")) : 0;
-        size_t live = 0;
-        for (uint32_t p : st.pact) live += p;
-        const bool split = split_mode > 0 && si + 1 == mStages.size() && live * st.M * sizeof(float2) >= (size_t(128) << 20);
-        hipStream_t sM = st.stream;
-        hipStream_t sF = !split ? st.stream : (split_mode == 2 ? mInStream : st.streamF);
-        hipStream_t sI = !split ? st.stream : (split_mode == 2 ? mStream : st.streamI);
+        // one stream per stage: forward FFT, MAC, inverse.  (Side streams for a large stage's FFTs were built and measured
+        // twice — dedicated ones and the input / main streams — and were slower each time: c5 2.12 / 2.33 vs 1.98 ms per step.)
+        hipStream_t sM = st.stream, sF = st.stream, sI = st.stream;
         st.Y = st.Yq[q];
 
         HCV_TRY(hipStreamWaitEvent(sF, mEvInput[q], 0));
         if (gate && tail_gate >= 2) HCV_TRY(hipStreamWaitEvent(sF, gate, 0));
         HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
         if (gate && tail_gate == 1) HCV_TRY(hipStreamWaitEvent(sM, gate, 0));
-        if (split)
-        {
-            HCV_TRY(hipEventRecord(st.fft_done[q], sF));
-            HCV_TRY(hipStreamWaitEvent(sM, st.fft_done[q], 0));
-        }
-
         if (head_here)
         {
             // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
@@ -944,12 +920,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
                 st.last_ot = (uint32_t) pl.ot;
             }
         }
-        if (split)
-        {
-            HCV_TRY(hipEventRecord(st.mac_done[q], sM));
-            HCV_TRY(hipStreamWaitEvent(sI, st.mac_done[q], 0));
-        }
-        else if (tail_gate && sj == 0 && mStages.size() > 1 && !mOneStream && st.P && !defer && !have_pre)
+        if (tail_gate && sj == 0 && mStages.size() > 1 && !mOneStream && st.P && !defer && !have_pre)
         {
             HCV_TRY(hipEventRecord(st.mac_done[q], sM));
             gate = st.mac_done[q];

@@ -69,23 +69,22 @@ __global__ void big_load_kernel(BigLoad a, float2 *__restrict__ Z, int M, int q0
 
 // ------------------------------------------------------------------------------------------------ four-step passes
 
-constexpr int BIG_COLS = 16;       // adjacent columns per workgroup (128-byte global segments)
-constexpr int BIG_ROWS = 8;        // adjacent rows per workgroup
-
+// tiles as in hcv_fftx.hip (FourStepTile): runs of 256 bytes per row of the tile, one thread group per column / row, up to
+// 1024 threads
 template <int L1>
-__global__ __launch_bounds__(256) void big_cols_kernel(const float2 *__restrict__ Zin, float2 *__restrict__ Tout, int M2, int M,
+__global__ __launch_bounds__((FourStepTile<(1 << L1), 8>::THREADS)) void big_cols_kernel(const float2 *__restrict__ Zin, float2 *__restrict__ Tout, int M2, int M,
                                                        const float2 *__restrict__ tw1, const float2 *__restrict__ twN)
 {
     constexpr int M1 = 1 << L1;
-    constexpr int TG = (M1 / 4) < 256 ? (M1 / 4) : 256;
-    constexpr int G = 256 / TG;
+    typedef FourStepTile<M1, 8> Tile;
+    constexpr int TG = Tile::TG, G = Tile::G, BIG_COLS = Tile::TILE, NT = Tile::THREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [BIG_COLS][M1]
 
     const int col0 = blockIdx.x * BIG_COLS;
     const float2 *zin = Zin + (long long) blockIdx.y * M;
     float2 *tout = Tout + (long long) blockIdx.y * M;
 
-    for (int e = threadIdx.x; e < BIG_COLS * M1; e += 256)
+    for (int e = threadIdx.x; e < BIG_COLS * M1; e += NT)
     {
         const int c = e % BIG_COLS, n1 = e / BIG_COLS;
         LdsBuf<float2>{ lds + c * lds_padded(M1) }[n1] = zin[(long long) n1 * M2 + col0 + c];
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void big_cols_kernel(const float2 *__restrict_
     __syncthreads();
     const int g = threadIdx.x / TG, t = threadIdx.x % TG;
     for (int c0 = 0; c0 < BIG_COLS; c0 += G) LdsFFT<L1, TG>::run(LdsBuf<float2>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
-    for (int e = threadIdx.x; e < BIG_COLS * M1; e += 256)
+    for (int e = threadIdx.x; e < BIG_COLS * M1; e += NT)
     {
         const int c = e % BIG_COLS, k1 = e / BIG_COLS;
         const int n2 = col0 + c;
@@ -103,27 +102,26 @@ __global__ __launch_bounds__(256) void big_cols_kernel(const float2 *__restrict_
 }
 
 template <int L2>
-__global__ __launch_bounds__(256) void big_rows_kernel(const float2 *__restrict__ Tin, float2 *__restrict__ Zout, int M1, int M,
+__global__ __launch_bounds__((FourStepTile<(1 << L2), 8>::THREADS)) void big_rows_kernel(const float2 *__restrict__ Tin, float2 *__restrict__ Zout, int M1, int M,
                                                        const float2 *__restrict__ tw2)
 {
     constexpr int M2 = 1 << L2;
-    constexpr int TG = (M2 / 4) < 256 ? (M2 / 4) : 256;
-    constexpr int G = 256 / TG;
+    typedef FourStepTile<M2, 8> Tile;
+    constexpr int TG = Tile::TG, G = Tile::G, BIG_ROWS = Tile::TILE, NT = Tile::THREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [BIG_ROWS][M2]
 
     const int row0 = blockIdx.x * BIG_ROWS;
     const float2 *tin = Tin + (long long) blockIdx.y * M + (long long) row0 * M2;
     float2 *zout = Zout + (long long) blockIdx.y * M;
 
-    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += 256) LdsBuf<float2>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = tin[e];
+    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += NT) LdsBuf<float2>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = tin[e];
     __syncthreads();
     const int g = threadIdx.x / TG, t = threadIdx.x % TG;
     for (int r0 = 0; r0 < BIG_ROWS; r0 += G)
     {
-        // G may exceed BIG_ROWS for short rows: the surplus groups transform rows of the same tile again
-        LdsFFT<L2, TG>::run(LdsBuf<float2>{ lds + ((r0 + g) % BIG_ROWS) * lds_padded(M2) }, t, tw2);
+        LdsFFT<L2, TG>::run(LdsBuf<float2>{ lds + (r0 + g) * lds_padded(M2) }, t, tw2);
     }
-    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += 256)
+    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += NT)
     {
         const int r = e % BIG_ROWS, k2 = e / BIG_ROWS;
         zout[(long long) (row0 + r) + (long long) M1 * k2] = LdsBuf<float2>{ lds + r * lds_padded(M2) }[k2];
@@ -230,12 +228,15 @@ static hipError_t big_cfft(int log2n, float2 *a, float2 *b, int batch, const Big
     int l1, l2;
     big_fft_split(log2n, l1, l2);
     const int M = 1 << (log2n - 1), M1 = 1 << l1, M2 = 1 << l2;
-    const size_t lds1 = sizeof(float2) * BIG_COLS * lds_padded(M1), lds2 = sizeof(float2) * BIG_ROWS * lds_padded(M2);
-    dim3 gc(M2 / BIG_COLS, batch), gr(M1 / BIG_ROWS, batch);
+    size_t lds1 = 0, lds2 = 0;
+    dim3 gc, gr, bc, br;
 #define HCV_BIG_COLS(L)                                                                                                \
     case L:                                                                                                            \
+        lds1 = sizeof(float2) * FourStepTile<(1 << L), 8>::TILE * lds_padded(M1);                                      \
+        gc = dim3(M2 / FourStepTile<(1 << L), 8>::TILE, batch);                                                        \
+        bc = dim3(FourStepTile<(1 << L), 8>::THREADS);                                                                 \
         if (lds1 > 48 * 1024) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(big_cols_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds1); \
-        hipLaunchKernelGGL(big_cols_kernel<L>, gc, dim3(256), lds1, st, a, b, M2, M, w.tw1, twN);                   \
+        hipLaunchKernelGGL(big_cols_kernel<L>, gc, bc, lds1, st, a, b, M2, M, w.tw1, twN);                           \
         break;
     switch (l1)
     {
@@ -245,8 +246,11 @@ static hipError_t big_cfft(int log2n, float2 *a, float2 *b, int batch, const Big
 #undef HCV_BIG_COLS
 #define HCV_BIG_ROWS(L)                                                                                                \
     case L:                                                                                                            \
+        lds2 = sizeof(float2) * FourStepTile<(1 << L), 8>::TILE * lds_padded(M2);                                      \
+        gr = dim3(M1 / FourStepTile<(1 << L), 8>::TILE, batch);                                                        \
+        br = dim3(FourStepTile<(1 << L), 8>::THREADS);                                                                 \
         if (lds2 > 48 * 1024) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(big_rows_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2); \
-        hipLaunchKernelGGL(big_rows_kernel<L>, gr, dim3(256), lds2, st, b, a, M1, M, w.tw2);                         \
+        hipLaunchKernelGGL(big_rows_kernel<L>, gr, br, lds2, st, b, a, M1, M, w.tw2);                                 \
         break;
     switch (l2)
     {

@@ -318,4 +318,19 @@ template <int LOG2M, int WG = 256> struct FFTGeom
 };
 
 
+// Tile of one four-step workgroup: TILE adjacent columns (or rows) of P points each, all transformed at once by
+// TILE * TG threads (at most 1024).  TILE aims at 128-byte runs in each of the split arrays, within 128 KiB of LDS
+// (136 KiB with the bank padding).
+template <int P, int ELEM_BYTES> struct FourStepTile
+{
+    static constexpr int TG = P / 16 < 256 ? P / 16 : 256;
+    static constexpr int WANT = 256 / ELEM_BYTES;                       // complex elements: 128 bytes per split array
+    static constexpr int CAP = 128 * 1024 / (P * ELEM_BYTES);
+    static constexpr int TILE = CAP < WANT ? CAP : WANT;
+    static constexpr int THREADS = TILE * TG < 1024 ? TILE * TG : 1024;
+    static constexpr int G = THREADS / TG;                              // sub-transforms in flight
+    static_assert(TILE % G == 0 && THREADS % 64 == 0, "tile geometry");
+};
+
+
 } // namespace hcv

@@ -141,6 +141,12 @@ namespace hcv
         float2 *mHeadSpec = nullptr;        // [nout][nin_alloc][M0] head taps as ONE zero-latency partition of the first FFT stage
         float2 *mHeadYq[2] = { nullptr, nullptr };   // [Tmax0][nout][M0], by block parity
         bool mHeadFFT = false;              // the head may take the FFT path (taps fit one hop of the first stage)
+        // Whole-hop mode: for calls made of whole, aligned hops of the LAST stage everything in front of that stage's segment
+        // (head + shorter stages) is one extra zero-latency partition of it
+        float2 *mTailHeadSpec = nullptr;    // [nout][nin_alloc][Mlast] spectrum of IR[0 : Mlast)
+        float2 *mTailHeadYq[2] = { nullptr, nullptr };   // [TmaxLast][nout][Mlast], by block parity
+        bool mTailHead = false;             // the layout allows it (contiguous zero-latency ladder)
+        bool mTailHeadPrev = false;         // the previous block ran in whole-hop mode
         float *mTaps = nullptr;
         long long *mTdValid = nullptr;
         std::vector<uint32_t> mTdCount;     // taps per pair

@@ -273,6 +273,34 @@ bool Engine::init(const EngineCfg &cfg)
             for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mHeadYq[k], sizeof(float2) * (size_t) s0.Tmax * mCfg.nout * s0.M));
         }
     }
+    // Whole-hop mode (see enqueue_chunk): needs the zero-latency ladder — head at [0, a), every shorter stage continuing
+    // where the previous coverage ends, the last stage starting exactly one of its hops in
+    if (mStages.size() >= 2 || (mCfg.has_td && !mStages.empty()))
+    {
+        static const bool allow = !(std::getenv("HCV_TAIL_HEAD") && std::atoi(std::getenv("HCV_TAIL_HEAD")) == 0);
+        uint64_t end = 0;
+        bool ok = allow;
+        if (mCfg.has_td)
+        {
+            ok = ok && mCfg.td_offset == 0 && mCfg.td_length > 0;
+            end = mCfg.td_length;
+        }
+        for (size_t k = 0; ok && k + 1 < mStages.size(); k++)
+        {
+            const StageCfg &sc = mStages[k]->cfg;
+            ok = sc.offset == end && sc.length > 0;
+            end = sc.offset + sc.length;
+        }
+        const Stage &tl = *mStages.back();
+        ok = ok && tl.cfg.offset == end && tl.cfg.offset == tl.M && !is_big_fft(tl.log2n);
+        if (ok)
+        {
+            mTailHead = true;
+            HCV_TRY(hipMalloc(&mTailHeadSpec, sizeof(float2) * pairs * tl.M));
+            HCV_TRY(hipMemset(mTailHeadSpec, 0, sizeof(float2) * pairs * tl.M));
+            for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTailHeadYq[k], sizeof(float2) * (size_t) tl.Tmax * mCfg.nout * tl.M));
+        }
+    }
     HCV_TRY(hipDeviceSynchronize());
     return true;
 }
@@ -390,6 +418,9 @@ Engine::~Engine()
     if (mIrBuf) (void) hipFree(mIrBuf);
     if (mTaps) (void) hipFree(mTaps);
     if (mHeadSpec) (void) hipFree(mHeadSpec);
+    if (mTailHeadSpec) (void) hipFree(mTailHeadSpec);
+    for (int k = 0; k < 2; k++)
+        if (mTailHeadYq[k]) (void) hipFree(mTailHeadYq[k]);
     for (int k = 0; k < 2; k++)
         if (mHeadYq[k]) (void) hipFree(mHeadYq[k]);
     if (mTdValid) (void) hipFree(mTdValid);
@@ -582,6 +613,12 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             mTdLpad = ((mx + 15) / 16) * 16;
             any = any || taps;
         }
+        if (mTailHead)
+        {
+            Stage &tl = *mStages.back();
+            const uint64_t first = std::min<uint64_t>(len, tl.M);
+            HCV_TRY(launch_rfft_ir(tl.log2n, first ? dsrc : mHist, (long long) first, 1, mTailHeadSpec + pair * (size_t) tl.M, tl.tw, &tl.big, mStream));
+        }
         mLoaded[pair] = any ? 1 : 0;
         mPending[pair] = 1;                                                         // set() always ends in reset()
         mCtlDirty = true;
@@ -609,6 +646,7 @@ void Engine::reset_all()
 bool Engine::global_reset()
 {
     mN = 0;
+    mTailHeadPrev = false;
     mCtlDirty = true;
     HCV_TRY(hipMemsetAsync(mHist, 0, sizeof(float) * mCfg.nin * mHistLen, mStream));
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
@@ -702,9 +740,20 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
     const bool td_any = mCfg.has_td && mTdLpad > 0;
     const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
+    // Whole-hop mode: the block is made of whole, aligned hops of the last stage.  Every output sample of such a block only
+    // needs inputs that the last stage's own frames hold, so IR[0 : its hop) is served by ONE extra zero-latency partition
+    // of that stage (emitted in the hop's own slot, like the head-through-FFT of the first stage) and the head and the
+    // shorter stages — a dozen launches in latency-bound chains — are not run at all.  Entering the mode drops their
+    // pending (now duplicate) results; leaving it rebuilds their input spectra from the history ring and catches up on
+    // the one hop whose result is due in the new block (see the stage loop).
+    const size_t last = mStages.empty() ? 0 : mStages.size() - 1;
+    const bool whole_hops = mTailHead && !td_check && (n0 % mStages[last]->M) == 0 && (B % mStages[last]->M) == 0 &&
+                            !(mStages[last]->max_hv > n0 / mStages[last]->M);
+    const bool entering = whole_hops && !mTailHeadPrev, leaving = !whole_hops && mTailHeadPrev;
+    mTailHeadPrev = whole_hops;
     // hop-aligned block of a larger matrix: the head goes through the first stage's FFTs (see init)
-    const bool head_fft = td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
-    const bool td = td_any && !head_fft;
+    const bool head_fft = !whole_hops && td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
+    const bool td = td_any && !head_fft && !whole_hops;
     if (td)
     {
         HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput[q], 0));
@@ -725,7 +774,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // When the short stages fit the caches (16x16) or the tail is short (64x64 with 2 s IRs) the overlap wins and is
     // kept.  HCV_TAIL_GATE = 0 / 1 forces the choice (2: hold the forward FFTs too).
     static const int tail_gate_env = std::getenv("HCV_TAIL_GATE") ? std::atoi(std::getenv("HCV_TAIL_GATE")) : -1;
-    int tail_gate = tail_gate_env;
+    int tail_gate = whole_hops ? 0 : tail_gate_env;
     if (tail_gate < 0)
     {
         double small_bytes = 0, small_traffic = 0, tail_bytes = 0;
@@ -800,14 +849,64 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     {
         const size_t si = mStages.size() - 1 - sj;
         Stage &st = *mStages[si];
+        if (whole_hops && si != last)
+        {
+            if (entering)
+            {
+                // this stage's pending results duplicate what the last stage now computes: drop them (after the emit that
+                // may still be reading them) together with any plan of a deferred accumulation
+                HCV_TRY(hipStreamWaitEvent(st.stream, mEvEmit[q ^ 1], 0));
+                HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, st.stream));
+                HCV_TRY(hipEventRecord(st.done[q], st.stream));
+                HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+                st.pre_hop = -1;
+            }
+            continue;
+        }
         src.timeline[src.count] = st.timeline;              // the ring may still hold hops of earlier calls
         src.stride[src.count] = st.tl_len;
         src.mask[src.count] = st.tl_len - 1;
         src.count++;
-        const bool head_here = head_fft && si == 0;
+        const bool tail_head_here = whole_hops && si == last;
+        const bool head_here = (head_fft && si == 0) || tail_head_here;
+        const float2 *head_spec = tail_head_here ? mTailHeadSpec : mHeadSpec;
+        float2 *head_y = tail_head_here ? mTailHeadYq[q] : mHeadYq[q];
         if (!st.P && !head_here) continue;
         const long long h_first = n0 / st.M;
         const int T = (int) ((n0 + B) / st.M - h_first);
+        if (leaving && si != last && st.P && h_first >= 1)
+        {
+            HCV_TRY(hipStreamWaitEvent(st.stream, mEvInput[q], 0));
+            st.Y = st.Yq[q];
+            // back from whole-hop mode: this stage was not run for a while.  Rebuild the input spectra its partitions reach
+            // back to from the history ring, and compute the hop just before this block — its result is emitted during the
+            // first hop of the block (every stage has one hop of latency).
+            const long long h_lo = std::max<long long>(0, h_first - (long long) st.P);
+            HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_lo, (int) (h_first - h_lo), (int) rows_in, st.X, (int) st.R, st.tw, &st.big, st.stream));
+            MacShape sc;
+            sc.M = (int) st.M;
+            sc.R = (int) st.R;
+            sc.P = (int) std::min<long long>(st.P, h_first);
+            sc.Pcap = (int) st.Pcap;
+            sc.nin = (int) nin_act;
+            sc.nin_alloc = (int) mNinAlloc;
+            sc.nout = (int) nout_act;
+            sc.diag = mCfg.diag ? 1 : 0;
+            sc.T = 1;
+            sc.max_ksplit = (int) std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M));
+            sc.target_blocks = 0;
+            MacPlan pc;
+            mac_plan(sc, pc);
+            const bool ccheck = (h_first - 1 - st.max_hv) < (long long) st.P - 1;
+            const long long c_elems = (long long) nout_act * st.M;
+            HCV_TRY(launch_spectral_mac(sc, pc, st.X, st.Hs, st.Y, st.hv, h_first - 1, ccheck, st.stream));
+            HCV_TRY(launch_reduce_partials(st.Y, pc.ksplit, c_elems, c_elems, st.stream));
+            HCV_TRY(hipStreamWaitEvent(st.stream, mEvEmit[q], 0));        // emit(k-2) has cleared the timeline span reused now
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, c_elems, h_first - 1, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                             &st.big, st.stream));
+            HCV_TRY(hipEventRecord(st.done[q], st.stream));          // (recorded again below when this block has hops of its own)
+            HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+        }
         const bool full_matrix = nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
         if (T <= 0)
         {
@@ -845,7 +944,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             hs.target_blocks = 0;
             MacPlan hp;
             mac_plan(hs, hp);
-            HCV_TRY(launch_spectral_mac(hs, hp, st.X, mHeadSpec, mHeadYq[q], st.hv, h_first, false, sM));
+            HCV_TRY(launch_spectral_mac(hs, hp, st.X, head_spec, head_y, st.hv, h_first, false, sM));
         }
 
         // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
@@ -929,7 +1028,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
         HCV_TRY(hipStreamWaitEvent(sI, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
         if (head_here)
-            HCV_TRY(launch_rifft_overlap_add(st.log2n, mHeadYq[q], 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
                                              &st.big, sI));           // h_first - 1: emitted with NO latency (hop h at h*M)
         if (st.P)
         {

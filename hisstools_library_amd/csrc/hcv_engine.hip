@@ -83,6 +83,7 @@ const float2 *twiddles(int device, int log2n, std::string *err)
 // ------------------------------------------------------------------------------------------------
 
 constexpr int kBgSlices = 16;
+constexpr int kTailHeadSplit = 8;
 
 struct Engine::Stage
 {
@@ -298,7 +299,8 @@ bool Engine::init(const EngineCfg &cfg)
             mTailHead = true;
             HCV_TRY(hipMalloc(&mTailHeadSpec, sizeof(float2) * pairs * tl.M));
             HCV_TRY(hipMemset(mTailHeadSpec, 0, sizeof(float2) * pairs * tl.M));
-            for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTailHeadYq[k], sizeof(float2) * (size_t) tl.Tmax * mCfg.nout * tl.M));
+            // (room for kTailHeadSplit k-slices: with one partition the MAC has only the input axis to split)
+            for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTailHeadYq[k], sizeof(float2) * (size_t) tl.Tmax * kTailHeadSplit * mCfg.nout * tl.M));
         }
     }
     HCV_TRY(hipDeviceSynchronize());
@@ -868,6 +870,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         src.mask[src.count] = st.tl_len - 1;
         src.count++;
         const bool tail_head_here = whole_hops && si == last;
+        int head_ksplit = 1;
         const bool head_here = (head_fft && si == 0) || tail_head_here;
         const float2 *head_spec = tail_head_here ? mTailHeadSpec : mHeadSpec;
         float2 *head_y = tail_head_here ? mTailHeadYq[q] : mHeadYq[q];
@@ -940,11 +943,12 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             hs.nout = (int) nout_act;
             hs.diag = mCfg.diag ? 1 : 0;
             hs.T = T;
-            hs.max_ksplit = 1;
+            hs.max_ksplit = tail_head_here ? kTailHeadSplit : 1;
             hs.target_blocks = 0;
             MacPlan hp;
             mac_plan(hs, hp);
             HCV_TRY(launch_spectral_mac(hs, hp, st.X, head_spec, head_y, st.hv, h_first, false, sM));
+            head_ksplit = hp.ksplit;
         }
 
         // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
@@ -1028,8 +1032,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
         HCV_TRY(hipStreamWaitEvent(sI, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
         if (head_here)
+        {
+            HCV_TRY(launch_reduce_partials(head_y, head_ksplit, (long long) T * nout_act * st.M, (long long) T * nout_act * st.M, sI));
             HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
                                              &st.big, sI));           // h_first - 1: emitted with NO latency (hop h at h*M)
+        }
         if (st.P)
         {
             if (have_pre)

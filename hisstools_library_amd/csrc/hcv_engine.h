@@ -112,6 +112,17 @@ namespace hcv
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
         size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }
         void collect_events();
+        // exact per-pair restart (hcv_ghost.hip): ghost spectra of the input before the restart, the pair's pending output retired
+        struct GhostEvent;
+        bool mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream);
+        bool retire_pair(size_t pair);
+        bool make_ghost_event(const std::vector<size_t> &pairs);
+        bool rebuild_ghost_tables();
+        void release_ghost(size_t pair);
+        void drop_ghosts();
+        bool prune_ghosts();
+        void *ghost_alloc(size_t bytes);
+        void ghost_free(void *p, size_t bytes);
 
         EngineCfg mCfg;
         int mDevice = 0;
@@ -155,6 +166,18 @@ namespace hcv
 
         // per pair
         std::vector<uint8_t> mPending, mLoaded;
+        std::vector<uint8_t> mRetired;      // the pair's pending output has already been taken out of the timelines (by set_ir)
+        std::vector<GhostEvent *> mGhostOf; // the restart whose ghost spectra the pair still needs (nullptr: none)
+        std::vector<GhostEvent *> mGhostEvents;
+        std::vector<std::pair<size_t, void *>> mGhostPool;      // released ghost-spectrum blocks (bytes, pointer), reused by size
+        float *mGhostHist = nullptr;        // [nin][mGhostLen] masked copy of the input history around a restart
+        long long mGhostLen = 0;
+        float *mRetireTmp = nullptr;        // one inverse-transformed frame of the largest stage
+        char *mGhostPin = nullptr;          // pinned staging of the device tables below
+        size_t mGhostPinBytes = 0;
+        hipEvent_t mGhostUploaded = nullptr;
+        long long mGhostPruneAt = -1;       // sample count at which the oldest restart stops mattering (-1: none)
+        uint32_t mLastNin = 0, mLastNout = 0;   // active matrix of the previous block
         long long mN = 0;                   // samples since the last global reset
         bool mProfiling = false;
         bool mOneStream = false;            // every kernel on mStream (small engines: dependency hops cost more than overlap gains)

@@ -114,12 +114,28 @@ struct Engine::Stage
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
+    // exact per-pair restart: device table of the live ghost entries of this stage, grouped by output
+    int *gh_start = nullptr;            // [nout + 1]
+    GhostEntry *gh_ent = nullptr;       // [pairs]
+    std::vector<GhostEntry> gh_host;    // mirror, in table order
+    std::vector<size_t> gh_pair;        // pair of each entry
+    int gh_count = 0;
+    long long gh_min_hr = 0, gh_max_hr = 0;
     std::vector<uint32_t> pact;
     const float2 *tw = nullptr;
     // stats
     uint64_t launches = 0, hops = 0;
     double ms = 0.0;
     uint32_t last_ksplit = 0, last_ot = 0;
+};
+
+struct Engine::GhostEvent
+{
+    long long t0 = 0;                   // sample the restart took effect at
+    int refs = 0;                       // pairs still pointing at this event
+    std::vector<int> slot;              // input row -> row of the spectra blocks (-1: not part of the restart)
+    std::vector<float2 *> spec;         // per stage: [rows][2][M], frame h at slot h & 1
+    std::vector<size_t> bytes;
 };
 
 struct Engine::EventPair
@@ -243,6 +259,8 @@ bool Engine::init(const EngineCfg &cfg)
     }
     mPending.assign(pairs, 0);
     mLoaded.assign(pairs, 0);
+    mRetired.assign(pairs, 0);
+    mGhostOf.assign(pairs, nullptr);
 
     for (const StageCfg &sc : mCfg.stages)
     {
@@ -370,6 +388,10 @@ void Engine::free_stage(Stage &st)
         st.mac_done[k] = nullptr;
     }
     if (st.hv) (void) hipFree(st.hv);
+    if (st.gh_start) (void) hipFree(st.gh_start);
+    if (st.gh_ent) (void) hipFree(st.gh_ent);
+    st.gh_start = nullptr;
+    st.gh_ent = nullptr;
     if (st.timeline) (void) hipFree(st.timeline);
     if (st.Ypre) (void) hipFree(st.Ypre);
     if (st.bg_done) (void) hipEventDestroy(st.bg_done);
@@ -399,6 +421,8 @@ Engine::~Engine()
         if (st->stream) (void) hipStreamSynchronize(st->stream);
     }
     if (mStream) (void) hipStreamSynchronize(mStream);
+    drop_ghosts();
+    for (auto &blk : mGhostPool) (void) hipFree(blk.second);
     for (Stage *st : mStages)
     {
         free_stage(*st);
@@ -433,6 +457,10 @@ Engine::~Engine()
         if (mEvEmit[k]) (void) hipEventDestroy(mEvEmit[k]);
     }
     if (mEvCtl) (void) hipEventDestroy(mEvCtl);
+    if (mGhostHist) (void) hipFree(mGhostHist);
+    if (mRetireTmp) (void) hipFree(mRetireTmp);
+    if (mGhostPin) (void) hipHostFree(mGhostPin);
+    if (mGhostUploaded) (void) hipEventDestroy(mGhostUploaded);
     if (mInStream && mInStream != mStream) (void) hipStreamDestroy(mInStream);
     if (mTdStream && mTdStream != mStream) (void) hipStreamDestroy(mTdStream);
     if (mStream) (void) hipStreamDestroy(mStream);
@@ -576,6 +604,9 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
         if (!fence_background()) return false;
         if (len && !device_ptr) HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mStream));
         const size_t pair = pair_index(in, out);
+        // what the pair still has to deliver belongs to the spectra about to be replaced: take it out of the timelines now
+        if (mLoaded[pair] && !mRetired[pair] && !retire_pair(pair)) return false;
+        mRetired[pair] = 1;                                                         // (an empty pair has nothing pending)
         bool any = false;
         for (Stage *sp : mStages)
         {
@@ -650,6 +681,7 @@ bool Engine::global_reset()
     mN = 0;
     mTailHeadPrev = false;
     mCtlDirty = true;
+    drop_ghosts();
     HCV_TRY(hipMemsetAsync(mHist, 0, sizeof(float) * mCfg.nin * mHistLen, mStream));
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     for (Stage *st : mStages)
@@ -662,6 +694,270 @@ bool Engine::global_reset()
     mTdMaxValid = 0;
     return true;
 }
+
+// ------------------------------------------------------------------------------------------------ exact per-pair restart
+// (see hcv_ghost.hip for the scheme).  All of it is control work on mStream, which every block's emit has ordered after
+// the stages' work; callers hold mMutex and have fenced the background accumulation.
+
+// HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
+// per stage and its pending output is not withdrawn) — for A/B comparison only
+static bool exact_restart()
+{
+    static const bool on = !(std::getenv("HCV_EXACT_RESTART") && std::atoi(std::getenv("HCV_EXACT_RESTART")) == 0);
+    return on;
+}
+
+void *Engine::ghost_alloc(size_t bytes)
+{
+    for (size_t k = 0; k < mGhostPool.size(); k++)
+        if (mGhostPool[k].first == bytes)
+        {
+            void *p = mGhostPool[k].second;
+            mGhostPool.erase(mGhostPool.begin() + (long) k);
+            return p;
+        }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void Engine::ghost_free(void *p, size_t bytes)
+{
+    if (p) mGhostPool.emplace_back(bytes, p);
+}
+
+void Engine::release_ghost(size_t pair)
+{
+    GhostEvent *ev = mGhostOf[pair];
+    if (!ev) return;
+    mGhostOf[pair] = nullptr;
+    if (--ev->refs > 0) return;
+    for (size_t s = 0; s < ev->spec.size(); s++) ghost_free(ev->spec[s], ev->bytes[s]);
+    mGhostEvents.erase(std::find(mGhostEvents.begin(), mGhostEvents.end(), ev));
+    delete ev;
+}
+
+void Engine::drop_ghosts()
+{
+    for (size_t p = 0; p < mGhostOf.size(); p++) release_ghost(p);
+    for (Stage *st : mStages) st->gh_count = 0;
+    mGhostPruneAt = -1;
+}
+
+// the restart of `ev` can still reach a launch of stage `st` while the current hop is at most P + 1 past the restart's
+static inline bool ghost_live(long long t0, long long now, uint32_t M, uint32_t Pcap)
+{
+    return now / M - t0 / M <= (long long) Pcap + 2;
+}
+
+bool Engine::prune_ghosts()
+{
+    bool changed = false;
+    for (size_t p = 0; p < mGhostOf.size(); p++)
+    {
+        GhostEvent *ev = mGhostOf[p];
+        if (!ev) continue;
+        bool live = false;
+        for (Stage *st : mStages) live = live || ghost_live(ev->t0, mN, st->M, st->Pcap);
+        if (!live)
+        {
+            release_ghost(p);
+            changed = true;
+        }
+    }
+    return changed ? rebuild_ghost_tables() : true;
+}
+
+bool Engine::rebuild_ghost_tables()
+{
+    const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
+    const size_t start_bytes = ((sizeof(int) * (mCfg.nout + 1) + 15) / 16) * 16;
+    const size_t per_stage = start_bytes + sizeof(GhostEntry) * pairs;
+    if (!mGhostPin)
+    {
+        mGhostPinBytes = per_stage * mStages.size();
+        HCV_TRY(hipHostMalloc(&mGhostPin, mGhostPinBytes, hipHostMallocDefault));
+        HCV_TRY(hipEventCreateWithFlags(&mGhostUploaded, hipEventDisableTiming));
+    }
+    else
+        HCV_TRY(hipEventSynchronize(mGhostUploaded));       // the previous upload has left the staging buffer
+    mGhostPruneAt = -1;
+    for (size_t si = 0; si < mStages.size(); si++)
+    {
+        Stage &st = *mStages[si];
+        if (!st.gh_start)
+        {
+            HCV_TRY(hipMalloc(&st.gh_start, start_bytes));
+            HCV_TRY(hipMalloc(&st.gh_ent, sizeof(GhostEntry) * pairs));
+        }
+        int *start = reinterpret_cast<int *>(mGhostPin + si * per_stage);
+        GhostEntry *ent = reinterpret_cast<GhostEntry *>(mGhostPin + si * per_stage + start_bytes);
+        st.gh_host.clear();
+        st.gh_pair.clear();
+        st.gh_min_hr = st.gh_max_hr = 0;
+        int n = 0;
+        for (uint32_t o = 0; o < mCfg.nout; o++)
+        {
+            start[o] = n;
+            for (uint32_t c = 0; c < mNinAlloc; c++)
+            {
+                const size_t pair = (size_t) o * mNinAlloc + c;
+                const GhostEvent *ev = mGhostOf[pair];
+                if (!ev || !ghost_live(ev->t0, mN, st.M, st.Pcap)) continue;
+                const int row = ev->slot[mCfg.diag ? o : c];
+                if (row < 0) continue;
+                const long long h_r = ev->t0 / st.M;
+                const float2 *blk = ev->spec[si] + (size_t) row * 2 * st.M;
+                GhostEntry e;
+                e.h_r = h_r;
+                e.g0 = reinterpret_cast<const float4 *>(blk + (size_t) (h_r & 1) * st.M);
+                e.g1 = reinterpret_cast<const float4 *>(blk + (size_t) ((h_r + 1) & 1) * st.M);
+                e.i = (int) c;
+                e.pad = 0;
+                ent[n] = e;
+                st.gh_host.push_back(e);
+                st.gh_pair.push_back(pair);
+                st.gh_min_hr = n ? std::min(st.gh_min_hr, h_r) : h_r;
+                st.gh_max_hr = n ? std::max(st.gh_max_hr, h_r) : h_r;
+                n++;
+            }
+        }
+        start[mCfg.nout] = n;
+        st.gh_count = n;
+        HCV_TRY(hipMemcpyAsync(st.gh_start, start, start_bytes, hipMemcpyHostToDevice, mStream));
+        if (n) HCV_TRY(hipMemcpyAsync(st.gh_ent, ent, sizeof(GhostEntry) * n, hipMemcpyHostToDevice, mStream));
+    }
+    for (const GhostEvent *ev : mGhostEvents)
+    {
+        long long until = 0;
+        for (Stage *st : mStages) until = std::max(until, (ev->t0 / st->M + (long long) st->Pcap + 3) * (long long) st->M);
+        mGhostPruneAt = mGhostPruneAt < 0 ? until : std::min(mGhostPruneAt, until);
+    }
+    HCV_TRY(hipEventRecord(mGhostUploaded, mStream));
+    mCtlDirty = true;
+    return true;
+}
+
+// Ghost spectra for the pairs restarting at mN: the pre-restart part of the two frames that straddle mN, per stage, for every
+// input one of the pairs reads.
+bool Engine::make_ghost_event(const std::vector<size_t> &pairs)
+{
+    for (size_t pair : pairs) release_ghost(pair);
+    if (mN <= 0 || pairs.empty() || mStages.empty() || !exact_restart()) return true;
+    GhostEvent *ev = new GhostEvent();
+    ev->t0 = mN;
+    ev->slot.assign(mCfg.nin, -1);
+    std::vector<int> rows;
+    for (size_t pair : pairs)
+    {
+        const uint32_t o = (uint32_t) (pair / mNinAlloc), c = (uint32_t) (pair % mNinAlloc);
+        const uint32_t row = mCfg.diag ? o : c;
+        if (ev->slot[row] < 0)
+        {
+            ev->slot[row] = (int) rows.size();
+            rows.push_back((int) row);
+        }
+    }
+    uint32_t nmax = 0;
+    for (Stage *st : mStages) nmax = std::max(nmax, st->N);
+    if (!mGhostHist)
+    {
+        mGhostLen = pow2ceil(2LL * nmax);
+        HCV_TRY(hipMalloc(&mGhostHist, sizeof(float) * mCfg.nin * mGhostLen));
+    }
+    HCV_TRY(launch_ghost_hist(mHist, mHistLen, mHistLen - 1, rows.data(), (int) rows.size(), mGhostHist, mGhostLen, mN, mStream));
+    for (Stage *st : mStages)
+    {
+        const size_t bytes = sizeof(float2) * rows.size() * 2 * st->M;
+        float2 *blk = static_cast<float2 *>(ghost_alloc(bytes));
+        if (!blk)
+        {
+            for (size_t s = 0; s < ev->spec.size(); s++) ghost_free(ev->spec[s], ev->bytes[s]);
+            delete ev;
+            mErr = "out of device memory for the restart spectra";
+            return false;
+        }
+        ev->spec.push_back(blk);
+        ev->bytes.push_back(bytes);
+        HCV_TRY(launch_rfft_frames(st->log2n, mGhostHist, mGhostLen, mGhostLen - 1, mN / st->M, 2, (int) rows.size(), blk, 2, st->tw, &st->big, mStream));
+    }
+    for (size_t pair : pairs)
+    {
+        mGhostOf[pair] = ev;
+        ev->refs++;
+    }
+    mGhostEvents.push_back(ev);
+    mCtlDirty = true;
+    return true;
+}
+
+// spectral_mac + the ghost products of the restarted pairs it reaches (every MAC of a stage goes through here)
+bool Engine::mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream)
+{
+    HCV_TRY(launch_spectral_mac(s, pl, st.X, H, Y, st.hv, h_first, check, stream));
+    if (st.gh_count && h_first + s.T - 1 >= st.gh_min_hr && h_first - st.gh_max_hr <= (long long) s.P)
+        HCV_TRY(launch_ghost_mac(s, H, Y, h_first, st.gh_start, st.gh_ent, nullptr, stream));
+    return true;
+}
+
+// Take what `pair` still has to deliver after mN out of the timelines: the hop each stage computed last, restricted to the
+// pair, with the spectra as they are now (so before a set() replaces them).
+bool Engine::retire_pair(size_t pair)
+{
+    const uint32_t o = (uint32_t) (pair / mNinAlloc), c = (uint32_t) (pair % mNinAlloc);
+    const uint32_t row = mCfg.diag ? o : c;
+    if (mN <= 0 || o >= mLastNout || row >= mLastNin || !exact_restart()) return true;
+    for (size_t si = 0; si < mStages.size(); si++)
+    {
+        Stage &st = *mStages[si];
+        const long long h_r = mN / st.M;
+        const long long P = std::min<long long>(st.pact[pair], h_r);
+        if (P <= 0) continue;
+        if (mTailHeadPrev && si + 1 != mStages.size()) continue;       // whole-hop mode: the shorter stages have nothing pending
+        if (!mRetireTmp)
+        {
+            uint32_t nmax = 0;
+            for (Stage *sp : mStages) nmax = std::max(nmax, sp->N);
+            HCV_TRY(hipMalloc(&mRetireTmp, sizeof(float) * nmax));
+        }
+        MacShape sh;
+        sh.M = (int) st.M;
+        sh.R = (int) st.R;
+        sh.P = (int) P;
+        sh.Pcap = (int) st.Pcap;
+        sh.nin = 1;
+        sh.nin_alloc = 1;
+        sh.nout = 1;
+        sh.diag = 0;
+        sh.T = 1;
+        sh.max_ksplit = (int) std::max<size_t>(1, st.y_elems / st.M);
+        sh.target_blocks = 0;
+        MacPlan pl;
+        mac_plan(sh, pl);
+        float2 *Y = st.Yq[0];
+        const float2 *H = st.Hs + pair * (size_t) st.Pcap * st.M;
+        HCV_TRY(launch_spectral_mac(sh, pl, st.X + (size_t) row * st.R * st.M, H, Y, st.hv + pair, h_r - 1, true, mStream));
+        for (int e = 0; e < st.gh_count; e++)
+            if (st.gh_pair[e] == pair)
+            {
+                GhostEntry one = st.gh_host[e];
+                one.i = 0;
+                HCV_TRY(launch_ghost_mac(sh, H, Y, h_r - 1, nullptr, nullptr, &one, mStream));
+            }
+        HCV_TRY(launch_reduce_partials(Y, pl.ksplit, (long long) st.M, (long long) st.M, mStream));
+        HCV_TRY(launch_rifft_rows(st.log2n, Y, 1, mRetireTmp, st.tw, &st.big, mStream));
+        // the hop's result sits at (h_r - 1 + 1) * M ..; valid half of the frame, scale 1 / (4N) as rifft_overlap_add
+        HCV_TRY(launch_timeline_sub(st.timeline + (size_t) o * st.tl_len, st.tl_len - 1, h_r * (long long) st.M, mRetireTmp + st.M, (int) st.M,
+                                    1.f / (float) (8 * st.M), mN, mStream));
+    }
+    mCtlDirty = true;
+    return true;
+}
+
 
 bool Engine::apply_pending_resets()
 {
@@ -679,13 +975,17 @@ bool Engine::apply_pending_resets()
     }
     else
     {
-        // A single pair restarts while others keep running.  The pair must ignore input older than "now"; with one
-        // shared input ring per input this is enforced at hop granularity for the FFT stages (the hop in progress is
-        // still visible to the pair) and exactly for the time-domain head.  See DESIGN.md "per-pair reset".
+        // Single pairs restart while the others keep running: take their pending output out of the timelines, fence them off
+        // the input spectra older than the hop in progress, and prepare the ghost spectra that make the fence exact to the
+        // sample (hcv_ghost.hip).  The time-domain head is fenced per sample directly.
         mCtlDirty = true;
+        std::vector<size_t> restart;
         for (size_t p = 0; p < mPending.size(); p++)
         {
             if (!mPending[p]) continue;
+            if (!mRetired[p] && !retire_pair(p)) return false;
+            if (mLoaded[p]) restart.push_back(p);
+            else release_ghost(p);
             for (Stage *st : mStages)
             {
                 const long long hvv = mN / st->M;
@@ -698,7 +998,10 @@ bool Engine::apply_pending_resets()
                 mTdMaxValid = std::max(mTdMaxValid, mN);
             }
         }
+        if (!make_ghost_event(restart)) return false;
+        if (!rebuild_ghost_tables()) return false;
     }
+    std::fill(mRetired.begin(), mRetired.end(), 0);
     std::fill(mPending.begin(), mPending.end(), 0);
     return true;
 }
@@ -724,6 +1027,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
     const int q = (int) (mBlockCount & 1);
 
+    if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
     // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
     if (mCtlDirty)
     {
@@ -837,7 +1141,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             const long long hop = st.pre_hop - 1 - a;
             const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
             float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
-            HCV_TRY(launch_spectral_mac(sb, pb, st.X, st.Hs + (size_t) (1 + a) * st.M, scratch, st.hv, hop, bcheck, st.stream));
+            if (!mac(st, sb, pb, st.Hs + (size_t) (1 + a) * st.M, scratch, hop, bcheck, st.stream)) return false;
             HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, st.stream));
             HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, st.stream));
             HCV_TRY(hipEventRecord(st.bg_done, st.stream));
@@ -903,7 +1207,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             mac_plan(sc, pc);
             const bool ccheck = (h_first - 1 - st.max_hv) < (long long) st.P - 1;
             const long long c_elems = (long long) nout_act * st.M;
-            HCV_TRY(launch_spectral_mac(sc, pc, st.X, st.Hs, st.Y, st.hv, h_first - 1, ccheck, st.stream));
+            if (!mac(st, sc, pc, st.Hs, st.Y, h_first - 1, ccheck, st.stream)) return false;
             HCV_TRY(launch_reduce_partials(st.Y, pc.ksplit, c_elems, c_elems, st.stream));
             HCV_TRY(hipStreamWaitEvent(st.stream, mEvEmit[q], 0));        // emit(k-2) has cleared the timeline span reused now
             HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, c_elems, h_first - 1, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
@@ -958,7 +1262,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
                 HCV_TRY(hipStreamWaitEvent(mTdStream, st.mac_done[q], 0));
                 HCV_TRY(hipStreamWaitEvent(mTdStream, mEvEmit[q], 0));
                 const long long he = (long long) T * nout_act * st.M;
-                HCV_TRY(launch_spectral_mac(hs, hp, st.X, head_spec, head_y, st.hv, h_first, false, mTdStream));
+                if (!mac(st, hs, hp, head_spec, head_y, h_first, false, mTdStream)) return false;
                 HCV_TRY(launch_reduce_partials(head_y, hp.ksplit, he, he, mTdStream));
                 HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
                                                  &st.big, mTdStream));
@@ -967,7 +1271,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             }
             else
             {
-                HCV_TRY(launch_spectral_mac(hs, hp, st.X, head_spec, head_y, st.hv, h_first, false, sM));
+                if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sM)) return false;
                 head_ksplit = hp.ksplit;
             }
         }
@@ -1030,13 +1334,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
                 s0.P = 1;
                 s0.max_ksplit = 1;
                 mac_plan(s0, pl);
-                HCV_TRY(launch_spectral_mac(s0, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, sM));
+                if (!mac(st, s0, pl, st.Hs, st.Y, h_first, check, sM)) return false;
             }
             else
             {
                 mac_plan(sh, pl);
                 if (!begin_event()) return false;
-                HCV_TRY(launch_spectral_mac(sh, pl, st.X, st.Hs, st.Y, st.hv, h_first, check, sM));
+                if (!mac(st, sh, pl, st.Hs, st.Y, h_first, check, sM)) return false;
                 if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
                 st.launches++;
                 st.hops += (uint64_t) T;
@@ -1102,6 +1406,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     HCV_TRY(hipEventRecord(mEvEmit[q], mStream));
     mN += B;
     mBlockCount++;
+    mLastNin = rows_in;
+    mLastNout = nout_act;
     return true;
 }
 

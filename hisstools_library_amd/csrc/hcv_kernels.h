@@ -64,6 +64,22 @@ namespace hcv
     hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
                                    long long h_first, bool check, hipStream_t st);
 
+    // ---- exact per-pair restart (hcv_ghost.hip) ----
+    struct GhostEntry
+    {
+        long long h_r;              // first frame the restarted pair may see (= the hop the restart fell into)
+        const float4 *g0, *g1;      // spectra of the pre-restart part of frames h_r and h_r + 1
+        int i, pad;                 // the pair's input column in H
+    };
+    // `rows` is a host array (passed to the kernel by value)
+    hipError_t launch_ghost_hist(const float *hist, long long hist_stride, long long hist_mask, const int *rows, int nrows, float *ghost, long long Lg,
+                                 long long t0, hipStream_t st);
+    // follows a spectral_mac launch of the same shape: subtracts the ghost products from slice 0 of its partial sums.  Entries
+    // come from a per-output table (start[o] .. start[o + 1]) or, for a one-pair launch, from `single`
+    hipError_t launch_ghost_mac(const MacShape &s, const float2 *H, float2 *Y, long long h_first, const int *start, const GhostEntry *ent,
+                                const GhostEntry *single, hipStream_t st);
+    hipError_t launch_timeline_sub(float *row, long long mask, long long base, const float *tmp, int n, float scale, long long t_min, hipStream_t st);
+
     // ---- time-domain head ----
     hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                                int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,

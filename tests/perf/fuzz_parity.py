@@ -5,9 +5,8 @@ the first mismatch (with the seed to reproduce it).
 
     python tests/perf/fuzz_parity.py [--seconds 120] [--seed 1]
 
-Control calls are restricted to those whose effect is defined independently of the reference's random FFT phases and of this
-engine's hop-granular per-pair fence: full resets, sets before streaming and clears; per-pair sets mid-stream
-are followed by a settling period that is excluded from the comparison."""
+Control calls: sets before streaming, and for the matrix classes IR swaps, clears and restarts of single pairs mid-stream
+(exact to the sample on both sides) as well as resets of everything; the whole output is compared, transients included."""
 import argparse
 import os
 import sys
@@ -109,13 +108,38 @@ def one_case(seed):
         L = int(rng.integers(1, 60000))
         h = O.synth_ir((seed + i) % 60, o, L)
         assert ref.set(i, o, h, True) == gpu.set(i, o, h, True), (i, o)
-    y_ref = ref.run(xs, nout, 1024)
+    # mid-stream control calls, applied to both sides at the same sample: IR swaps, clears and restarts of single pairs while
+    # the others keep running (exact to the sample on both sides), and resets of everything
+    events = {}
+    if rng.random() < 0.6:
+        for _ in range(int(rng.integers(1, 5))):
+            pos = int(rng.integers(1, S))
+            i = int(rng.integers(0, nin))
+            o = i if kind == "parallel" else int(rng.integers(0, nout))
+            what = rng.choice(["set", "set", "set", "reset_pair", "clear_pair", "reset_all"])
+            if what == "set":
+                L = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(1, 60000)), int(rng.integers(1, 60000))]))
+                h = O.synth_ir((seed + 3 * i + pos) % 60, o, L)
+                events.setdefault(pos, []).append(lambda c, i=i, o=o, h=h: c.set(i, o, h, True))
+            elif what == "reset_pair":
+                events.setdefault(pos, []).append(lambda c, i=i, o=o: c.reset(i, o))
+            elif what == "clear_pair":
+                events.setdefault(pos, []).append(lambda c, i=i, o=o: c.clear(i, o, False))
+            else:
+                events.setdefault(pos, []).append(lambda c: c.reset())
+    cuts = sorted({0, S} | set(events))
+    y_ref = np.zeros((nout, S), np.float32)
     y = np.zeros((nout, S), np.float32)
-    for pos, n in blocks(rng, S):
-        y[:, pos:pos + n] = gpu.run(xs[:, pos:pos + n], nout, n)
-    worst = max(rel(y[o], y_ref[o]) for o in range(nout))
-    return kind, f"{nin}x{nout} latency={latency} pairs={len(pairs)} S={S}", worst
-
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        for fn in events.get(a, []):
+            r1, r2 = fn(ref), fn(gpu)
+            assert r1 == r2, (a, r1, r2)
+        y_ref[:, a:b] = ref.run(np.ascontiguousarray(xs[:, a:b]), nout, 1024)
+        for pos, n in blocks(rng, b - a):
+            y[:, a + pos:a + pos + n] = gpu.run(np.ascontiguousarray(xs[:, a + pos:a + pos + n]), nout, n)
+    peak = max(float(np.abs(y_ref).max()), 1e-30)
+    worst = max(float(np.abs(y[o].astype(np.float64) - y_ref[o].astype(np.float64)).max()) / peak for o in range(nout))
+    return kind, f"{nin}x{nout} latency={latency} pairs={len(pairs)} S={S} events={sum(len(v) for v in events.values())}", worst
 
 def main():
     ap = argparse.ArgumentParser()

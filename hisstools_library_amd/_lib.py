@@ -110,6 +110,12 @@ SIGNATURES = {
     "hcv_spectral_size": (usz, [usz, usz, C.c_int]),
     "hcv_spectral_convolve_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
     "hcv_spectral_correlate_f32": (C.c_int, [f32p, usz, f32p, usz, C.c_int, f32p]),
+    "hcv_spectral_convolve_f64": (C.c_int, [f64p, usz, f64p, usz, C.c_int, f64p]),
+    "hcv_spectral_correlate_f64": (C.c_int, [f64p, usz, f64p, usz, C.c_int, f64p]),
+    "hcv_spectral_convolve_complex_f32": (C.c_int, [f32p, usz, f32p, usz, f32p, usz, f32p, usz, C.c_int, f32p, f32p]),
+    "hcv_spectral_correlate_complex_f32": (C.c_int, [f32p, usz, f32p, usz, f32p, usz, f32p, usz, C.c_int, f32p, f32p]),
+    "hcv_spectral_convolve_complex_f64": (C.c_int, [f64p, usz, f64p, usz, f64p, usz, f64p, usz, C.c_int, f64p, f64p]),
+    "hcv_spectral_correlate_complex_f64": (C.c_int, [f64p, usz, f64p, usz, f64p, usz, f64p, usz, C.c_int, f64p, f64p]),
     "hcv_spectral_convolve_f32_dev": (C.c_int, [vp, usz, vp, usz, C.c_int, vp, vp, C.c_int]),
     "hcv_spectral_correlate_f32_dev": (C.c_int, [vp, usz, vp, usz, C.c_int, vp, vp, C.c_int]),
     "hcv_fft_exec": (C.c_int, [C.POINTER(FFTCall)]),

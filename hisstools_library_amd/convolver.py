@@ -119,7 +119,8 @@ class EdgeMode(IntEnum):               # spectral_processor::EdgeMode, SpectralP
 
 
 class spectral_processor:
-    """Real overloads of spectral_processor<float>::convolve / correlate (SpectralProcessor.hpp:173-184)."""
+    """spectral_processor<T>::convolve / correlate (SpectralProcessor.hpp:164-184): the real overloads (float32 or float64 by
+    the inputs' dtype) and the complex overloads (``convolve_complex`` / ``correlate_complex``), plus change_phase."""
 
     def __init__(self, max_fft_size=1 << 20):
         self.L = _lib.load()
@@ -130,19 +131,48 @@ class spectral_processor:
 
     correlated_size = convolved_size
 
-    def _run(self, fn, in1, in2, mode, what):
-        a, b = _f32(in1), _f32(in2)
+    @staticmethod
+    def _typed(*arrays):
+        """float64 when any operand is float64, float32 otherwise; returns (dtype, pointer type, contiguous arrays)"""
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        dbl = any(a.dtype == np.float64 for a in arrays)
+        dt = np.float64 if dbl else np.float32
+        return dt, (f64p if dbl else f32p), [np.ascontiguousarray(a, dt) for a in arrays]
+
+    def _run(self, op, in1, in2, mode, what):
+        dt, pt, (a, b) = self._typed(in1, in2)
+        fn = getattr(self.L, f"hcv_spectral_{op}_{'f64' if dt == np.float64 else 'f32'}")
         n = self.L.hcv_spectral_size(a.size, b.size, int(mode))
-        out = np.zeros(n, np.float32)
+        out = np.zeros(n, dt)
         if n:
-            _check(fn(_fp(a), a.size, _fp(b), b.size, int(mode), _fp(out)), what)
+            _check(fn(a.ctypes.data_as(pt), a.size, b.ctypes.data_as(pt), b.size, int(mode), out.ctypes.data_as(pt)), what)
         return out
 
     def convolve(self, in1, in2, mode=EdgeMode.Linear):
-        return self._run(self.L.hcv_spectral_convolve_f32, in1, in2, mode, "spectral_processor.convolve")
+        return self._run("convolve", in1, in2, mode, "spectral_processor.convolve")
 
     def correlate(self, in1, in2, mode=EdgeMode.Linear):
-        return self._run(self.L.hcv_spectral_correlate_f32, in1, in2, mode, "spectral_processor.correlate")
+        return self._run("correlate", in1, in2, mode, "spectral_processor.correlate")
+
+    def _run_complex(self, op, r1, i1, r2, i2, mode, what):
+        dt, pt, ins = self._typed(r1, i1, r2, i2)
+        fn = getattr(self.L, f"hcv_spectral_{op}_complex_{'f64' if dt == np.float64 else 'f32'}")
+        n = self.L.hcv_spectral_size(max(ins[0].size, ins[1].size), max(ins[2].size, ins[3].size), int(mode))
+        r_out, i_out = np.zeros(n, dt), np.zeros(n, dt)
+        if n:
+            args = []
+            for a in ins:
+                args += [a.ctypes.data_as(pt), a.size]
+            _check(fn(*args, int(mode), r_out.ctypes.data_as(pt), i_out.ctypes.data_as(pt)), what)
+        return r_out, i_out
+
+    def convolve_complex(self, r_in1, i_in1, r_in2, i_in2, mode=EdgeMode.Linear):
+        """convolve(r_out, i_out, r_in1, i_in1, r_in2, i_in2, mode) (SpectralProcessor.hpp:164-167); returns (r_out, i_out)"""
+        return self._run_complex("convolve", r_in1, i_in1, r_in2, i_in2, mode, "spectral_processor.convolve_complex")
+
+    def correlate_complex(self, r_in1, i_in1, r_in2, i_in2, mode=EdgeMode.Linear):
+        """correlate(r_out, i_out, …) (SpectralProcessor.hpp:176-179): in1 x conj(in2) in the spectral domain"""
+        return self._run_complex("correlate", r_in1, i_in1, r_in2, i_in2, mode, "spectral_processor.correlate_complex")
 
     def convolve_dev(self, in1_ptr: int, size1: int, in2_ptr: int, size2: int, out_ptr: int, mode=EdgeMode.Linear, correlate=False, stream: int = 0, sync=True):
         """hcv_spectral_convolve_f32_dev / _correlate_f32_dev: float32 operands and result resident in HBM (device pointers as

@@ -178,6 +178,22 @@ HCV_API int hcv_spectral_correlate_f32(const float *in1, size_t size1, const flo
 HCV_API int hcv_spectral_convolve_f32_dev(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out, void *stream, int sync);
 HCV_API int hcv_spectral_correlate_f32_dev(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out, void *stream, int sync);
 
+/* the real overloads in double and the complex overloads in float and double (SpectralProcessor.hpp:164-167, 176-179; binary_op
+ * :559-614).  A complex operand is a real and an imaginary array that may differ in length (the shorter is zero-padded); its
+ * size is the longer of the two, and r_out / i_out each receive hcv_spectral_size(size1, size2, mode) values.  In the two wrap
+ * modes the complex overloads follow the real overloads' arrangement: the reference's complex instantiation reads past the
+ * result there (its Split wrap() takes an offset where the shared arrange code passes an end position, :401-408 / :429-435). */
+HCV_API int hcv_spectral_convolve_f64(const double *in1, size_t size1, const double *in2, size_t size2, int mode, double *out);
+HCV_API int hcv_spectral_correlate_f64(const double *in1, size_t size1, const double *in2, size_t size2, int mode, double *out);
+HCV_API int hcv_spectral_convolve_complex_f32(const float *r_in1, size_t r_size1, const float *i_in1, size_t i_size1, const float *r_in2, size_t r_size2,
+                                              const float *i_in2, size_t i_size2, int mode, float *r_out, float *i_out);
+HCV_API int hcv_spectral_correlate_complex_f32(const float *r_in1, size_t r_size1, const float *i_in1, size_t i_size1, const float *r_in2, size_t r_size2,
+                                               const float *i_in2, size_t i_size2, int mode, float *r_out, float *i_out);
+HCV_API int hcv_spectral_convolve_complex_f64(const double *r_in1, size_t r_size1, const double *i_in1, size_t i_size1, const double *r_in2, size_t r_size2,
+                                              const double *i_in2, size_t i_size2, int mode, double *r_out, double *i_out);
+HCV_API int hcv_spectral_correlate_complex_f64(const double *r_in1, size_t r_size1, const double *i_in1, size_t i_size1, const double *r_in2, size_t r_size2,
+                                               const double *i_in2, size_t i_size2, int mode, double *r_out, double *i_out);
+
 /* ---------------------------------------------------------------- the full hisstools_* FFT surface (second "next" row)
  * Every transform of HISSTools_FFT.h:87-369 — float and double, complex and real, in place on split data or out of
  * place from / to interleaved samples, plus zip / unzip — as ONE batched entry point.  `op` selects the reference

@@ -384,129 +384,14 @@ size_t hcvo_spectral_size(size_t n1, size_t n2, int mode, size_t max_fft)
     return mode != HCVO_EDGE_LINEAR ? s.max : s.linear;
 }
 
-/* copy_fold (:361-377): [mirrored head | in | mirrored tail], fold_size samples each side */
-static void spectral_copy_fold(float *dst, const float *in, size_t size, size_t fold_size, int repeat)
-{
-    size_t off = repeat ? 0 : 1;
-    for (size_t i = 0; i < size; i++) dst[fold_size + i] = in[i];
-    for (size_t i = 0; i < fold_size; i++)
-    {
-        dst[i] = in[off + fold_size - 1 - i];
-        dst[fold_size + size + i] = in[size - off - 1 - i];
-    }
-}
+#define REAL float
+#define FN(x) x##_f32
+#include "hcv_oracle_spectral.inc"
+#undef REAL
+#undef FN
 
-static void spectral_binary(const float *in1, size_t n1, const float *in2, size_t n2, int mode, int correlate, float *out, size_t max_fft)
-{
-    if (!hcvo_spectral_size(n1, n2, mode, max_fft)) return;
-    if (n1 == 1 && n2 == 1) { out[0] = in1[0] * in2[0]; return; }
-
-    hcvo_op_sizes s = spectral_sizes(n1, n2, mode);
-    size_t half = s.fft >> 1;
-    float *re1 = (float *) calloc(4 * half + s.fft + s.fold_copy + 8, sizeof(float));
-    float *im1 = re1 + half, *re2 = im1 + half, *im2 = re2 + half, *t = im2 + half, *folded = t + s.fft;
-
-    /* binary_op (:617-644): the longer input is the one that gets folded */
-    if (!s.fold)
-    {
-        hcvo_rfft_f32(in1, n1, s.fft_log2, re1, im1);
-        hcvo_rfft_f32(in2, n2, s.fft_log2, re2, im2);
-    }
-    else
-    {
-        size_t fold_size = s.min >> 1;
-        int repeat = mode == HCVO_EDGE_FOLD_REPEAT;
-        if (n1 >= n2)
-        {
-            spectral_copy_fold(folded, in1, n1, fold_size, repeat);
-            hcvo_rfft_f32(folded, s.fold_copy, s.fft_log2, re1, im1);
-            hcvo_rfft_f32(in2, n2, s.fft_log2, re2, im2);
-        }
-        else
-        {
-            spectral_copy_fold(folded, in2, n2, fold_size, repeat);
-            hcvo_rfft_f32(folded, s.fold_copy, s.fft_log2, re2, im2);
-            hcvo_rfft_f32(in1, n1, s.fft_log2, re1, im1);
-        }
-    }
-
-    /* real_operation (SpectralFunctions.hpp:63-83) with impl::convolve / impl::correlate (:265-281) */
-    float scale = 0.25f / (float) s.fft;
-    float dc = scale * (re1[0] * re2[0]);
-    float nq = scale * (im1[0] * im2[0]);
-    for (size_t k = 0; k < half; k++)
-    {
-        float a = re1[k], b = im1[k], c = re2[k], d = im2[k];
-        if (!correlate) { re1[k] = scale * (a * c - b * d); im1[k] = scale * (b * c + a * d); }
-        else            { re1[k] = scale * (a * c + b * d); im1[k] = scale * (b * c - a * d); }
-    }
-    re1[0] = dc;
-    im1[0] = nq;
-    hcvo_rifft_f32(re1, im1, s.fft_log2, t);
-
-#define SP_COPY(o_off, off, n) do { for (size_t i_ = 0; i_ < (size_t) (n); i_++) out[(o_off) + i_] = t[(off) + i_]; } while (0)
-#define SP_WRAP(o_off, last, n) do { for (size_t i_ = 0; i_ < (size_t) (n); i_++) out[(o_off) + i_] += t[(last) - (n) + i_]; } while (0)
-#define SP_ZERO(a_, b_) do { for (size_t i_ = (a_); i_ < (size_t) (b_); i_++) out[i_] = 0.f; } while (0)
-    if (!correlate)
-    {
-        size_t min_m1 = s.min - 1;                              /* arrange_convolve (:448-486) */
-        switch (mode)
-        {
-            case HCVO_EDGE_LINEAR: SP_COPY(0, 0, s.linear); break;
-            case HCVO_EDGE_WRAP: SP_COPY(0, 0, s.max); SP_WRAP(0, s.linear, min_m1); break;
-            case HCVO_EDGE_WRAP_CENTRE:
-            {
-                size_t wrapped = min_m1 >> 1;
-                SP_COPY(0, wrapped, s.max);
-                SP_WRAP(0, s.linear, min_m1 - wrapped);
-                SP_WRAP(s.max - wrapped, wrapped, wrapped);
-                break;
-            }
-            default: SP_COPY(0, min_m1, s.max); break;
-        }
-    }
-    else
-    {
-        size_t size2_m1 = s.size2 - 1;                          /* arrange_correlate (:488-545) */
-        switch (mode)
-        {
-            case HCVO_EDGE_LINEAR: SP_COPY(0, 0, s.size1); SP_COPY(s.size1, s.fft - size2_m1, size2_m1); break;
-            case HCVO_EDGE_WRAP:
-                SP_COPY(0, 0, s.size1);
-                SP_ZERO(s.size1, s.size2);
-                SP_WRAP(s.max - size2_m1, s.fft, size2_m1);
-                break;
-            case HCVO_EDGE_WRAP_CENTRE:
-            {
-                size_t w1 = (s.min - 1) >> 1;
-                size_t w2 = size2_m1 < s.max - w1 ? size2_m1 : s.max - w1;
-                size_t w3 = size2_m1 - w2;
-                size_t offset = w3 ? 0 : s.max - (size2_m1 + w1);
-                SP_ZERO(0, s.max);
-                SP_COPY(0, w1, s.size1 - w1);
-                SP_COPY(s.max - w1, 0, w1);
-                SP_WRAP(offset, s.fft, w2);
-                SP_WRAP(s.max - w3, s.fft - w2, w3);
-                break;
-            }
-            default:
-                if (s.size1 >= s.size2) SP_COPY(0, 0, s.max);
-                else { size_t cs = s.max - 1; SP_COPY(0, 0, 1); SP_COPY(1, s.fft - cs, cs); }
-                break;
-        }
-    }
-#undef SP_COPY
-#undef SP_WRAP
-#undef SP_ZERO
-    free(re1);
-}
-
-void hcvo_spectral_convolve_f32(const float *in1, size_t n1, const float *in2, size_t n2, int mode, float *out, size_t max_fft)
-{
-    spectral_binary(in1, n1, in2, n2, mode, 0, out, max_fft);
-}
-
-void hcvo_spectral_correlate_f32(const float *in1, size_t n1, const float *in2, size_t n2, int mode, float *out, size_t max_fft)
-{
-    spectral_binary(in1, n1, in2, n2, mode, 1, out, max_fft);
-}
+#define REAL double
+#define FN(x) x##_f64
+#include "hcv_oracle_spectral.inc"
+#undef REAL
+#undef FN

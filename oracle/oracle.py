@@ -567,43 +567,72 @@ def have_ref_spectral() -> bool:
 
 
 def _spectral_lib(backend):
+    """dict of callables keyed by (op, complex, dtype): op in {"convolve", "correlate"}; plus "size" """
     if backend in _spectral:
         return _spectral[backend]
+    fns = {}
     if backend == "port":
         L = lib("port").cdll
         size = _decl(L, "hcvo_spectral_size", _sz, _sz, _sz, C.c_int, _sz)
-        conv = _decl(L, "hcvo_spectral_convolve_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p, _sz)
-        corr = _decl(L, "hcvo_spectral_correlate_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p, _sz)
-        cap = 1 << 24
-        fns = (lambda a, b, m: size(a, b, m, cap), lambda *x: conv(*x, cap), lambda *x: corr(*x, cap))
+        fns["size"] = lambda n1, n2, mode: size(n1, n2, mode, 1 << 24)
+        for op in ("convolve", "correlate"):
+            for suf, pt in (("f32", _f32p), ("f64", _f64p)):
+                f = _decl(L, f"hcvo_spectral_{op}_{suf}", None, pt, _sz, pt, _sz, C.c_int, pt, _sz)
+                fns[(op, False, suf)] = lambda *a, f=f: f(*a, 1 << 24)
+                g = _decl(L, f"hcvo_spectral_{op}_complex_{suf}", None, pt, _sz, pt, _sz, pt, _sz, pt, _sz, C.c_int, pt, pt, _sz)
+                fns[(op, True, suf)] = lambda *a, g=g: g(*a, 1 << 24)
     else:
         if not have_ref_spectral():
-            raise FileNotFoundError(REF_SPECTRAL_PATH)
+            raise RuntimeError("oracle/_ref/libhisstools_ref_spectral.so missing: run `make -C oracle ref` where /root/reference exists")
         L = C.CDLL(REF_SPECTRAL_PATH)
-        fns = (_decl(L, "ref_spectral_size", _sz, _sz, _sz, C.c_int),
-               _decl(L, "ref_spectral_convolve_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p),
-               _decl(L, "ref_spectral_correlate_f32", None, _f32p, _sz, _f32p, _sz, C.c_int, _f32p))
+        fns["size"] = _decl(L, "ref_spectral_size", _sz, _sz, _sz, C.c_int)
+        for op in ("convolve", "correlate"):
+            for suf, pt in (("f32", _f32p), ("f64", _f64p)):
+                fns[(op, False, suf)] = _decl(L, f"ref_spectral_{op}_{suf}", None, pt, _sz, pt, _sz, C.c_int, pt)
+                fns[(op, True, suf)] = _decl(L, f"ref_spectral_{op}_complex_{suf}", None, pt, _sz, pt, _sz, pt, _sz, pt, _sz, C.c_int, pt, pt)
     _spectral[backend] = fns
     return fns
 
 
 def spectral_size(n1, n2, mode, backend="port"):
-    return _spectral_lib(backend)[0](n1, n2, int(mode))
+    return _spectral_lib(backend)["size"](n1, n2, int(mode))
+
+
+def _spectral_typed(arrays):
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    dbl = any(a.dtype == np.float64 for a in arrays)
+    dt = np.float64 if dbl else np.float32
+    return dt, ("f64" if dbl else "f32"), (_f64p if dbl else _f32p), [np.ascontiguousarray(a, dt) for a in arrays]
 
 
 def spectral_convolve(in1, in2, mode, backend="port", correlate=False):
-    """spectral_processor<float>::convolve / correlate (real overloads)."""
-    size, conv, corr = _spectral_lib(backend)
-    a, b = _f32(in1), _f32(in2)
-    n = size(a.size, b.size, int(mode))
-    out = np.zeros(n, np.float32)
+    """spectral_processor<T>::convolve / correlate, real overloads; float32 or float64 by the inputs' dtype."""
+    fns = _spectral_lib(backend)
+    dt, suf, pt, (a, b) = _spectral_typed([in1, in2])
+    n = fns["size"](a.size, b.size, int(mode))
+    out = np.zeros(n, dt)
     if n:
-        (corr if correlate else conv)(_fp(a), a.size, _fp(b), b.size, int(mode), _fp(out))
+        fns[("correlate" if correlate else "convolve", False, suf)](a.ctypes.data_as(pt), a.size, b.ctypes.data_as(pt), b.size, int(mode), out.ctypes.data_as(pt))
     return out
 
 
 def spectral_correlate(in1, in2, mode, backend="port"):
     return spectral_convolve(in1, in2, mode, backend, correlate=True)
+
+
+def spectral_convolve_complex(r1, i1, r2, i2, mode, backend="port", correlate=False):
+    """the complex overloads (SpectralProcessor.hpp:164-167, 176-179); returns (r_out, i_out).  NOTE backend="ref" reads past
+    its result in the two wrap modes (a reference defect, see hcv_oracle_spectral.inc)."""
+    fns = _spectral_lib(backend)
+    dt, suf, pt, ins = _spectral_typed([r1, i1, r2, i2])
+    n = fns["size"](max(ins[0].size, ins[1].size), max(ins[2].size, ins[3].size), int(mode))
+    r_out, i_out = np.zeros(n, dt), np.zeros(n, dt)
+    if n:
+        args = []
+        for a in ins:
+            args += [a.ctypes.data_as(pt), a.size]
+        fns[("correlate" if correlate else "convolve", True, suf)](*args, int(mode), r_out.ctypes.data_as(pt), i_out.ctypes.data_as(pt))
+    return r_out, i_out
 
 
 # --------------------------------------------------------------------------------------- spectral IR functions (fourth "next" row)

@@ -42,6 +42,38 @@ extern "C"
         sp.correlate(out, { in1, n1 }, { in2, n2 }, static_cast<spectral_processor<float>::EdgeMode>(mode));
     }
 
+    // the real overloads in double, and the complex overloads in both precisions (SpectralProcessor.hpp:164-167, 176-179).
+    // NOTE: in the two wrap modes the reference's complex instantiation reads past the result (its Split wrap() takes an
+    // offset where arrange_* passes an end position, :401-408); callers compare those modes against the real overloads.
+    void ref_spectral_convolve_f64(const double *in1, uintptr_t n1, const double *in2, uintptr_t n2, int mode, double *out)
+    {
+        spectral_processor<double> sp(table_size(n1, n2));
+        sp.convolve(out, { in1, n1 }, { in2, n2 }, static_cast<spectral_processor<double>::EdgeMode>(mode));
+    }
+
+    void ref_spectral_correlate_f64(const double *in1, uintptr_t n1, const double *in2, uintptr_t n2, int mode, double *out)
+    {
+        spectral_processor<double> sp(table_size(n1, n2));
+        sp.correlate(out, { in1, n1 }, { in2, n2 }, static_cast<spectral_processor<double>::EdgeMode>(mode));
+    }
+
+#define REF_COMPLEX(T, SUF)                                                                                                                  \
+    void ref_spectral_convolve_complex_##SUF(const T *r1, uintptr_t nr1, const T *i1, uintptr_t ni1, const T *r2, uintptr_t nr2, const T *i2,  \
+                                             uintptr_t ni2, int mode, T *r_out, T *i_out)                                                    \
+    {                                                                                                                                        \
+        spectral_processor<T> sp(table_size(nr1 > ni1 ? nr1 : ni1, nr2 > ni2 ? nr2 : ni2));                                                  \
+        sp.convolve(r_out, i_out, { r1, nr1 }, { i1, ni1 }, { r2, nr2 }, { i2, ni2 }, static_cast<spectral_processor<T>::EdgeMode>(mode));   \
+    }                                                                                                                                        \
+    void ref_spectral_correlate_complex_##SUF(const T *r1, uintptr_t nr1, const T *i1, uintptr_t ni1, const T *r2, uintptr_t nr2, const T *i2, \
+                                              uintptr_t ni2, int mode, T *r_out, T *i_out)                                                   \
+    {                                                                                                                                        \
+        spectral_processor<T> sp(table_size(nr1 > ni1 ? nr1 : ni1, nr2 > ni2 ? nr2 : ni2));                                                  \
+        sp.correlate(r_out, i_out, { r1, nr1 }, { i1, ni1 }, { r2, nr2 }, { i2, ni2 }, static_cast<spectral_processor<T>::EdgeMode>(mode));  \
+    }
+    REF_COMPLEX(float, f32)
+    REF_COMPLEX(double, f64)
+#undef REF_COMPLEX
+
     // ---------------------------------------------------------------- spectral IR functions (SpectralFunctions.hpp:365-413) and
     // spectral_processor::change_phase (SpectralProcessor.hpp:188-208): fourth "next" row.  op: 0 copy, 1 spike, 2 delay,
     // 3 time_reverse, 4 phase.  In-place calls (out == in) are what the reference's own callers make.

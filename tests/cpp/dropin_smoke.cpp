@@ -66,5 +66,29 @@ int main()
     for (int i = 0; i < 7; i++)
         if (std::fabs(lin[i] - expect[i]) > 1e-5f) return 1;
     std::printf("drop-in spectral_processor::convolve ok\n");
+
+    // the double and the complex overloads (SpectralProcessor.hpp:164-184) and the transform members (:117-160)
+    spectral_processor<double> spd;
+    using ModeD = spectral_processor<double>::EdgeMode;
+    const double ad[5] = { 1., 2., 3., 4., 5. }, bd[3] = { 1., -1., 0.5 }, zero3[3] = { 0., 0., 0. };
+    double lind[7] = { 0 }, ro[7] = { 0 }, io[7] = { 0 };
+    spd.convolve(lind, { ad, 5 }, { bd, 3 }, ModeD::Linear);
+    for (int i = 0; i < 7; i++)
+        if (std::fabs(lind[i] - (double) expect[i]) > 1e-12) return 1;
+    // (a + j a) * (b + j 0) = a*b + j a*b ; correlate of a real signal with itself peaks at lag 0 with the energy
+    spd.convolve(ro, io, { ad, 5 }, { ad, 5 }, { bd, 3 }, { zero3, 0 }, ModeD::Linear);
+    for (int i = 0; i < 7; i++)
+        if (std::fabs(ro[i] - (double) expect[i]) > 1e-12 || std::fabs(io[i] - (double) expect[i]) > 1e-12) return 1;
+    double cr[9] = { 0 }, ci[9] = { 0 };
+    spd.correlate(cr, ci, { ad, 5 }, { zero3, 0 }, { ad, 5 }, { zero3, 0 }, ModeD::Linear);
+    if (std::fabs(cr[0] - 55.0) > 1e-11 || std::fabs(ci[0]) > 1e-11) return 1;
+    float fr[8] = { 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, fi[8] = { 0.f };
+    FFT_SPLIT_COMPLEX_F split(fr, fi);
+    sp.fft(split, 3);                                           // the transform of an impulse is flat
+    for (int i = 0; i < 8; i++)
+        if (std::fabs(fr[i] - 1.f) > 1e-6f || std::fabs(fi[i]) > 1e-6f) return 1;
+    sp.ifft(split, 3);
+    if (std::fabs(fr[0] - 8.f) > 1e-5f) return 1;
+    std::printf("drop-in spectral_processor double / complex overloads and transforms ok\n");
     return 0;
 }

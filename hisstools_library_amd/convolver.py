@@ -122,7 +122,7 @@ class spectral_processor:
     """spectral_processor<T>::convolve / correlate (SpectralProcessor.hpp:164-184): the real overloads (float32 or float64 by
     the inputs' dtype) and the complex overloads (``convolve_complex`` / ``correlate_complex``), plus change_phase."""
 
-    def __init__(self, max_fft_size=1 << 20):
+    def __init__(self, max_fft_size=1 << 22):
         self.L = _lib.load()
         self._max = max_fft_size
 

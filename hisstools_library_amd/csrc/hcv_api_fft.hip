@@ -247,7 +247,7 @@ extern "C" size_t hcv_spectral_size(size_t size1, size_t size2, int mode)       
 {
     if (!size1 || !size2 || mode < 0 || mode > EDGE_FOLD_REPEAT) return 0;
     const OpSizes s = op_sizes(size1, size2, mode);
-    if (s.fft_log2 > (unsigned) hcv::kMaxFFTLog2) return 0;     // our "max_fft_size" is 2^20
+    if (s.fft_log2 > hcv_api::kMaxSpectralLog2) return 0;       // our "max_fft_size" is 2^22
     return mode != EDGE_LINEAR ? s.mx : s.linear;
 }
 
@@ -371,6 +371,8 @@ static int spectral_binary(const float *in1, size_t n1, const float *in2, size_t
     int dev = 0;
     size_t result = 0;
     if (!spectral_ready(n1, n2, mode, dev, result)) return result == (size_t) -1 ? -1 : 0;
+    // beyond the convolution engine's largest FFT the general FFT surface takes over (hcv_api_spectral.hip)
+    if (op_sizes(n1, n2, mode).fft_log2 > (unsigned) hcv::kMaxFFTLog2) return hcv_api::spectral_real_general_f32(in1, n1, in2, n2, mode, correlate, out);
     bool ok = true;
     float *d1 = nullptr, *d2 = nullptr, *dout = nullptr;
     SpectralWork w;
@@ -395,6 +397,11 @@ static int spectral_binary_dev(const float *d1, size_t n1, const float *d2, size
     int dev = 0;
     size_t result = 0;
     if (!spectral_ready(n1, n2, mode, dev, result)) return result == (size_t) -1 ? -1 : 0;
+    if (op_sizes(n1, n2, mode).fft_log2 > (unsigned) hcv::kMaxFFTLog2)
+    {
+        set_error("hcv_spectral_*_f32_dev: circular sizes above 2^20 are served by the host-pointer entry points only");
+        return -1;
+    }
     static std::mutex mutex;
     static std::map<int, SpectralWork> cache;
     std::lock_guard<std::mutex> g(mutex);

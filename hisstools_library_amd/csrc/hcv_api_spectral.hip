@@ -18,7 +18,7 @@ using hcv_api::set_error;
 namespace
 {
     enum { EDGE_LINEAR = 0, EDGE_WRAP = 1, EDGE_WRAP_CENTRE = 2, EDGE_FOLD = 3, EDGE_FOLD_REPEAT = 4 };
-    constexpr unsigned kMaxSpectralLog2 = 20;                   // as hcv_spectral_size (hcv_api_fft.hip)
+    using hcv_api::kMaxSpectralLog2;
 
     struct OpSizes                                              // op_sizes, SpectralProcessor.hpp:318-357
     {
@@ -363,6 +363,11 @@ namespace
         }
         return ok ? 0 : -1;
     }
+}
+
+int hcv_api::spectral_real_general_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, bool correlate, float *out)
+{
+    return real_binary<float>({ in1, size1 }, { in2, size2 }, mode, correlate, out);
 }
 
 extern "C" int hcv_spectral_convolve_f64(const double *in1, size_t size1, const double *in2, size_t size2, int mode, double *out)

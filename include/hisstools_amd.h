@@ -168,7 +168,7 @@ HCV_API void hcv_convolver_clear_stats(hcv_convolver *h);
  * spectral_processor::convolve / correlate (SpectralProcessor.hpp:173-184; sizes :210-218,549-560).
  * mode: 0 Linear, 1 Wrap, 2 WrapCentre, 3 Fold, 4 FoldRepeat (EdgeMode, SpectralProcessor.hpp:22).
  * hcv_spectral_size = convolved_size = correlated_size: samples written to `out` (0 = nothing is written: an empty input,
- * or an FFT beyond 2^20 — the engine's "max_fft_size").  Returns 0 ok, -1 device failure. */
+ * or an FFT beyond 2^22 — the engine's "max_fft_size"; the _dev entries below stop at 2^20).  Returns 0 ok, -1 device failure. */
 HCV_API size_t hcv_spectral_size(size_t size1, size_t size2, int mode);
 HCV_API int hcv_spectral_convolve_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out);
 HCV_API int hcv_spectral_correlate_f32(const float *in1, size_t size1, const float *in2, size_t size2, int mode, float *out);

@@ -115,7 +115,8 @@ def test_gpu_large_sizes(sp, oracle, n1, n2):
 def test_gpu_sizes_and_limits(sp):
     assert sp.convolved_size(10, 4, 0) == 13 and sp.convolved_size(10, 4, 1) == 10 and sp.correlated_size(4, 10, 3) == 10
     assert sp.convolved_size(0, 4, 0) == 0
-    assert sp.convolved_size(1 << 20, 2, 0) == 0                  # would need a 2^21-point FFT: beyond the engine's maximum
+    assert sp.convolved_size(1 << 22, 2, 0) == 0                  # would need a 2^23-point FFT: beyond the engine's maximum
+    assert sp.convolved_size(1 << 20, 2, 0) == (1 << 20) + 1
     assert sp.convolve(np.zeros(0, np.float32), np.ones(3, np.float32), 0).size == 0
 
 

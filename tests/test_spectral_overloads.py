@@ -161,4 +161,25 @@ def test_gpu_limits_and_empty_operands(sp):
     a, b = np.arange(1, 6, dtype=np.float64), np.array([1.0, -2.0, 0.5])
     r, i = sp.convolve_complex(a, z64, z64, b, 0)
     assert np.abs(r).max() < 1e-12 and np.allclose(i, np.convolve(a, b), atol=1e-12)
-    assert sp.convolve(np.ones(1 << 20), np.ones(2), 0).size == 0            # would need a 2^21-point FFT
+    assert sp.convolve(np.ones(1 << 22), np.ones(2), 0).size == 0            # would need a 2^23-point FFT
+
+
+@pytest.mark.gpu
+def test_gpu_sizes_beyond_the_engine_fft(sp, oracle):
+    """circular sizes of 2^21 and 2^22: the float real overloads leave the convolution engine's kernels (<= 2^20) for the
+    general FFT surface; checked against the oracle and, sparsely, against the defining sum in float64"""
+    n1, n2 = 1_500_000, 700_000                                  # linear size 2.2 M -> 2^22
+    a, b = oracle.synth_audio(3, n1), oracle.synth_ir(3, 3, n2)
+    for corr in (False, True):
+        y = sp.correlate(a, b, 0) if corr else sp.convolve(a, b, 0)
+        ref = oracle.spectral_convolve(a, b, 0, correlate=corr)
+        assert y.dtype == np.float32 and y.shape == ref.shape
+        assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+    y = sp.convolve(a, b, 0)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    for k in (0, 5, 699_999, 1_000_000, 2_199_998):
+        lo, hi = max(0, k - n2 + 1), min(k, n1 - 1)
+        t = float(np.dot(a64[lo:hi + 1], b64[k - hi:k - lo + 1][::-1]))
+        assert abs(y[k] - t) <= 2e-5 * np.abs(y).max()
+    yd = sp.convolve(a64[:1_100_000], b64, 2)                    # double, WrapCentre, 2^21
+    assert np.abs(yd - oracle.spectral_convolve(a64[:1_100_000], b64, 2)).max() <= 1e-10 * np.abs(yd).max()

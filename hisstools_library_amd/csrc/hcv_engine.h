@@ -107,7 +107,7 @@ namespace hcv
         bool alloc_stage(Stage &st);
         void free_stage(Stage &st);
         bool global_reset();
-        bool fence_background();
+        bool fence_background(bool keep_plan = false);
         bool apply_pending_resets();
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
         size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }

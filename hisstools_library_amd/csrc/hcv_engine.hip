@@ -85,6 +85,15 @@ const float2 *twiddles(int device, int log2n, std::string *err)
 constexpr int kBgSlices = 16;
 constexpr int kTailHeadSplit = 8;
 
+// HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
+// per stage and its pending output is not withdrawn) — for A/B comparison only
+static bool exact_restart()
+{
+    static const bool on = !(std::getenv("HCV_EXACT_RESTART") && std::atoi(std::getenv("HCV_EXACT_RESTART")) == 0);
+    return on;
+}
+
+
 struct Engine::Stage
 {
     StageCfg cfg;
@@ -501,8 +510,9 @@ void Engine::set_td_window(uint64_t offset, uint64_t length)
 }
 
 // Control work (IR loads, resets, regrow) changes what a background accumulation reads or means: order it after any
-// background MAC still in flight and drop the pre-accumulated spectra.  Caller holds mMutex.
-bool Engine::fence_background()
+// background MAC still in flight and drop the pre-accumulated spectra — unless the caller keeps the plan and corrects them
+// itself (a restart of single pairs: retire_pair takes the pair out of the slices already accumulated).  Caller holds mMutex.
+bool Engine::fence_background(bool keep_plan)
 {
     for (Stage *st : mStages)
     {
@@ -511,7 +521,7 @@ bool Engine::fence_background()
             HCV_TRY(hipStreamWaitEvent(mStream, st->bg_done, 0));
             st->bg_pending = false;
         }
-        st->pre_hop = -1;
+        if (!keep_plan) st->pre_hop = -1;
     }
     return true;
 }
@@ -601,7 +611,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
 
     {
         std::lock_guard<std::mutex> g(mMutex);
-        if (!fence_background()) return false;
+        if (!fence_background(exact_restart())) return false;
         if (len && !device_ptr) HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mStream));
         const size_t pair = pair_index(in, out);
         // what the pair still has to deliver belongs to the spectra about to be replaced: take it out of the timelines now
@@ -698,14 +708,6 @@ bool Engine::global_reset()
 // ------------------------------------------------------------------------------------------------ exact per-pair restart
 // (see hcv_ghost.hip for the scheme).  All of it is control work on mStream, which every block's emit has ordered after
 // the stages' work; callers hold mMutex and have fenced the background accumulation.
-
-// HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
-// per stage and its pending output is not withdrawn) — for A/B comparison only
-static bool exact_restart()
-{
-    static const bool on = !(std::getenv("HCV_EXACT_RESTART") && std::atoi(std::getenv("HCV_EXACT_RESTART")) == 0);
-    return on;
-}
 
 void *Engine::ghost_alloc(size_t bytes)
 {
@@ -954,6 +956,43 @@ bool Engine::retire_pair(size_t pair)
         HCV_TRY(launch_timeline_sub(st.timeline + (size_t) o * st.tl_len, st.tl_len - 1, h_r * (long long) st.M, mRetireTmp + st.M, (int) st.M,
                                     1.f / (float) (8 * st.M), mN, mStream));
     }
+    // the deferred accumulation for the hop in progress: the slices launched so far hold the pair's products over frames it
+    // may no longer see — take them out of slot 0 (the slices still to come are fenced by hv like any other launch)
+    for (size_t si = 0; si < mStages.size(); si++)
+    {
+        Stage &st = *mStages[si];
+        if (st.pre_hop < 0 || st.bg_launched <= 0 || st.pact[pair] <= 1) continue;
+        const int per = (st.bg_parts + st.bg_slices - 1) / st.bg_slices;
+        const long long covered = std::min<long long>(std::min(st.bg_parts, st.bg_launched * per), (long long) st.pact[pair] - 1);
+        if (covered <= 0) continue;
+        MacShape sh;
+        sh.M = (int) st.M;
+        sh.R = (int) st.R;
+        sh.P = (int) covered;
+        sh.Pcap = (int) st.Pcap;
+        sh.nin = 1;
+        sh.nin_alloc = 1;
+        sh.nout = 1;
+        sh.diag = 0;
+        sh.T = 1;
+        sh.max_ksplit = (int) std::max<size_t>(1, st.y_elems / st.M);
+        sh.target_blocks = 0;
+        MacPlan pl;
+        mac_plan(sh, pl);
+        float2 *Y = st.Yq[0];
+        const float2 *H = st.Hs + pair * (size_t) st.Pcap * st.M + st.M;          // partitions 1 .. covered at hop pre_hop - 1
+        HCV_TRY(launch_spectral_mac(sh, pl, st.X + (size_t) row * st.R * st.M, H, Y, st.hv + pair, st.pre_hop - 1, true, mStream));
+        for (int e = 0; e < st.gh_count; e++)
+            if (st.gh_pair[e] == pair)
+            {
+                GhostEntry one = st.gh_host[e];
+                one.i = 0;
+                HCV_TRY(launch_ghost_mac(sh, H, Y, st.pre_hop - 1, nullptr, nullptr, &one, mStream));
+            }
+        HCV_TRY(launch_reduce_partials(Y, pl.ksplit, (long long) st.M, (long long) st.M, mStream));
+        HCV_TRY(launch_timeline_sub(reinterpret_cast<float *>(st.Ypre + (size_t) o * st.M), -1LL, 0, reinterpret_cast<const float *>(Y), 2 * (int) st.M, 1.f,
+                                    0, mStream));
+    }
     mCtlDirty = true;
     return true;
 }
@@ -968,7 +1007,7 @@ bool Engine::apply_pending_resets()
         if (mLoaded[p] && !mPending[p]) all = false;
     }
     if (!any) return true;
-    if (!fence_background()) return false;
+    if (!fence_background(!all && exact_restart())) return false;
     if (all)
     {
         if (!global_reset()) return false;
@@ -1033,6 +1072,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     {
         HCV_TRY(hipEventRecord(mEvCtl, mStream));
         HCV_TRY(hipStreamWaitEvent(mInStream, mEvCtl, 0));
+        // (deferred slices are launched without waiting for the block's input: order them after the control work directly)
+        for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvCtl, 0));
         mCtlDirty = false;
     }
     // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
@@ -1216,13 +1257,22 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
         }
         const bool full_matrix = nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+        // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
+        static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
+        static const int slices_env = std::getenv("HCV_BG_SLICES") ? std::atoi(std::getenv("HCV_BG_SLICES")) : kBgSlices;
         if (T <= 0)
         {
-            if (st.pre_hop >= 0)
+            if (st.pre_hop >= 0 && (!full_matrix || st.pre_hop != h_first)) st.pre_hop = -1;     // the plan no longer fits what is being processed
+            if (st.pre_hop < 0 && allow_defer && full_matrix && st.P > 1 && B < st.M && h_first >= 1)
             {
-                if (!full_matrix || st.pre_hop != h_first) st.pre_hop = -1;     // the plan no longer fits what is being processed
-                else if (!advance_background(st, false)) return false;
+                // no plan for the hop in progress (the first small call after large ones, or control work dropped it): make it
+                // now — the frames it needs are complete — so that the boundary does not pay the whole accumulation inline
+                st.bg_parts = (int) std::min<long long>(st.P - 1, h_first);
+                st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
+                st.bg_launched = 0;
+                st.pre_hop = h_first;
             }
+            if (st.pre_hop >= 0 && !advance_background(st, false)) return false;
             continue;
         }
 
@@ -1294,8 +1344,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
         const long long y_elems = (long long) T * nout_act * st.M;
 
-        // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
-        static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
         const bool defer = allow_defer && st.P > 0 && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && nout_act == mCfg.nout &&
                            nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
         const bool have_pre = defer && st.pre_hop == h_first;
@@ -1392,7 +1440,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         {
             // plan the background accumulation for hop h+1: partitions 1 .. min(P-1, h+1) (those that have input), in up to
             // kBgSlices launches that the following calls issue as the hop's samples arrive (advance_background)
-            static const int slices_env = std::getenv("HCV_BG_SLICES") ? std::atoi(std::getenv("HCV_BG_SLICES")) : kBgSlices;
             st.bg_parts = (int) std::min<long long>(st.P - 1, h_first + 1);
             st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
             st.bg_launched = 0;

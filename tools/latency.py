@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Per-call latency of synchronous small-block process() calls (real-time usage): tools/latency.py <workload> <block> [hops]
-Prints mean / p50 / p99 / max milliseconds per call and the real-time budget of the block at the workload's sample rate."""
+Prints mean / p50 / p99 / max milliseconds per call and the real-time budget of the block at the workload's sample rate.
+SWAP_EVERY=K replaces the IR of one (in, out) pair every K calls (a live IR swap: set_dev between two process calls) and
+reports the set() time and the latency of the call that follows (retiring + ghost spectra of the exact restart)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,13 +37,19 @@ bigy = torch.zeros((nout, 8192), device=dev)
 for _ in range(prime):
     conv.process_dev(big.data_ptr(), 8192, bigy.data_ptr(), 8192, nin, nout, 8192)
 conv.synchronize()
-ts = []
+ts, set_ms, after = [], [], []
+swap_every = int(os.environ.get("SWAP_EVERY", "0"))
 paced = os.environ.get("PACED", "1") != "0"      # real-time pacing: call k is issued no earlier than k * B / fs
 t_start = time.perf_counter()
 for k in range(ncalls):
     if paced:
         while time.perf_counter() < t_start + k * B / fs:
             pass
+    if swap_every and k and k % swap_every == 0:
+        t0 = time.perf_counter()
+        assert conv.set_dev((k // swap_every) % nin, (k // swap_every * 7) % nout, h.data_ptr(), L, True) == 0
+        set_ms.append((time.perf_counter() - t0) * 1e3)
+        after.append(k)
     t0 = time.perf_counter()
     conv.process_dev(xs.data_ptr(), B, ys.data_ptr(), B, nin, nout, B, sync=True)
     ts.append(time.perf_counter() - t0)
@@ -50,3 +58,6 @@ print(f"{w} block={B} paced={int(paced)} defer={os.environ.get('HCV_DEFER','1')}
       f"max={ts.max():.3f} ms | budget {1e3*B/fs:.3f} ms | sum={ts.sum():.1f} ms for {1e3*ncalls*B/fs:.1f} ms of audio")
 slow = [(i, round(float(t), 3)) for i, t in enumerate(ts) if t > 0.6]
 print("   calls > 0.6 ms:", slow[:24])
+if set_ms:
+    a = ts[after]
+    print(f"   live swaps: {len(set_ms)}; set() mean {np.mean(set_ms):.3f} max {np.max(set_ms):.3f} ms; the call after a swap mean {a.mean():.3f} max {a.max():.3f} ms")

@@ -17,4 +17,4 @@ for w in ${WORKLOADS:-c5 ns64 c4}; do
   [ -n "$T" ] && python tools/prof_summary.py "$T" 0.5 40 > $OUT/r01_${w}_kernel_summary.txt
   rm -rf $D
 done
-for spec in "ns64 128 3" "ns64 64 3" "c4 128 8"; do echo "latency $spec: $(python tools/latency.py $spec 2>&1 | grep -v amdgpu.ids | tr "\n" " ")" >> $OUT/latency.txt; done
+for spec in "ns64 128 3" "ns64 64 3" "c4 128 6" "c5 256 2"; do echo "latency $spec (SWAP_EVERY=37): $(SWAP_EVERY=37 python tools/latency.py $spec 2>&1 | grep -v amdgpu.ids | tr "\n" " ")" >> $OUT/latency.txt; done

@@ -138,6 +138,8 @@ namespace hcv
         hipStream_t mStream = nullptr, mInStream = nullptr, mTdStream = nullptr;
         hipEvent_t mEvInput[2] = { nullptr, nullptr }, mEvTd[2] = { nullptr, nullptr }, mEvEmit[2] = { nullptr, nullptr };
         hipEvent_t mEvCtl = nullptr;
+        hipEvent_t mEvSerial = nullptr;     // end of a run of serial blocks (see enqueue_chunk)
+        bool mPrevSerial = false;           // the previous block ran serially on the main stream
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         uint64_t mBlockCount = 0;
 

@@ -131,6 +131,7 @@ struct Engine::Stage
     int gh_count = 0;
     long long gh_min_hr = 0, gh_max_hr = 0;
     std::vector<uint32_t> pact;
+    uint64_t live_parts = 0;            // sum of pact
     const float2 *tw = nullptr;
     // stats
     uint64_t launches = 0, hops = 0;
@@ -246,6 +247,7 @@ bool Engine::init(const EngineCfg &cfg)
         HCV_TRY(hipEventCreateWithFlags(&mEvEmit[k], hipEventDisableTiming));
     }
     HCV_TRY(hipEventCreateWithFlags(&mEvCtl, hipEventDisableTiming));
+    HCV_TRY(hipEventCreateWithFlags(&mEvSerial, hipEventDisableTiming));
 
     // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
     mHistLen = pow2ceil(3LL * mMaxBlock + std::max<long long>(nmax, 4096));
@@ -466,6 +468,7 @@ Engine::~Engine()
         if (mEvEmit[k]) (void) hipEventDestroy(mEvEmit[k]);
     }
     if (mEvCtl) (void) hipEventDestroy(mEvCtl);
+    if (mEvSerial) (void) hipEventDestroy(mEvSerial);
     if (mGhostHist) (void) hipFree(mGhostHist);
     if (mRetireTmp) (void) hipFree(mRetireTmp);
     if (mGhostPin) (void) hipHostFree(mGhostPin);
@@ -633,6 +636,8 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
                 const float *src = seg ? dsrc + st.cfg.offset : mHist;              // never dereferenced when seg == 0
                 HCV_TRY(launch_rfft_ir(st.log2n, src, (long long) seg, (int) wr, st.Hs + pair * (size_t) st.Pcap * st.M, st.tw, &st.big, mStream));
             }
+            st.live_parts += newP;
+            st.live_parts -= st.pact[pair];
             st.pact[pair] = newP;
             st.P = *std::max_element(st.pact.begin(), st.pact.end());
             any = any || newP;
@@ -1066,25 +1071,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
     const int q = (int) (mBlockCount & 1);
 
-    if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
-    // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
-    if (mCtlDirty)
-    {
-        HCV_TRY(hipEventRecord(mEvCtl, mStream));
-        HCV_TRY(hipStreamWaitEvent(mInStream, mEvCtl, 0));
-        // (deferred slices are launched without waiting for the block's input: order them after the control work directly)
-        for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvCtl, 0));
-        mCtlDirty = false;
-    }
-    // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
-    static const bool pipeline = !(std::getenv("HCV_PIPELINE") && std::atoi(std::getenv("HCV_PIPELINE")) == 0);
-    if (!pipeline) HCV_TRY(hipStreamWaitEvent(mInStream, mEvEmit[q ^ 1], 0));
-    // the block two back read the history this scatter may overwrite
-    for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(mInStream, st->done[q], 0));
-    HCV_TRY(hipStreamWaitEvent(mInStream, mEvTd[q], 0));
-    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, mInStream));
-    HCV_TRY(hipEventRecord(mEvInput[q], mInStream));
-
     const bool td_any = mCfg.has_td && mTdLpad > 0;
     const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
     // Whole-hop mode: the block is made of whole, aligned hops of the last stage.  Every output sample of such a block only
@@ -1101,14 +1087,62 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // hop-aligned block of a larger matrix: the head goes through the first stage's FFTs (see init)
     const bool head_fft = !whole_hops && td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
     const bool td = td_any && !head_fft && !whole_hops;
+
+    // Serial blocks: everything on the main stream, in program order, with no events at all.  A dependency on a pending event
+    // of another stream costs the host ~10 us (a kernel launch 2.6, an event record 1.7 — tools/micro/api_cost.hip), so a
+    // small engine running one stage per block (whole-hop mode: 26 calls, five such dependencies, 111 us of host time for
+    // 60 us of kernels on the 8x1 workload) is bound by its own enqueue; big engines keep the overlap.  HCV_SERIAL = 0 / 1
+    // forces the choice for whole-hop blocks; single-stream engines are always serial.
+    static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
+    static const double serial_mb = std::getenv("HCV_SERIAL_MB") ? std::atof(std::getenv("HCV_SERIAL_MB")) : 256.0;
+    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0
+                                                                        : (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < serial_mb * 1048576.0));
+    hipStream_t sIn = serial ? mStream : mInStream, sTd = serial ? mStream : mTdStream;
+    auto rec = [&](hipEvent_t e, hipStream_t s) -> hipError_t { return serial ? hipSuccess : hipEventRecord(e, s); };
+    auto wt = [&](hipStream_t s, hipEvent_t e) -> hipError_t { return serial ? hipSuccess : hipStreamWaitEvent(s, e, 0); };
+    if (serial && !mPrevSerial)
+    {
+        // the previous block's emit waited for all of its work, so the main stream is already behind everything except
+        // background slices still in flight on a stage's own stream
+        for (Stage *st : mStages)
+            if (st->bg_pending) HCV_TRY(hipStreamWaitEvent(mStream, st->bg_done, 0));
+    }
+    else if (!serial && mPrevSerial)
+    {
+        // back to the streams: they start behind everything the serial blocks put on the main stream
+        HCV_TRY(hipEventRecord(mEvSerial, mStream));
+        HCV_TRY(hipStreamWaitEvent(mInStream, mEvSerial, 0));
+        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvSerial, 0));
+        for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvSerial, 0));
+    }
+    mPrevSerial = serial;
+    if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
+    // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
+    if (mCtlDirty)
+    {
+        HCV_TRY(rec(mEvCtl, mStream));
+        HCV_TRY(wt(sIn, mEvCtl));
+        // (deferred slices are launched without waiting for the block's input: order them after the control work directly)
+        for (Stage *st : mStages) HCV_TRY(wt(st->stream, mEvCtl));
+        mCtlDirty = false;
+    }
+    // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
+    static const bool pipeline = !(std::getenv("HCV_PIPELINE") && std::atoi(std::getenv("HCV_PIPELINE")) == 0);
+    if (!pipeline) HCV_TRY(wt(sIn, mEvEmit[q ^ 1]));
+    // the block two back read the history this scatter may overwrite
+    for (Stage *st : mStages) HCV_TRY(wt(sIn, st->done[q]));
+    HCV_TRY(wt(sIn, mEvTd[q]));
+    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
+    HCV_TRY(rec(mEvInput[q], sIn));
+
     if (td)
     {
-        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvInput[q], 0));
-        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvEmit[q], 0));      // emit(k-2) has consumed tdout[q]
+        HCV_TRY(wt(sTd, mEvInput[q]));
+        HCV_TRY(wt(sTd, mEvEmit[q]));      // emit(k-2) has consumed tdout[q]
         const bool check = td_check;
         HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
-                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, mTdStream));
-        HCV_TRY(hipEventRecord(mEvTd[q], mTdStream));
+                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, sTd));
+        HCV_TRY(rec(mEvTd[q], sTd));
     }
 
     EmitSources src;
@@ -1151,6 +1185,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // a (b - a)-partition MAC at hop pre_hop - 1 - a over the spectra shifted by 1 + a partitions.
     auto advance_background = [&](Stage &st, bool boundary) -> bool
     {
+        const hipStream_t sS = serial ? mStream : st.stream;
         if (st.pre_hop < 0 || st.bg_launched >= st.bg_slices) return true;
         const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M;
         int due = boundary ? st.bg_slices : (int) std::min<long long>(st.bg_slices, std::max<long long>(0, into * st.bg_slices / (long long) st.M));
@@ -1162,7 +1197,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             float2 *slot = st.Ypre + (long long) st.bg_launched * slot_elems;
             if (b <= a)
             {
-                HCV_TRY(hipMemsetAsync(slot, 0, sizeof(float2) * slot_elems, st.stream));
+                HCV_TRY(hipMemsetAsync(slot, 0, sizeof(float2) * slot_elems, sS));
                 continue;
             }
             MacShape sb;
@@ -1182,10 +1217,10 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             const long long hop = st.pre_hop - 1 - a;
             const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
             float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
-            if (!mac(st, sb, pb, st.Hs + (size_t) (1 + a) * st.M, scratch, hop, bcheck, st.stream)) return false;
-            HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, st.stream));
-            HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, st.stream));
-            HCV_TRY(hipEventRecord(st.bg_done, st.stream));
+            if (!mac(st, sb, pb, st.Hs + (size_t) (1 + a) * st.M, scratch, hop, bcheck, sS)) return false;
+            HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS));
+            HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, sS));
+            HCV_TRY(hipEventRecord(st.bg_done, sS));
             st.bg_pending = true;
         }
         return true;
@@ -1196,16 +1231,17 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     {
         const size_t si = mStages.size() - 1 - sj;
         Stage &st = *mStages[si];
+        const hipStream_t sS = serial ? mStream : st.stream;
         if (whole_hops && si != last)
         {
             if (entering)
             {
                 // this stage's pending results duplicate what the last stage now computes: drop them (after the emit that
                 // may still be reading them) together with any plan of a deferred accumulation
-                HCV_TRY(hipStreamWaitEvent(st.stream, mEvEmit[q ^ 1], 0));
-                HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, st.stream));
-                HCV_TRY(hipEventRecord(st.done[q], st.stream));
-                HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+                HCV_TRY(wt(sS, mEvEmit[q ^ 1]));
+                HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, sS));
+                HCV_TRY(rec(st.done[q], sS));
+                HCV_TRY(wt(mStream, st.done[q]));
                 st.pre_hop = -1;
             }
             continue;
@@ -1225,13 +1261,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const int T = (int) ((n0 + B) / st.M - h_first);
         if (leaving && si != last && st.P && h_first >= 1)
         {
-            HCV_TRY(hipStreamWaitEvent(st.stream, mEvInput[q], 0));
+            HCV_TRY(wt(sS, mEvInput[q]));
             st.Y = st.Yq[q];
             // back from whole-hop mode: this stage was not run for a while.  Rebuild the input spectra its partitions reach
             // back to from the history ring, and compute the hop just before this block — its result is emitted during the
             // first hop of the block (every stage has one hop of latency).
             const long long h_lo = std::max<long long>(0, h_first - (long long) st.P);
-            HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_lo, (int) (h_first - h_lo), (int) rows_in, st.X, (int) st.R, st.tw, &st.big, st.stream));
+            HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_lo, (int) (h_first - h_lo), (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sS));
             MacShape sc;
             sc.M = (int) st.M;
             sc.R = (int) st.R;
@@ -1248,13 +1284,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             mac_plan(sc, pc);
             const bool ccheck = (h_first - 1 - st.max_hv) < (long long) st.P - 1;
             const long long c_elems = (long long) nout_act * st.M;
-            if (!mac(st, sc, pc, st.Hs, st.Y, h_first - 1, ccheck, st.stream)) return false;
-            HCV_TRY(launch_reduce_partials(st.Y, pc.ksplit, c_elems, c_elems, st.stream));
-            HCV_TRY(hipStreamWaitEvent(st.stream, mEvEmit[q], 0));        // emit(k-2) has cleared the timeline span reused now
+            if (!mac(st, sc, pc, st.Hs, st.Y, h_first - 1, ccheck, sS)) return false;
+            HCV_TRY(launch_reduce_partials(st.Y, pc.ksplit, c_elems, c_elems, sS));
+            HCV_TRY(wt(sS, mEvEmit[q]));        // emit(k-2) has cleared the timeline span reused now
             HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, c_elems, h_first - 1, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
-                                             &st.big, st.stream));
-            HCV_TRY(hipEventRecord(st.done[q], st.stream));          // (recorded again below when this block has hops of its own)
-            HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+                                             &st.big, sS));
+            HCV_TRY(rec(st.done[q], sS));          // (recorded again below when this block has hops of its own)
+            HCV_TRY(wt(mStream, st.done[q]));
         }
         const bool full_matrix = nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
         // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
@@ -1278,13 +1314,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
         // one stream per stage: forward FFT, MAC, inverse.  (Side streams for a large stage's FFTs were built and measured
         // twice — dedicated ones and the input / main streams — and were slower each time: c5 2.12 / 2.33 vs 1.98 ms per step.)
-        hipStream_t sM = st.stream, sF = st.stream, sI = st.stream;
+        hipStream_t sM = sS, sF = sS, sI = sS;
         st.Y = st.Yq[q];
 
-        HCV_TRY(hipStreamWaitEvent(sF, mEvInput[q], 0));
-        if (gate && tail_gate >= 2) HCV_TRY(hipStreamWaitEvent(sF, gate, 0));
+        HCV_TRY(wt(sF, mEvInput[q]));
+        if (gate && tail_gate >= 2) HCV_TRY(wt(sF, gate));
         HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
-        if (gate && tail_gate == 1) HCV_TRY(hipStreamWaitEvent(sM, gate, 0));
+        if (gate && tail_gate == 1) HCV_TRY(wt(sM, gate));
         if (head_here)
         {
             // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
@@ -1303,20 +1339,20 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             MacPlan hp;
             mac_plan(hs, hp);
             static const bool head_side = !(std::getenv("HCV_HEAD_STREAM") && std::atoi(std::getenv("HCV_HEAD_STREAM")) == 0);
-            if (tail_head_here && head_side && !mOneStream)
+            if (tail_head_here && head_side && !serial)
             {
                 // whole-hop mode: the head partition's MAC, reduction and inverse run on the otherwise idle head stream, beside
                 // the tail MAC, so the last stage's own stream carries only FFT -> MAC -> reduce -> inverse (c4 853 -> 917,
                 // c5 66.4 -> 68.2, c3 72 -> 84 Msamples/s).  Both inverses add into the same timeline; the adds are atomic.
-                HCV_TRY(hipEventRecord(st.mac_done[q], sM));                       // = "forward FFTs of this block are done"
-                HCV_TRY(hipStreamWaitEvent(mTdStream, st.mac_done[q], 0));
-                HCV_TRY(hipStreamWaitEvent(mTdStream, mEvEmit[q], 0));
+                HCV_TRY(rec(st.mac_done[q], sM));                       // = "forward FFTs of this block are done"
+                HCV_TRY(wt(sTd, st.mac_done[q]));
+                HCV_TRY(wt(sTd, mEvEmit[q]));
                 const long long he = (long long) T * nout_act * st.M;
-                if (!mac(st, hs, hp, head_spec, head_y, h_first, false, mTdStream)) return false;
-                HCV_TRY(launch_reduce_partials(head_y, hp.ksplit, he, he, mTdStream));
+                if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sTd)) return false;
+                HCV_TRY(launch_reduce_partials(head_y, hp.ksplit, he, he, sTd));
                 HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
-                                                 &st.big, mTdStream));
-                HCV_TRY(hipEventRecord(mEvTd[q], mTdStream));
+                                                 &st.big, sTd));
+                HCV_TRY(rec(mEvTd[q], sTd));
                 head_on_side = true;
             }
             else
@@ -1398,12 +1434,12 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         }
         if (tail_gate && sj == 0 && mStages.size() > 1 && !mOneStream && st.P && !defer && !have_pre)
         {
-            HCV_TRY(hipEventRecord(st.mac_done[q], sM));
+            HCV_TRY(rec(st.mac_done[q], sM));
             gate = st.mac_done[q];
         }
 
         // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
-        HCV_TRY(hipStreamWaitEvent(sI, mEvEmit[q], 0));             // emit(k-2) has cleared the timeline span reused now
+        HCV_TRY(wt(sI, mEvEmit[q]));             // emit(k-2) has cleared the timeline span reused now
         if (head_here && !head_on_side)
         {
             HCV_TRY(launch_reduce_partials(head_y, head_ksplit, (long long) T * nout_act * st.M, (long long) T * nout_act * st.M, sI));
@@ -1432,8 +1468,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
                                                  &st.big, sI));
             }
         }
-        HCV_TRY(hipEventRecord(st.done[q], sI));
-        HCV_TRY(hipStreamWaitEvent(mStream, st.done[q], 0));
+        HCV_TRY(rec(st.done[q], sI));
+        HCV_TRY(wt(mStream, st.done[q]));
 
         st.pre_hop = -1;
         if (defer)
@@ -1447,10 +1483,10 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         }
     }
 
-    if (td || whole_hops) HCV_TRY(hipStreamWaitEvent(mStream, mEvTd[q], 0));
-    HCV_TRY(hipStreamWaitEvent(mStream, mEvInput[q], 0));           // a block with no live stage still orders after its scatter
+    if (td || whole_hops) HCV_TRY(wt(mStream, mEvTd[q]));
+    HCV_TRY(wt(mStream, mEvInput[q]));           // a block with no live stage still orders after its scatter
     HCV_TRY(launch_emit(src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
-    HCV_TRY(hipEventRecord(mEvEmit[q], mStream));
+    HCV_TRY(rec(mEvEmit[q], mStream));
     mN += B;
     mBlockCount++;
     mLastNin = rows_in;
@@ -1473,7 +1509,13 @@ bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_a
         {
             std::lock_guard<std::mutex> g(mMutex);
             if (!apply_pending_resets()) return false;
-            if (rows_in) HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mInStream));
+            // the upload goes on the main stream and is handed to the block like control work: a serial block scatters on the
+            // main stream, a streamed one makes its input stream wait for it (enqueue_chunk, mCtlDirty)
+            if (rows_in)
+            {
+                HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
+                mCtlDirty = true;
+            }
             if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
             HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
         }

@@ -139,3 +139,44 @@ def test_restart_then_full_reset_and_regrow(H, oracle):
     script = [(10_007, lambda c: c.set(0, 0, irs[(1, 1)], True)), (14_000, lambda c: c.reset()), (30_001, lambda c: c.set(1, 0, long_ir, True)),
               (31_000, lambda c: c.set(0, 1, long_ir, True))]
     both(H, oracle, lambda ns: loaded(ns, 2, 2, 0, irs), xs, 2, script, 333)
+
+
+def test_many_restarts_soak(H, oracle):
+    """300 live swaps / restarts / clears in one stream, several of them alive at any time (IR 12000 samples, an event every
+    1000): ghost-spectrum blocks are pooled and re-used, expired entries pruned, tables rebuilt — the output stays exact and
+    device memory stops growing once the pool has reached its working size."""
+    import torch
+    nin, nout, L, S = 3, 3, 12_000, 300_000
+    rng = np.random.default_rng(9)
+    xs = np.stack([oracle.synth_audio(80 + i, S) for i in range(nin)])
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    script = []
+    for k in range(1, 300):
+        pos = 1000 * k + int(rng.integers(0, 999))
+        i, o = int(rng.integers(0, nin)), int(rng.integers(0, nout))
+        what = k % 7
+        if what == 5:
+            script.append((pos, lambda c, i=i, o=o: c.reset(i, o)))
+        elif what == 6:
+            script.append((pos, lambda c, i=i, o=o: c.clear(i, o, False)))
+        else:
+            h = oracle.synth_ir(int(rng.integers(0, 50)), o, int(rng.integers(2000, L)))
+            script.append((pos, lambda c, i=i, o=o, h=h: c.set(i, o, h, True)))
+    ref, gpu = loaded(oracle, nin, nout, 0, irs), loaded(H, nin, nout, 0, irs)
+    y_ref = drive(ref, xs, nout, script, 1024)
+    torch.cuda.synchronize()
+    free = []
+    cuts = sorted({0, S} | {pos for pos, _ in script})
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        for pos, fn in script:
+            if pos == a:
+                fn(gpu)
+        out.append(gpu.run(np.ascontiguousarray(xs[:, a:b]), nout, [128, 500, 64]))
+        free.append(torch.cuda.mem_get_info()[0])
+    y = np.concatenate(out, axis=1)
+    peak = float(np.abs(y_ref).max())
+    for o in range(nout):
+        assert float(np.abs(y[o].astype(np.float64) - y_ref[o]).max()) / peak < TOL_SUM, o
+    # the second half of the run allocates nothing new
+    assert min(free[len(free) // 2:]) >= min(free[: len(free) // 2]) - (1 << 20), (min(free[: len(free) // 2]), min(free[len(free) // 2:]))

@@ -180,3 +180,28 @@ def test_many_restarts_soak(H, oracle):
         assert float(np.abs(y[o].astype(np.float64) - y_ref[o]).max()) / peak < TOL_SUM, o
     # the second half of the run allocates nothing new
     assert min(free[len(free) // 2:]) >= min(free[: len(free) // 2]) - (1 << 20), (min(free[: len(free) // 2]), min(free[len(free) // 2:]))
+
+
+@pytest.mark.parametrize("block", [[8192, 32768, 1000, 333], 256])
+def test_ir_swap_on_the_extended_ladder(H, oracle, block):
+    """the MI355X far-tail ladder (FFTs of 131072 and 1048576 points through the four-step transforms): ghost spectra and the
+    retiring of pending output go through the same big-FFT kernels; checked against float64 ground truth"""
+    from scipy.signal import fftconvolve
+    L, S, cut = 700_000, 900_000, 300_000 + 4321
+    if block == 256:
+        S, cut = 420_000, 200_000 + 77
+    xs = np.stack([oracle.synth_audio(90 + i, S) for i in range(2)])
+    h0, h1, h1n = oracle.synth_ir(0, 0, L), oracle.synth_ir(1, 0, L - 5000), oracle.synth_ir(6, 6, L - 100_000)
+    c = H.Convolver(2, 1, custom=(L, True, 256, 1024, 4096, 16384), tailRatio=8, maxBlock=32768)
+    assert c.set(0, 0, h0, True) == 0 and c.set(1, 0, h1, True) == 0
+    y_a = c.run(np.ascontiguousarray(xs[:, :cut]), 1, block)[0]
+    assert c.set(1, 0, h1n, True) == 0
+    y_b = c.run(np.ascontiguousarray(xs[:, cut:]), 1, block)[0]
+    y = np.concatenate([y_a, y_b])
+    f = lambda x, h: fftconvolve(x.astype(np.float64), h.astype(np.float64))[:S]      # noqa: E731
+    x1_after = xs[1].copy()
+    x1_after[:cut] = 0
+    before = f(xs[1], h1)
+    before[cut:] = 0
+    truth = f(xs[0], h0) + before + f(x1_after, h1n)
+    assert float(np.abs(y - truth).max()) / float(np.abs(truth).max()) < TOL_SUM

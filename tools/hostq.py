@@ -3,6 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, numpy as np
 import hisstools_library_amd as H
 import bench
+B_ENV = int(os.environ.get("BLOCK", "8192"))
 for w in sys.argv[1:]:
     nin, nout, L, fs, layout = bench.WORKLOADS[w]
     dev = torch.device("cuda", 0)
@@ -11,7 +12,7 @@ for w in sys.argv[1:]:
     for o in range(nout):
         for i in range(nin):
             torch.cuda.synchronize(); assert conv.set_dev(i, o, h.data_ptr(), L, True) == 0
-    B = 8192
+    B = B_ENV
     xs = torch.rand((nin, B), device=dev); ys = torch.zeros((nout, B), device=dev)
     for _ in range(100): conv.process_dev(xs.data_ptr(), B, ys.data_ptr(), B, nin, nout, B)
     conv.synchronize()

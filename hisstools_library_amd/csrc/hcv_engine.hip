@@ -1162,9 +1162,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         for (size_t si = 0; si < mStages.size(); si++)
         {
             const Stage &sg = *mStages[si];
-            size_t live_p = 0;
-            for (uint32_t p : sg.pact) live_p += p;
-            const double bytes = (double) live_p * sg.M * sizeof(float2);
+            const double bytes = (double) sg.live_parts * sg.M * sizeof(float2);
             const double hops = (double) ((n0 + B) / sg.M - n0 / sg.M);
             if (si + 1 == mStages.size()) tail_bytes = bytes * std::max(1.0, hops / 8.0);
             else

@@ -109,7 +109,12 @@ namespace hcv
         bool global_reset();
         bool fence_background(bool keep_plan = false);
         bool apply_pending_resets();
+        struct Block;
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
+        bool enqueue_stage(Block &blk, size_t si, size_t sj);
+        static MacShape mac_shape(const Stage &st, int P, int Pcap, int nin, int nin_alloc, int nout, int diag, int T, int max_ksplit);
+        bool advance_background(const Block &blk, Stage &st, bool boundary);
+        bool catch_up_stage(const Block &blk, Stage &st, long long h_first);
         size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }
         void collect_events();
         // exact per-pair restart (hcv_ghost.hip): ghost spectra of the input before the restart, the pair's pending output retired

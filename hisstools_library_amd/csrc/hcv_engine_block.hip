@@ -1,0 +1,495 @@
+// The per-block scheduler of the engine: which kernels one process() block launches, on which streams and in which order
+// (stream plan in front of enqueue_chunk), and the host- and device-pointer entry points that feed it.
+
+#include "hcv_engine_impl.h"
+
+namespace hcv
+{
+
+// Launch the background slices of `st` that are due: all of them at the hop's boundary, otherwise in proportion to the
+// part of the hop's samples that has arrived with this call.  Slice s covers partitions 1 + [a, b) of hop pre_hop:
+// a (b - a)-partition MAC at hop pre_hop - 1 - a over the spectra shifted by 1 + a partitions.
+bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
+{
+    HCV_BLOCK_LOCALS(blk);
+    const hipStream_t sS = serial ? mStream : st.stream;
+    if (st.pre_hop < 0 || st.bg_launched >= st.bg_slices) return true;
+    const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M;
+    int due = boundary ? st.bg_slices : (int) std::min<long long>(st.bg_slices, std::max<long long>(0, into * st.bg_slices / (long long) st.M));
+    const int per = (st.bg_parts + st.bg_slices - 1) / st.bg_slices;
+    const long long slot_elems = (long long) mCfg.nout * st.M;
+    for (; st.bg_launched < due; st.bg_launched++)
+    {
+        const int a = st.bg_launched * per, b = std::min(st.bg_parts, a + per);
+        float2 *slot = st.Ypre + (long long) st.bg_launched * slot_elems;
+        if (b <= a)
+        {
+            HCV_TRY(hipMemsetAsync(slot, 0, sizeof(float2) * slot_elems, sS));
+            continue;
+        }
+        const MacShape sb = mac_shape(st, /* P */ b - a, /* Pcap */ (int) st.Pcap,
+                                      /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) mCfg.nout, /* diag */ mCfg.diag ? 1 : 0,
+                                      /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) mCfg.nout * st.M)));       // (full matrix only)
+        MacPlan pb;
+        mac_plan(sb, pb);
+        const long long hop = st.pre_hop - 1 - a;
+        const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
+        float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
+        if (!mac(st, sb, pb, st.Hs + (size_t) (1 + a) * st.M, scratch, hop, bcheck, sS)) return false;
+        HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS));
+        HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, sS));
+        HCV_TRY(hipEventRecord(st.bg_done, sS));
+        st.bg_pending = true;
+    }
+    return true;
+}
+
+// Back from whole-hop mode: this stage was not run for a while.  Rebuild the input spectra its partitions reach back to from the
+// history ring, and compute the hop just before this block — its result is emitted during the first hop of the block (every
+// stage has one hop of latency).
+bool Engine::catch_up_stage(const Block &blk, Stage &st, long long h_first)
+{
+    HCV_BLOCK_LOCALS(blk);
+    const hipStream_t sS = blk.stage_stream(st.stream);
+    HCV_TRY(wt(sS, mEvInput[q]));
+    st.Y = st.Yq[q];
+    const long long h_lo = std::max<long long>(0, h_first - (long long) st.P);
+    HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_lo, (int) (h_first - h_lo), (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sS));
+    const MacShape sc = mac_shape(st, /* P */ (int) std::min<long long>(st.P, h_first), /* Pcap */ (int) st.Pcap,
+                                  /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
+                                  /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M)));
+    MacPlan pc;
+    mac_plan(sc, pc);
+    const bool ccheck = (h_first - 1 - st.max_hv) < (long long) st.P - 1;
+    const long long c_elems = (long long) nout_act * st.M;
+    if (!mac(st, sc, pc, st.Hs, st.Y, h_first - 1, ccheck, sS)) return false;
+    HCV_TRY(launch_reduce_partials(st.Y, pc.ksplit, c_elems, c_elems, sS));
+    HCV_TRY(wt(sS, mEvEmit[q]));        // emit(k-2) has cleared the timeline span reused now
+    HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, c_elems, h_first - 1, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                     &st.big, sS));
+    HCV_TRY(rec(st.done[q], sS));          // (recorded again below when this block has hops of its own)
+    HCV_TRY(wt(mStream, st.done[q]));
+    return true;
+}
+
+// One stage's share of a block: forward FFTs of the hops the block completes, the spectral MAC (with the head partition where
+// the mode has one), the inverse into the stage's timeline — or, when the block completes no hop of this stage, the deferred
+// slices that are due.  sj counts from the largest stage (0 = the tail, launched first: its MAC is the critical path).
+bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
+{
+    HCV_BLOCK_LOCALS(blk);
+    Stage &st = *mStages[si];
+    const hipStream_t sS = serial ? mStream : st.stream;
+    if (whole_hops && si != last)
+    {
+        if (entering)
+        {
+            // this stage's pending results duplicate what the last stage now computes: drop them (after the emit that
+            // may still be reading them) together with any plan of a deferred accumulation
+            HCV_TRY(wt(sS, mEvEmit[q ^ 1]));
+            HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, sS));
+            HCV_TRY(rec(st.done[q], sS));
+            HCV_TRY(wt(mStream, st.done[q]));
+            st.pre_hop = -1;
+        }
+        return true;
+    }
+    blk.src.timeline[blk.src.count] = st.timeline;              // the ring may still hold hops of earlier calls
+    blk.src.stride[blk.src.count] = st.tl_len;
+    blk.src.mask[blk.src.count] = st.tl_len - 1;
+    blk.src.count++;
+    const bool tail_head_here = whole_hops && si == last;
+    int head_ksplit = 1;
+    bool head_on_side = false;
+    const bool head_here = (head_fft && si == 0) || tail_head_here;
+    const float2 *head_spec = tail_head_here ? mTailHeadSpec : mHeadSpec;
+    float2 *head_y = tail_head_here ? mTailHeadYq[q] : mHeadYq[q];
+    if (!st.P && !head_here) return true;
+    const long long h_first = n0 / st.M;
+    const int T = (int) ((n0 + B) / st.M - h_first);
+    if (leaving && si != last && st.P && h_first >= 1 && !catch_up_stage(blk, st, h_first)) return false;
+    // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
+    static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
+    static const int slices_env = std::getenv("HCV_BG_SLICES") ? std::atoi(std::getenv("HCV_BG_SLICES")) : kBgSlices;
+    if (T <= 0)
+    {
+        if (st.pre_hop >= 0 && (!full_matrix || st.pre_hop != h_first)) st.pre_hop = -1;     // the plan no longer fits what is being processed
+        if (st.pre_hop < 0 && allow_defer && full_matrix && st.P > 1 && B < st.M && h_first >= 1)
+        {
+            // no plan for the hop in progress (the first small call after large ones, or control work dropped it): make it
+            // now — the frames it needs are complete — so that the boundary does not pay the whole accumulation inline
+            st.bg_parts = (int) std::min<long long>(st.P - 1, h_first);
+            st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
+            st.bg_launched = 0;
+            st.pre_hop = h_first;
+        }
+        if (st.pre_hop >= 0 && !advance_background(blk, st, false)) return false;
+        return true;
+    }
+
+    // one stream per stage: forward FFT, MAC, inverse.  (Side streams for a large stage's FFTs were built and measured
+    // twice — dedicated ones and the input / main streams — and were slower each time: c5 2.12 / 2.33 vs 1.98 ms per step.)
+    hipStream_t sM = sS, sF = sS, sI = sS;
+    st.Y = st.Yq[q];
+
+    HCV_TRY(wt(sF, mEvInput[q]));
+    if (blk.gate && tail_gate >= 2) HCV_TRY(wt(sF, blk.gate));
+    HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
+    if (blk.gate && tail_gate == 1) HCV_TRY(wt(sM, blk.gate));
+    if (head_here)
+    {
+        // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
+        const MacShape hs = mac_shape(st, /* P */ 1, /* Pcap */ 1,
+                                      /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
+                                      /* T */ T, /* max_ksplit */ tail_head_here ? kTailHeadSplit : 1);
+        MacPlan hp;
+        mac_plan(hs, hp);
+        static const bool head_side = !(std::getenv("HCV_HEAD_STREAM") && std::atoi(std::getenv("HCV_HEAD_STREAM")) == 0);
+        if (tail_head_here && head_side && !serial)
+        {
+            // whole-hop mode: the head partition's MAC, reduction and inverse run on the otherwise idle head stream, beside
+            // the tail MAC, so the last stage's own stream carries only FFT -> MAC -> reduce -> inverse (c4 853 -> 917,
+            // c5 66.4 -> 68.2, c3 72 -> 84 Msamples/s).  Both inverses add into the same timeline; the adds are atomic.
+            HCV_TRY(rec(st.mac_done[q], sM));                       // = "forward FFTs of this block are done"
+            HCV_TRY(wt(sTd, st.mac_done[q]));
+            HCV_TRY(wt(sTd, mEvEmit[q]));
+            const long long he = (long long) T * nout_act * st.M;
+            if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sTd)) return false;
+            HCV_TRY(launch_reduce_partials(head_y, hp.ksplit, he, he, sTd));
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                             &st.big, sTd));
+            HCV_TRY(rec(mEvTd[q], sTd));
+            head_on_side = true;
+        }
+        else
+        {
+            if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sM)) return false;
+            head_ksplit = hp.ksplit;
+        }
+    }
+
+    // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
+    // reference, PartitionedConvolve.cpp:285,322,373): right after a reset the reduction is short
+    const long long p_live = std::min<long long>(st.P, h_first + T);
+    MacShape sh = mac_shape(st, /* P */ (int) p_live, /* Pcap */ (int) st.Pcap,
+                            /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
+                            /* T */ T, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M)));
+    const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
+    const long long y_elems = (long long) T * nout_act * st.M;
+
+    const bool defer = allow_defer && st.P > 0 && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && nout_act == mCfg.nout &&
+                       nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+    const bool have_pre = defer && st.pre_hop == h_first;
+
+    EventPair *ev = nullptr;
+    auto begin_event = [&]() -> bool
+    {
+        if (!mProfiling) return true;
+        for (EventPair *c : mEvents)
+            if (!c->live) { ev = c; break; }
+        if (!ev)
+        {
+            ev = new EventPair();
+            HCV_TRY(hipEventCreate(&ev->a));
+            HCV_TRY(hipEventCreate(&ev->b));
+            mEvents.push_back(ev);
+        }
+        ev->stage = si;
+        ev->live = true;
+        HCV_TRY(hipEventRecord(ev->a, sM));
+        return true;
+    };
+
+    // ---- MAC phase (stream sM)
+    MacPlan pl;
+    pl.ksplit = 1;
+    if (st.P)
+    {
+        if (have_pre)
+        {
+            // boundary of a hop whose partitions 1..P-1 were accumulated in the background: whatever slices are still
+            // due, their total into slot 0, then partition 0 only
+            if (!advance_background(blk, st, true)) return false;
+            HCV_TRY(launch_reduce_partials(st.Ypre, st.bg_slices, (long long) mCfg.nout * st.M, (long long) mCfg.nout * st.M, sM));
+            MacShape s0 = sh;
+            s0.P = 1;
+            s0.max_ksplit = 1;
+            mac_plan(s0, pl);
+            if (!mac(st, s0, pl, st.Hs, st.Y, h_first, check, sM)) return false;
+        }
+        else
+        {
+            mac_plan(sh, pl);
+            if (!begin_event()) return false;
+            if (!mac(st, sh, pl, st.Hs, st.Y, h_first, check, sM)) return false;
+            if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
+            st.launches++;
+            st.hops += (uint64_t) T;
+            st.last_ksplit = (uint32_t) pl.ksplit;
+            st.last_ot = (uint32_t) pl.ot;
+        }
+    }
+    if (tail_gate && sj == 0 && mStages.size() > 1 && !mOneStream && st.P && !defer && !have_pre)
+    {
+        HCV_TRY(rec(st.mac_done[q], sM));
+        blk.gate = st.mac_done[q];
+    }
+
+    // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
+    HCV_TRY(wt(sI, mEvEmit[q]));             // emit(k-2) has cleared the timeline span reused now
+    if (head_here && !head_on_side)
+    {
+        HCV_TRY(launch_reduce_partials(head_y, head_ksplit, (long long) T * nout_act * st.M, (long long) T * nout_act * st.M, sI));
+        HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                         &st.big, sI));           // h_first - 1: emitted with NO latency (hop h at h*M)
+    }
+    if (st.P)
+    {
+        if (have_pre)
+        {
+            // inverse FFT of Y (partition 0) + Ypre (partitions >= 1): the two buffers are read as two "partials"
+            if (is_big_fft(st.log2n))
+            {
+                HCV_TRY(launch_reduce_partials(st.Y, 2, (long long) (st.Ypre - st.Y), y_elems, sI));
+                HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1,
+                                                 st.tw, &st.big, sI));
+            }
+            else
+                HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 2, (long long) (st.Ypre - st.Y), h_first, 1, (int) nout_act, st.timeline, st.tl_len,
+                                                 st.tl_len - 1, st.tw, &st.big, sI));
+        }
+        else
+        {
+            HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, sI));
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
+                                             &st.big, sI));
+        }
+    }
+    HCV_TRY(rec(st.done[q], sI));
+    HCV_TRY(wt(mStream, st.done[q]));
+
+    st.pre_hop = -1;
+    if (defer)
+    {
+        // plan the background accumulation for hop h+1: partitions 1 .. min(P-1, h+1) (those that have input), in up to
+        // kBgSlices launches that the following calls issue as the hop's samples arrive (advance_background)
+        st.bg_parts = (int) std::min<long long>(st.P - 1, h_first + 1);
+        st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
+        st.bg_launched = 0;
+        st.pre_hop = st.bg_parts > 0 ? h_first + 1 : -1;
+    }
+    return true;
+}
+
+// One block of at most max_block samples, everything device side.  Caller holds mMutex.
+//
+// Stream plan for block k (q = k & 1; every event and the FIR output buffer exist twice, indexed by block parity):
+//
+//   in stream:    wait readers(k-2) ─ scatter_input ─ record in[q]
+//   stage s:      wait in[q], emit[q] (= emit of block k-2) ─ rfft_frames → spectral_mac → reduce → rifft_overlap_add ─ record done_s[q]
+//   head stream:  wait in[q], emit[q]                       ─ fir_head → tdout[q]                                   ─ record td[q]
+//   main stream:  wait done_s[q] for all s, td[q] ─ emit(tdout[q]) ─ record emit[q]
+//
+// The stages only meet in emit(), so the latency-bound short stages and the FIR head hide under the HBM-bound tail;
+// and because block k+1's scatter and FFTs do not wait for block k's emit, consecutive asynchronous calls overlap.
+// Ring depths make that safe: the history ring holds three blocks + a frame (a block's readers must be done before
+// the block two later is scattered over them), each stage timeline holds two blocks + a hop (emit(k-2) must have
+// cleared what block k's hops are added into).
+bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B)
+{
+    const long long n0 = mN;
+    const long long hmask = mHistLen - 1;
+    const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+    const int q = (int) (mBlockCount & 1);
+
+    const bool td_any = mCfg.has_td && mTdLpad > 0;
+    const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
+    // Whole-hop mode: the block is made of whole, aligned hops of the last stage.  Every output sample of such a block only
+    // needs inputs that the last stage's own frames hold, so IR[0 : its hop) is served by ONE extra zero-latency partition
+    // of that stage (emitted in the hop's own slot, like the head-through-FFT of the first stage) and the head and the
+    // shorter stages — a dozen launches in latency-bound chains — are not run at all.  Entering the mode drops their
+    // pending (now duplicate) results; leaving it rebuilds their input spectra from the history ring and catches up on
+    // the one hop whose result is due in the new block (see the stage loop).
+    const size_t last = mStages.empty() ? 0 : mStages.size() - 1;
+    const bool whole_hops = mTailHead && !td_check && (n0 % mStages[last]->M) == 0 && (B % mStages[last]->M) == 0 &&
+                            !(mStages[last]->max_hv > n0 / mStages[last]->M);
+    const bool entering = whole_hops && !mTailHeadPrev, leaving = !whole_hops && mTailHeadPrev;
+    mTailHeadPrev = whole_hops;
+    // hop-aligned block of a larger matrix: the head goes through the first stage's FFTs (see init)
+    const bool head_fft = !whole_hops && td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
+    const bool td = td_any && !head_fft && !whole_hops;
+
+    // Serial blocks: everything on the main stream, in program order, with no events at all.  A dependency on a pending event
+    // of another stream costs the host ~10 us (a kernel launch 2.6, an event record 1.7 — tools/micro/api_cost.hip), so a
+    // small engine running one stage per block (whole-hop mode: 26 calls, five such dependencies, 111 us of host time for
+    // 60 us of kernels on the 8x1 workload) is bound by its own enqueue; big engines keep the overlap.  HCV_SERIAL = 0 / 1
+    // forces the choice for whole-hop blocks; single-stream engines are always serial.
+    static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
+    static const double serial_mb = std::getenv("HCV_SERIAL_MB") ? std::atof(std::getenv("HCV_SERIAL_MB")) : 256.0;
+    const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < serial_mb * 1048576.0;
+    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
+    Block blk;
+    blk.din = din; blk.dout = dout; blk.in_stride = in_stride; blk.out_stride = out_stride;
+    blk.nin_act = nin_act; blk.nout_act = nout_act; blk.rows_in = rows_in; blk.B = B;
+    blk.n0 = n0; blk.hmask = hmask; blk.q = q; blk.last = last;
+    blk.td_any = td_any; blk.td_check = td_check; blk.whole_hops = whole_hops; blk.entering = entering; blk.leaving = leaving;
+    blk.head_fft = head_fft; blk.td = td; blk.serial = serial;
+    blk.full_matrix = nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+    blk.main = mStream; blk.sIn = serial ? mStream : mInStream; blk.sTd = serial ? mStream : mTdStream;
+    blk.src.count = 0;
+    const hipStream_t sIn = blk.sIn, sTd = blk.sTd;
+    auto rec = [&](hipEvent_t e, hipStream_t s) { return blk.rec(e, s); };
+    auto wt = [&](hipStream_t s, hipEvent_t e) { return blk.wt(s, e); };
+    if (serial && !mPrevSerial)
+    {
+        // the previous block's emit waited for all of its work, so the main stream is already behind everything except
+        // background slices still in flight on a stage's own stream
+        for (Stage *st : mStages)
+            if (st->bg_pending) HCV_TRY(hipStreamWaitEvent(mStream, st->bg_done, 0));
+    }
+    else if (!serial && mPrevSerial)
+    {
+        // back to the streams: they start behind everything the serial blocks put on the main stream
+        HCV_TRY(hipEventRecord(mEvSerial, mStream));
+        HCV_TRY(hipStreamWaitEvent(mInStream, mEvSerial, 0));
+        HCV_TRY(hipStreamWaitEvent(mTdStream, mEvSerial, 0));
+        for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvSerial, 0));
+    }
+    mPrevSerial = serial;
+    if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
+    // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
+    if (mCtlDirty)
+    {
+        HCV_TRY(rec(mEvCtl, mStream));
+        HCV_TRY(wt(sIn, mEvCtl));
+        // (deferred slices are launched without waiting for the block's input: order them after the control work directly)
+        for (Stage *st : mStages) HCV_TRY(wt(st->stream, mEvCtl));
+        mCtlDirty = false;
+    }
+    // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
+    static const bool pipeline = !(std::getenv("HCV_PIPELINE") && std::atoi(std::getenv("HCV_PIPELINE")) == 0);
+    if (!pipeline) HCV_TRY(wt(sIn, mEvEmit[q ^ 1]));
+    // the block two back read the history this scatter may overwrite
+    for (Stage *st : mStages) HCV_TRY(wt(sIn, st->done[q]));
+    HCV_TRY(wt(sIn, mEvTd[q]));
+    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
+    HCV_TRY(rec(mEvInput[q], sIn));
+
+    if (td)
+    {
+        HCV_TRY(wt(sTd, mEvInput[q]));
+        HCV_TRY(wt(sTd, mEvEmit[q]));      // emit(k-2) has consumed tdout[q]
+        const bool check = td_check;
+        HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
+                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, sTd));
+        HCV_TRY(rec(mEvTd[q], sTd));
+    }
+
+    // Tail gate: when this block carries a hop of a long, bandwidth-bound tail stage, the shorter stages' MACs are held
+    // until the tail's spectral_mac has finished.  That kernel is one wave of workgroups balanced over every CU and
+    // streams through the caches; short-stage MACs whose spectra do not fit those caches, run beside it, are evicted by
+    // it, re-read from HBM and take slots from some of its workgroups — together they take longer than one after the
+    // other (64x64 with 10 s IRs: tail alone 2.29 ms at 6.9 TB/s + short stages 0.33 ms, against 2.97 ms overlapped).
+    // When the short stages fit the caches (16x16) or the tail is short (64x64 with 2 s IRs) the overlap wins and is
+    // kept.  HCV_TAIL_GATE = 0 / 1 forces the choice (2: hold the forward FFTs too).
+    static const int tail_gate_env = std::getenv("HCV_TAIL_GATE") ? std::atoi(std::getenv("HCV_TAIL_GATE")) : -1;
+    int tail_gate = whole_hops ? 0 : tail_gate_env;
+    if (tail_gate < 0)
+    {
+        double small_bytes = 0, small_traffic = 0, tail_bytes = 0;
+        for (size_t si = 0; si < mStages.size(); si++)
+        {
+            const Stage &sg = *mStages[si];
+            const double bytes = (double) sg.live_parts * sg.M * sizeof(float2);
+            const double hops = (double) ((n0 + B) / sg.M - n0 / sg.M);
+            if (si + 1 == mStages.size()) tail_bytes = bytes * std::max(1.0, hops / 8.0);
+            else
+            {
+                small_bytes += bytes;
+                small_traffic += bytes * std::max(1.0, hops / 4.0);       // hop tiles of 4 share one read of the spectra
+            }
+        }
+        // measured only to pay when the block carries exactly one tail hop (at two hops per block the hop-tiled tail already
+        // shares the chip better: ns64 at 16384-sample blocks 376 ungated vs 357 gated Msamples/s)
+        const bool one_tail_hop = !mStages.empty() && (n0 + B) / mStages.back()->M - n0 / mStages.back()->M == 1;
+        tail_gate = (one_tail_hop && small_bytes >= 64.0 * 1048576.0 && tail_bytes >= 12.0 * small_traffic) ? 1 : 0;
+    }
+    blk.tail_gate = tail_gate;
+
+
+    // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
+    for (size_t sj = 0; sj < mStages.size(); sj++)
+        if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj)) return false;
+
+    if (td || whole_hops) HCV_TRY(wt(mStream, mEvTd[q]));
+    HCV_TRY(wt(mStream, mEvInput[q]));           // a block with no live stage still orders after its scatter
+    HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
+    HCV_TRY(rec(mEvEmit[q], mStream));
+    mN += B;
+    mBlockCount++;
+    mLastNin = rows_in;
+    mLastNout = nout_act;
+    return true;
+}
+
+bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_act, uint32_t nout_act, uint64_t n, bool accumulate)
+{
+    HCV_TRY(hipSetDevice(mDevice));
+    nout_act = std::min(nout_act, mCfg.nout);
+    nin_act = std::min(nin_act, mCfg.nin);
+    if (!nout_act || !n) return true;
+    const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+
+    for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
+    {
+        const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
+        for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i] + pos, sizeof(float) * B);
+        {
+            std::lock_guard<std::mutex> g(mMutex);
+            if (!apply_pending_resets()) return false;
+            // the upload goes on the main stream and is handed to the block like control work: a serial block scatters on the
+            // main stream, a streamed one makes its input stream wait for it (enqueue_chunk, mCtlDirty)
+            if (rows_in)
+            {
+                HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
+                mCtlDirty = true;
+            }
+            if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
+            HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
+        }
+        HCV_TRY(hipStreamSynchronize(mStream));
+        for (uint32_t o = 0; o < nout_act; o++)
+        {
+            float *dst = outs[o] + pos;
+            const float *src = mPinOut + (size_t) o * B;
+            if (accumulate)
+                for (uint32_t j = 0; j < B; j++) dst[j] += src[j];
+            else
+                std::memcpy(dst, src, sizeof(float) * B);
+        }
+    }
+    if (mProfiling) collect_events();
+    return true;
+}
+
+bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
+                         bool sync)
+{
+    HCV_TRY(hipSetDevice(mDevice));
+    nout_act = std::min(nout_act, mCfg.nout);
+    nin_act = std::min(nin_act, mCfg.nin);
+    if (!nout_act || !n) return true;
+    {
+        std::lock_guard<std::mutex> g(mMutex);
+        if (!apply_pending_resets()) return false;
+        for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
+        {
+            const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
+            if (!enqueue_chunk(ins + pos, in_stride, outs + pos, out_stride, nin_act, nout_act, B)) return false;
+        }
+    }
+    if (sync) return synchronize();
+    return true;
+}
+
+} // namespace hcv

@@ -1,0 +1,140 @@
+// Private to the engine's translation units (hcv_engine.hip: set-up and control; hcv_engine_restart.hip: exact per-pair
+// restart; hcv_engine_block.hip: the per-block scheduler): the structures behind Engine's opaque members.
+#pragma once
+
+#include "hcv_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace hcv
+{
+
+#define HCV_TRY(expr)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return fail(#expr, e_);                                                                  \
+    } while (0)
+
+inline long long pow2ceil(long long v)
+{
+    long long p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+constexpr int kBgSlices = 16;
+constexpr int kTailHeadSplit = 8;
+
+// HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
+// per stage and its pending output is not withdrawn) — for A/B comparison only
+inline bool exact_restart()
+{
+    static const bool on = !(std::getenv("HCV_EXACT_RESTART") && std::atoi(std::getenv("HCV_EXACT_RESTART")) == 0);
+    return on;
+}
+
+
+struct Engine::Stage
+{
+    StageCfg cfg;
+    int log2n = 0;
+    uint32_t N = 0, M = 0;
+    uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
+    float2 *Hs = nullptr, *X = nullptr;
+    float2 *Y = nullptr;                // scratch of the current block = Yq[block parity]
+    float2 *Yq[2] = { nullptr, nullptr };   // split-K partials, double-buffered so MAC(k+1) can run while block k is inverted
+    size_t y_elems = 0;
+    // Deferred ("time-spread") mode, the GPU form of the reference's partition scheduler (PartitionedConvolve.cpp:321-348):
+    // partitions 1..P-1 of hop h+1 only need spectra up to hop h, so they are accumulated BETWEEN the boundaries of hop h
+    // and hop h+1, in up to kBgSlices short launches spread over the calls of that hop in step with the samples that
+    // have arrived (a single long launch would sit in a hardware queue that other streams share and stall them for
+    // milliseconds); the boundary of hop h+1 then only pays partition 0 + the inverse FFT.
+    float2 *Ypre = nullptr;             // [kBgSlices][nout][M]: one partial sum per slice; slot 0 receives their total
+    long long pre_hop = -1;             // hop index the slices accumulate for (-1 = no plan)
+    int bg_parts = 0;                   // partitions 1..bg_parts of that hop are to be accumulated
+    int bg_slices = 0, bg_launched = 0; // planned / already launched slices
+    hipEvent_t bg_done = nullptr;       // recorded after every background launch
+    bool bg_pending = false;
+    float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
+    long long tl_len = 0;
+    BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
+    hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream (the MAC stream)
+    hipEvent_t mac_done[2] = { nullptr, nullptr };     // the stage's spectral_mac of a block has finished (tail gate)
+    hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
+    long long *hv = nullptr;
+    long long max_hv = 0;
+    // exact per-pair restart: device table of the live ghost entries of this stage, grouped by output
+    int *gh_start = nullptr;            // [nout + 1]
+    GhostEntry *gh_ent = nullptr;       // [pairs]
+    std::vector<GhostEntry> gh_host;    // mirror, in table order
+    std::vector<size_t> gh_pair;        // pair of each entry
+    int gh_count = 0;
+    long long gh_min_hr = 0, gh_max_hr = 0;
+    std::vector<uint32_t> pact;
+    uint64_t live_parts = 0;            // sum of pact
+    const float2 *tw = nullptr;
+    // stats
+    uint64_t launches = 0, hops = 0;
+    double ms = 0.0;
+    uint32_t last_ksplit = 0, last_ot = 0;
+};
+
+struct Engine::GhostEvent
+{
+    long long t0 = 0;                   // sample the restart took effect at
+    int refs = 0;                       // pairs still pointing at this event
+    std::vector<int> slot;              // input row -> row of the spectra blocks (-1: not part of the restart)
+    std::vector<float2 *> spec;         // per stage: [rows][2][M], frame h at slot h & 1
+    std::vector<size_t> bytes;
+};
+
+struct Engine::EventPair
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    size_t stage = 0;
+    bool live = false;
+};
+
+// Everything one block's enqueue needs to know, decided once on the host (enqueue_chunk) and shared by the helpers below.
+struct Engine::Block
+{
+    const float *din = nullptr;
+    float *dout = nullptr;
+    int64_t in_stride = 0, out_stride = 0;
+    uint32_t nin_act = 0, nout_act = 0, rows_in = 0, B = 0;
+    long long n0 = 0, hmask = 0;
+    int q = 0;                          // block parity: every event and double buffer is indexed by it
+    size_t last = 0;                    // index of the last stage
+    bool td_any = false, td_check = false, whole_hops = false, entering = false, leaving = false, head_fft = false, td = false;
+    bool serial = false, full_matrix = false;
+    int tail_gate = 0;
+    hipEvent_t gate = nullptr;          // the tail's spectral_mac of this block has finished (tail gate)
+    hipStream_t main = nullptr, sIn = nullptr, sTd = nullptr;
+    EmitSources src;
+
+    // serial blocks run on the main stream alone, in program order: no event is recorded or waited for
+    hipError_t rec(hipEvent_t e, hipStream_t s) const { return serial ? hipSuccess : hipEventRecord(e, s); }
+    hipError_t wt(hipStream_t s, hipEvent_t e) const { return serial ? hipSuccess : hipStreamWaitEvent(s, e, 0); }
+    hipStream_t stage_stream(hipStream_t own) const { return serial ? main : own; }
+};
+
+// the block's constants under the names the code below uses
+#define HCV_BLOCK_LOCALS(b)                                                                                                                        \
+    const long long n0 = (b).n0, hmask = (b).hmask;                                                                                                \
+    const uint32_t nin_act = (b).nin_act, nout_act = (b).nout_act, rows_in = (b).rows_in, B = (b).B;                                                \
+    const int q = (b).q;                                                                                                                           \
+    const size_t last = (b).last;                                                                                                                  \
+    const bool whole_hops = (b).whole_hops, entering = (b).entering, leaving = (b).leaving, head_fft = (b).head_fft, serial = (b).serial,          \
+               full_matrix = (b).full_matrix;                                                                                                      \
+    const int tail_gate = (b).tail_gate;                                                                                                           \
+    const hipStream_t sTd = (b).sTd;                                                                                                               \
+    auto rec = [&](hipEvent_t e_, hipStream_t s_) { return (b).rec(e_, s_); };                                                                     \
+    auto wt = [&](hipStream_t s_, hipEvent_t e_) { return (b).wt(s_, e_); };                                                                       \
+    (void) n0; (void) hmask; (void) nin_act; (void) nout_act; (void) rows_in; (void) B; (void) q; (void) last; (void) whole_hops; (void) entering; \
+    (void) leaving; (void) head_fft; (void) serial; (void) full_matrix; (void) tail_gate; (void) sTd; (void) rec; (void) wt
+
+} // namespace hcv

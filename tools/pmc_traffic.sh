@@ -1,12 +1,13 @@
 #!/bin/bash
 # HBM traffic of the tail spectral_mac launch from PMC counters, collected in separate passes (no tracing domains
-# beyond --kernel-trace).  Usage on the GPU box: tools/pmc_traffic.sh <workload> ; writes gpurun_out/pmc_<workload>/
+# beyond --kernel-trace; the headline leg only — with the extended-ladder leg in the same process counter collection crashed or
+# hung on this ROCm stack, so it is switched off here and every pass runs under `timeout`).  Usage on the GPU box: tools/pmc_traffic.sh <workload> ; writes gpurun_out/pmc_<workload>/
 w=${1:-c5}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$w
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload $w --steps 4 --warmup 1 --batched-block 0 > $out/$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace -d $out/calib_$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py > $out/calib_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload $w --steps 4 --warmup 1 --batched-block 0 --extended-ratio 0 > $out/$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d $out/calib_$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py > $out/calib_$c.log 2>&1
 done
 ls -R $out | head -40

@@ -21,6 +21,10 @@ so per-GPU work is fixed: weak scaling.
 
 The CPU baseline leg (rank 0, N = 1 only) times the UNMODIFIED reference (oracle/_ref, when the prebuilt library
 travelled with the repo; else the C port) on a bounded sub-matrix of the same workload on one host core.
+
+`--sharding grid` exercises the other half of SURVEY 8e instead: (N/2) x 2 ranks, the two ranks of a row group convolve half of
+the inputs each and sum their partial outputs with ONE all-reduce per step (RCCL; BENCH_BACKEND=gloo lets two ranks share a GPU to
+check the path on a one-GPU box).  The default stays output-row sharding.
 """
 import argparse
 import json
@@ -175,6 +179,10 @@ def main():
     ap.add_argument("--tail-ratio", type=int, default=0, help="run the HEADLINE on the extended far-tail ladder (0 = reference partitioning)")
     ap.add_argument("--extended-ratio", type=int, default=8, help="also measure the extended far-tail ladder with this ratio (0 = skip)")
     ap.add_argument("--ir-file", default="", help="WAVE / AIFF / AIFC file with real impulse responses instead of the synthetic ones")
+    ap.add_argument("--sharding", default="rows", choices=["rows", "grid"],
+                    help="rows: every rank owns output rows and all inputs, no data-path collective (default).  grid: (N/2) x 2 ranks — the two "
+                         "ranks of a row group each convolve half of the inputs and sum their partial outputs with one RCCL all-reduce per step "
+                         "(SURVEY 8e: the reduce path; needs an even N >= 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores CPU leg")
     args = ap.parse_args()
@@ -193,16 +201,35 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the convolution engine has no CPU fallback")
+    local = local % torch.cuda.device_count()       # (several ranks may share a GPU when the reduce path is exercised with gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    grid = args.sharding == "grid"
+    if grid and (world < 2 or world % 2):
+        raise SystemExit("--sharding grid needs an even number of ranks (>= 2)")
 
     import hisstools_library_amd as H
 
     nin, nout, L, fs, layout = WORKLOADS[args.workload]
     B = args.block
+    # grid sharding: rank = row * 2 + col; a row group of two ranks owns `nout` output rows, each rank half of the inputs
+    nin_total, row, col, row_group = nin, rank, 0, None
+    if grid:
+        if nin % 2:
+            raise SystemExit("--sharding grid needs an even number of inputs")
+        row, col = divmod(rank, 2)
+        nin = nin_total // 2
+        for r in range(world // 2):                     # every rank creates every group
+            grp = dist.new_group(ranks=[2 * r, 2 * r + 1])
+            if r == row:
+                row_group = grp
     stages = stage_layout(L, layout)
 
     BB = max(args.batched_block, 0)
@@ -210,7 +237,9 @@ def main():
     decay = torch.pow(torch.tensor(10.0, device=dev), -3.0 * torch.arange(L, device=dev, dtype=torch.float32) / L)
     nring = max(8, -(-BB // B))
     g.manual_seed(777)
-    xs = torch.rand((nin, nring * B), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0     # same audio on every rank
+    xs = torch.rand((nin_total, nring * B), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0     # same audio on every rank
+    xs = xs[col * nin:(col + 1) * nin].contiguous()                                                    # (grid: this rank's inputs)
+    yb = torch.zeros((nout, B), device=dev, dtype=torch.float32) if grid else None                     # contiguous block for the all-reduce
     ys = torch.zeros((nout, nring * B), device=dev, dtype=torch.float32)
 
     file_irs = None
@@ -233,9 +262,9 @@ def main():
                 if file_irs is not None:
                     # real impulse responses (--ir-file): pair (i, o) takes channel (i * nout + o) mod channels, cut or
                     # zero-padded to the workload's IR length
-                    h = file_irs[(i * nout + rank * nout + o) % file_irs.shape[0]]
+                    h = file_irs[((col * nin + i) * nout + row * nout + o) % file_irs.shape[0]]
                 else:
-                    g.manual_seed(1000 * i + (rank * nout + o) + 1)
+                    g.manual_seed(1000 * (col * nin + i) + (row * nout + o) + 1)
                     h = (torch.rand(L, generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0) * decay
                     h = h / torch.linalg.vector_norm(h)
                 torch.cuda.synchronize()
@@ -247,7 +276,13 @@ def main():
 
         def step(k):
             off = 4 * (k % nring) * B
-            conv.process_dev(xs.data_ptr() + off, nring * B, ys.data_ptr() + off, nring * B, nin, nout, B)
+            if not grid:
+                conv.process_dev(xs.data_ptr() + off, nring * B, ys.data_ptr() + off, nring * B, nin, nout, B)
+                return
+            # reduce path: this rank's partial block, then ONE all-reduce over the row group (the only exchange step)
+            conv.process_dev(xs.data_ptr() + off, nring * B, yb.data_ptr(), B, nin, nout, B)
+            conv.synchronize()
+            dist.all_reduce(yb, op=dist.ReduceOp.SUM, group=row_group)
 
         # reach steady state first (every partition of every stage live, so the unpredicated kernel variant runs)
         for k in range(L // B + 2):
@@ -264,7 +299,13 @@ def main():
                 step(k)
             conv.synchronize()
             tp = time.perf_counter() - tp
-            if prev is not None and abs(tp - prev) <= 0.05 * prev:
+            settled = prev is not None and abs(tp - prev) <= 0.05 * prev
+            if grid:
+                # every step holds a collective: all ranks must leave the probe loop together
+                flag = torch.tensor([1.0 if settled else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                settled = bool(flag.item() > 0.5)
+            if settled:
                 break
             prev = tp
         conv.clear_stats()
@@ -294,7 +335,7 @@ def main():
         # offline-style calls: one process() of `batched_block` samples spans several tail hops, so spectral_mac re-uses
         # every IR spectrum across the hops of the call (hop tiling) instead of re-reading it per hop
         batched = None
-        if batched_block > B:
+        if batched_block > B and not grid:
             ksteps = max(2, min(steps, 8))
             for _ in range(2):
                 conv.process_dev(xs.data_ptr(), nring * B, ys.data_ptr(), nring * B, nin, nout, batched_block)
@@ -319,7 +360,7 @@ def main():
     # the same workload on the extended far-tail ladder (MI355X extension, not the reference's partitioning): reported
     # beside the headline, never as it
     extended = None
-    if args.extended_ratio and not args.tail_ratio:
+    if args.extended_ratio and not args.tail_ratio and not grid:
         try:
             e_el, e_stats, e_fin, _, _ = run(args.extended_ratio, args.steps, args.warmup, 0)
             extended = {"tail_ratio": args.extended_ratio, "stages": [(s_["fft_size"], s_["partitions"]) for s_ in e_stats],
@@ -329,7 +370,7 @@ def main():
             extended = {"error": str(e)}
 
     if rank == 0:
-        total_out = nout * world
+        total_out = nout * (world // 2 if grid else world)
         value = total_out * B * args.steps / elapsed / 1e6
         tail = stats[-1]
         Hh = tail["fft_size"] // 2
@@ -359,11 +400,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic" if not args.ir_file else "synthetic audio, impulse responses from " + os.path.basename(args.ir_file),
             "config": {
-                "workload": f"{args.workload}: Convolver {nin}x{nout} per GPU ({nin}x{total_out} over {world} GPU), IR {L} samples @ {fs} Hz, "
+                "workload": f"{args.workload}: Convolver {nin}x{nout} per GPU ({nin_total}x{total_out} over {world} GPU), IR {L} samples @ {fs} Hz, "
                             f"stages {stages}, process block {B} samples, audio + spectra resident in HBM",
-                "sharding": "output rows per rank, no data-path collective",
+                "sharding": ("output rows per rank, no data-path collective" if not grid else
+                             f"grid {world // 2} x 2: a row group's two ranks take half of the inputs each and sum their partial outputs with one "
+                             f"all-reduce per step ({os.environ.get('BENCH_BACKEND', 'nccl')})"),
                 "realtime_factor": round(B * args.steps / elapsed / fs, 3),
-                "pair_msamples_per_s": round(value * nin, 2),
+                "pair_msamples_per_s": round(value * nin_total, 2),
                 "ir_load_s": round(t_load, 2),
                 "finite_output": finite,
                 "batched": batched,

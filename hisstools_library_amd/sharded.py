@@ -81,9 +81,24 @@ class ShardedConvolver:
             return 0
         return self.engine.set(inChan - self.in_lo, outChan - self.out_lo, ir, resize)
 
-    def reset(self):
-        if self.engine is not None:
-            self.engine.reset()
+    def reset(self, inChan: Optional[int] = None, outChan: Optional[int] = None):
+        """reset() restarts every pair; reset(in, out) one pair while the others keep running (Convolver.cpp:79-97) — SPMD like
+        set(): every rank may call it, the owner acts."""
+        if inChan is None:
+            if self.engine is not None:
+                self.engine.reset()
+            return 0
+        if inChan >= self.numIns:
+            return 1
+        if outChan >= self.numOuts:
+            return 2
+        if not self.owns(inChan, outChan) or self.engine is None:
+            return 0
+        return self.engine.reset(inChan - self.in_lo, outChan - self.out_lo)
+
+    def clear(self, inChan: int, outChan: int, resize: bool = False):
+        """clear(in, out, resize) = set(in, out, nullptr, 0, resize) (Convolver.cpp:55-58)"""
+        return self.set(inChan, outChan, None, resize)
 
     # ---- streaming
     def process(self, ins: np.ndarray) -> np.ndarray:

@@ -24,8 +24,8 @@ class OracleEngine:
     def set(self, i, o, ir, resize):
         return self.c.set(i, o, ir, resize)
 
-    def reset(self):
-        self.c.reset()
+    def reset(self, *pair):
+        return self.c.reset(*pair)
 
     def process(self, ins, outs):
         self.c.process(ins, outs)
@@ -66,6 +66,20 @@ def main():
     assert err <= tol, (rank, err)
     allouts = sc.gather(got)
     assert np.abs(allouts - expect).max() / peak <= tol
+
+    # control calls while streaming: an IR swap, a restart and a clear of single pairs reach their owner and nobody else
+    new_ir = O.synth_ir(7, 7, L - 500)
+    script = {1024: lambda c: c.set(nin - 1, 0, new_ir, True), 2048: lambda c: c.reset(0, nout - 1), 3072: lambda c: c.clear(nin - 1, nout - 1, False)}
+    full.reset()
+    sc.reset()
+    assert sc.reset(nin, 0) == 1 and sc.reset(0, nout) == 2
+    for pos in range(0, S, B):
+        if pos in script:
+            assert script[pos](full) in (0, None) and script[pos](sc) == 0
+        expect[:, pos:pos + B] = full.run(xs[:, pos:pos + B], nout, B)
+        got[:, pos:pos + B] = sc.process(xs[:, pos:pos + B])
+    err2 = np.abs(got - expect[lo:hi]).max() / peak if hi > lo else 0.0
+    assert err2 <= tol, (rank, err2)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok ({layout}, err {err:.2e})")

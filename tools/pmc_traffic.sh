@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$w
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload $w --steps 4 --warmup 1 --batched-block 0 --extended-ratio 0 > $out/$c.log 2>&1
-  timeout 300 rocprofv3 --pmc $c --kernel-trace -d $out/calib_$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py > $out/calib_$c.log 2>&1
+  timeout ${PMC_TIMEOUT:-600} rocprofv3 --pmc $c --kernel-trace -d $out/$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload $w --steps 4 --warmup 1 --batched-block 0 --extended-ratio 0 > $out/$c.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $c --kernel-trace -d $out/calib_$c -o run --output-format csv -- python $GRAFT_REPO_ROOT/tools/pmc_calib.py > $out/calib_$c.log 2>&1
 done
 ls -R $out | head -40

@@ -47,6 +47,7 @@ WORKLOADS = {
     "c2":   (1,  1,  480000,  48000, (False, 4096, 0, 0, 0)),
     "ns64": (64, 64, 480000,  48000, (True, 256, 1024, 4096, 16384)),
     "m16":  (16, 16, 96000,   48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 2 s IRs (not a BASELINE config)
+    "m16l": (16, 16, 480000,  48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 10 s IRs (not a BASELINE config)
 }
 
 

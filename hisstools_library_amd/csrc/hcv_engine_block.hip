@@ -325,7 +325,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // 60 us of kernels on the 8x1 workload) is bound by its own enqueue; big engines keep the overlap.  HCV_SERIAL = 0 / 1
     // forces the choice for whole-hop blocks; single-stream engines are always serial.
     static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
-    static const double serial_mb = std::getenv("HCV_SERIAL_MB") ? std::atof(std::getenv("HCV_SERIAL_MB")) : 256.0;
+    static const double serial_mb = std::getenv("HCV_SERIAL_MB") ? std::atof(std::getenv("HCV_SERIAL_MB")) : 1024.0;
     const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < serial_mb * 1048576.0;
     const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
     Block blk;

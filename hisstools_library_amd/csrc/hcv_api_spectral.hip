@@ -9,6 +9,8 @@
 #include "hcv_fftx.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -107,27 +109,43 @@ namespace
 
     inline unsigned blocks_for(size_t n) { return (unsigned) ((n + 255) / 256); }
 
+    // Device scratch of these calls: grow-only buffers cached per device and handed out by position, so that a sequence of
+    // calls pays for allocation once (a dozen hipMalloc / hipFree pairs cost more than the transforms of a mid-sized call).
+    // One call at a time per process holds the pool.
+    struct ScratchPool
+    {
+        std::mutex mutex;
+        std::map<int, std::vector<std::pair<void *, size_t>>> slots;       // device -> (pointer, bytes) by position
+    };
+    ScratchPool gScratch;
+
     struct DeviceBuffers
     {
-        std::vector<void *> held;
+        std::unique_lock<std::mutex> lock;
+        std::vector<std::pair<void *, size_t>> *slots = nullptr;
+        size_t next = 0;
+        explicit DeviceBuffers(int dev) : lock(gScratch.mutex), slots(&gScratch.slots[dev]) {}
         template <typename T>
         T *get(size_t elems, bool &ok)
         {
-            void *p = nullptr;
             if (!ok) return nullptr;
-            if (hipMalloc(&p, std::max<size_t>(16, elems * sizeof(T))) != hipSuccess)
+            const size_t bytes = std::max<size_t>(16, elems * sizeof(T));
+            if (next >= slots->size()) slots->emplace_back(nullptr, 0);
+            std::pair<void *, size_t> &slot = (*slots)[next++];
+            if (slot.second < bytes)
             {
-                (void) hipGetLastError();
-                set_error("spectral_processor: device allocation failed");
-                ok = false;
-                return nullptr;
+                if (slot.first) (void) hipFree(slot.first);
+                slot = { nullptr, 0 };
+                if (hipMalloc(&slot.first, bytes) != hipSuccess)
+                {
+                    (void) hipGetLastError();
+                    set_error("spectral_processor: device allocation failed");
+                    ok = false;
+                    return nullptr;
+                }
+                slot.second = bytes;
             }
-            held.push_back(p);
-            return static_cast<T *>(p);
-        }
-        ~DeviceBuffers()
-        {
-            for (void *p : held) (void) hipFree(p);
+            return static_cast<T *>(slot.first);
         }
     };
 
@@ -274,7 +292,7 @@ namespace
         const bool single = in1.size == 1 && in2.size == 1;
         hipStream_t st = nullptr;
         bool ok = true;
-        DeviceBuffers mem;
+        DeviceBuffers mem(dev);
         T *d1 = mem.get<T>(in1.size, ok), *d2 = mem.get<T>(in2.size, ok), *folded = mem.get<T>(fft, ok);
         T *re1 = mem.get<T>(half, ok), *im1 = mem.get<T>(half, ok), *re2 = mem.get<T>(half, ok), *im2 = mem.get<T>(half, ok);
         T *t = mem.get<T>(fft, ok), *dout = mem.get<T>(result, ok);
@@ -325,7 +343,7 @@ namespace
         if (single) correlate = false;
         hipStream_t st = nullptr;
         bool ok = true;
-        DeviceBuffers mem;
+        DeviceBuffers mem(dev);
         const In<T> ins[4] = { r1, i1, r2, i2 };
         T *raw[4], *plane[4];
         for (int k = 0; k < 4; k++)

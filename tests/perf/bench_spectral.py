@@ -61,9 +61,36 @@ def main():
                 r["cpu_reference_ms_1core"] = round(1e3 * (time.perf_counter() - t0), 2)
         rows.append(r)
         print(json.dumps(r), flush=True)
+    # the remaining overloads (double real, complex float / double) through the host-pointer entry points: wall time of one call,
+    # PCIe both ways included, best of --reps, with the reference on one host core beside it
+    over = []
+    rng = np.random.default_rng(3)
+    for n1, n2 in ((16000, 16000), (262144, 262144), (1000000, 1000000)):
+        for kind in ("real f64", "complex f32", "complex f64"):
+            dt = np.float32 if kind.endswith("f32") else np.float64
+            ins = [rng.uniform(-1, 1, n).astype(dt) for n in ((n1, n2) if kind.startswith("real") else (n1, n1, n2, n2))]
+            call = (lambda: sp.convolve(*ins, EdgeMode.Linear)) if kind.startswith("real") else (lambda: sp.convolve_complex(*ins, EdgeMode.Linear))
+            call()
+            best = 1e30
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                y = call()
+                best = min(best, time.perf_counter() - t0)
+            r = {"overload": kind, "size1": n1, "size2": n2, "ms_host_call": round(1e3 * best, 3),
+                 "out_msamples_per_s": round((n1 + n2 - 1) / best / 1e6, 1)}
+            if args.cpu:
+                from oracle import oracle as O
+                if O.have_ref_spectral():
+                    ref = (lambda: O.spectral_convolve(*ins, 0, "ref")) if kind.startswith("real") else (lambda: O.spectral_convolve_complex(*ins, 0, "ref"))
+                    ref()
+                    t0 = time.perf_counter()
+                    ref()
+                    r["cpu_reference_ms_1core"] = round(1e3 * (time.perf_counter() - t0), 2)
+            over.append(r)
+            print(json.dumps(r), flush=True)
     if args.json:
         with open(args.json, "w") as fh:
-            json.dump({"rows": rows, "note": "fft_traffic_GBps = three transforms of fft_size, each read + written once (8 bytes per sample) / time"}, fh, indent=1)
+            json.dump({"rows": rows, "overloads_host_pointers": over, "note": "fft_traffic_GBps = three transforms of fft_size, each read + written once (8 bytes per sample) / time"}, fh, indent=1)
 
 
 if __name__ == "__main__":

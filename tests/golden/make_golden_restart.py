@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as O  # noqa: E402
-from restart_scenarios import SCENARIOS, build, drive  # noqa: E402
+from restart_scenarios import SCENARIOS, build, build_ntomono, drive, drive_ntomono  # noqa: E402
 
 
 def main():
@@ -23,6 +23,8 @@ def main():
     for name, sc in SCENARIOS.items():
         conv, xs, script = build(O, sc, backend="ref")
         S[name] = drive(conv, xs, sc["nout"], script, 1024)
+    conv, xs, script = build_ntomono(O, backend="ref")
+    S["ntomono_3"] = drive_ntomono(conv, xs, script, 1024)
     out = os.path.join(ROOT, "tests", "golden", "golden_restart_v1.npz")
     np.savez_compressed(out, **{k: np.asarray(v, np.float32) for k, v in S.items()})
     print("wrote", out, os.path.getsize(out), "bytes")

@@ -49,3 +49,36 @@ def drive(conv, xs, nout, script, block):
                 fn(conv)
         out.append(conv.run(np.ascontiguousarray(xs[:, a:b]), nout, block))
     return np.concatenate(out, axis=1)
+
+
+# NToMonoConvolve (one output, reset(inChan) / set(inChan, …) mid-stream): (position, op, inChan, ir seed, ir length)
+NTOMONO = dict(nin=3, latency=1, L=16000, S=60000, events=[(15001, "reset", 1, None, 0), (26000, "set", 2, 11, 9000), (40500, "set", 0, 12, 16000)])
+
+
+def build_ntomono(ns, **kw):
+    from oracle import oracle as O
+    sc = NTOMONO
+    conv = ns.NToMonoConvolve(sc["nin"], sc["L"], sc["latency"], **kw)
+    for i in range(sc["nin"]):
+        assert conv.set(i, O.synth_ir(i, 3, sc["L"]), True) == 0
+    xs = np.stack([O.synth_audio(120 + i, sc["S"]) for i in range(sc["nin"])])
+    script = []
+    for pos, op, i, seed, n in sc["events"]:
+        if op == "set":
+            h = O.synth_ir(seed, seed, n)
+            script.append((pos, lambda c, i=i, h=h: c.set(i, h, True)))
+        else:
+            script.append((pos, lambda c, i=i: c.reset(i)))
+    return conv, xs, script
+
+
+def drive_ntomono(conv, xs, script, block):
+    total = xs.shape[1]
+    cuts = sorted({0, total} | {pos for pos, _ in script})
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        for pos, fn in script:
+            if pos == a:
+                fn(conv)
+        out.append(conv.run(np.ascontiguousarray(xs[:, a:b]), block))
+    return np.concatenate(out)

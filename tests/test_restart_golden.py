@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from restart_scenarios import SCENARIOS, build, drive
+from restart_scenarios import SCENARIOS, build, build_ntomono, drive, drive_ntomono
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 2e-6          # of the stream's peak: rounding-level agreement between differently staggered FFT phases
@@ -55,3 +55,16 @@ def test_gpu_reproduces_the_reference_through_live_control_calls(gold, name, blo
     sc = SCENARIOS[name]
     conv, xs, script = build(H, sc)
     assert worst(drive(conv, xs, sc["nout"], script, block), gold[name]) < TOL_SUM
+
+
+def test_oracle_ntomono_live_control_calls(oracle, gold):
+    conv, xs, script = build_ntomono(oracle)
+    assert worst(drive_ntomono(conv, xs, script, 512), gold["ntomono_3"]) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", [256, [1000, 37, 4096]])
+def test_gpu_ntomono_live_control_calls(gold, block):
+    import hisstools_library_amd as H
+    conv, xs, script = build_ntomono(H)
+    assert worst(drive_ntomono(conv, xs, script, block), gold["ntomono_3"]) < TOL_SUM

@@ -8,6 +8,9 @@ SCENARIOS = {
     "zero_latency_2x2": dict(nin=2, nout=2, latency=0, L=30000, S=90000, parallel=False, events=[
         (20011, "set", 1, 0, 7, 30000), (33000, "reset", 0, 1, None, 0), (41003, "set", 0, 0, 8, 12000), (60000, "clear", 1, 1, None, 0),
         (70777, "set", 1, 1, 9, 25000)]),
+    # resize(in, out, length) silences the pair until its next set (MonoConvolve.cpp:101-110: mLength = 0)
+    "resize_then_set": dict(nin=2, nout=2, latency=0, L=20000, S=70000, parallel=False, events=[
+        (18001, "resize", 0, 1, None, 40000), (30000, "set", 0, 1, 10, 35000), (45005, "resize", 1, 0, None, 1000), (52000, "set", 1, 0, 11, 1000)]),
     "medium_latency_2to1": dict(nin=2, nout=1, latency=2, L=6000, S=60000, parallel=False, events=[
         (17000, "reset", 1, 0, None, 0), (30001, "set", 0, 0, 5, 6000)]),
     "parallel_3": dict(nin=3, nout=3, latency=0, L=20000, S=70000, parallel=True, events=[
@@ -34,6 +37,8 @@ def build(ns, sc, **kw):
             script.append((pos, lambda c, i=i, o=o, h=h: c.set(i, o, h, True)))
         elif op == "reset":
             script.append((pos, lambda c, i=i, o=o: c.reset(i, o)))
+        elif op == "resize":
+            script.append((pos, lambda c, i=i, o=o, n=n: c.resize(i, o, n)))
         else:
             script.append((pos, lambda c, i=i, o=o: c.clear(i, o, False)))
     return conv, xs, script

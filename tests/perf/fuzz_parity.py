@@ -116,13 +116,16 @@ def one_case(seed):
             pos = int(rng.integers(1, S))
             i = int(rng.integers(0, nin))
             o = i if kind == "parallel" else int(rng.integers(0, nout))
-            what = rng.choice(["set", "set", "set", "reset_pair", "clear_pair", "reset_all"])
+            what = rng.choice(["set", "set", "set", "reset_pair", "clear_pair", "reset_all", "resize_pair"])
             if what == "set":
                 L = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(1, 60000)), int(rng.integers(1, 60000))]))
                 h = O.synth_ir((seed + 3 * i + pos) % 60, o, L)
                 events.setdefault(pos, []).append(lambda c, i=i, o=o, h=h: c.set(i, o, h, True))
             elif what == "reset_pair":
                 events.setdefault(pos, []).append(lambda c, i=i, o=o: c.reset(i, o))
+            elif what == "resize_pair":
+                n = int(rng.integers(1, 80000))
+                events.setdefault(pos, []).append(lambda c, i=i, o=o, n=n: c.resize(i, o, n))
             elif what == "clear_pair":
                 events.setdefault(pos, []).append(lambda c, i=i, o=o: c.clear(i, o, False))
             else:

@@ -109,6 +109,7 @@ namespace hcv
         bool global_reset();
         bool fence_background(bool keep_plan = false);
         bool apply_pending_resets();
+        bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
         struct Block;
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
         bool enqueue_stage(Block &blk, size_t si, size_t sj);

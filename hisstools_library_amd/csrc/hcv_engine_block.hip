@@ -446,7 +446,7 @@ bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_a
         for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i] + pos, sizeof(float) * B);
         {
             std::lock_guard<std::mutex> g(mMutex);
-            if (!apply_pending_resets()) return false;
+            if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
             // the upload goes on the main stream and is handed to the block like control work: a serial block scatters on the
             // main stream, a streamed one makes its input stream wait for it (enqueue_chunk, mCtlDirty)
             if (rows_in)
@@ -481,7 +481,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
     if (!nout_act || !n) return true;
     {
         std::lock_guard<std::mutex> g(mMutex);
-        if (!apply_pending_resets()) return false;
+        if (!update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
         for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
         {
             const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);

@@ -282,6 +282,36 @@ bool Engine::retire_pair(size_t pair)
 }
 
 
+// The caller changed how many inputs / outputs it passes (Convolver.cpp:148-153, NToMonoConvolve.cpp:41 process only the
+// active channels).  A pair that drops out is muted at the sample — what it still had to deliver is retired — and a pair that
+// comes (back) in restarts from silence like any restarted pair; the rows of the history and of the timelines that were not
+// maintained while a channel was inactive are thereby never looked at (the ghost spectra are taken from the same ring contents
+// as the frames, so whatever sits there cancels exactly), and the timeline rows of a returning output are cleared.
+// (The reference freezes an inactive pair's private state instead and resumes it later as if no time had passed.)
+bool Engine::update_active_matrix(uint32_t rows_in, uint32_t nout_act)
+{
+    if (mN <= 0 || (rows_in == mLastNin && nout_act == mLastNout)) return true;
+    if (!fence_background(exact_restart())) return false;
+    for (uint32_t o = 0; o < mCfg.nout; o++)
+        for (uint32_t c = 0; c < mNinAlloc; c++)
+        {
+            const size_t p = (size_t) o * mNinAlloc + c;
+            const uint32_t row = mCfg.diag ? o : c;
+            const bool was = o < mLastNout && row < mLastNin, now = o < nout_act && row < rows_in;
+            if (!mLoaded[p] || was == now) continue;
+            if (was && !mPending[p] && !mRetired[p])
+            {
+                if (!retire_pair(p)) return false;
+                mRetired[p] = 1;
+            }
+            if (now) mPending[p] = 1;
+        }
+    for (uint32_t o = mLastNout; o < nout_act && o < mCfg.nout; o++)
+        for (Stage *st : mStages) HCV_TRY(hipMemsetAsync(st->timeline + (size_t) o * st->tl_len, 0, sizeof(float) * st->tl_len, mStream));
+    mCtlDirty = true;
+    return true;
+}
+
 bool Engine::apply_pending_resets()
 {
     bool any = false, all = true;

@@ -205,3 +205,42 @@ def test_ir_swap_on_the_extended_ladder(H, oracle, block):
     before[cut:] = 0
     truth = f(xs[0], h0) + before + f(x1_after, h1n)
     assert float(np.abs(y - truth).max()) / float(np.abs(truth).max()) < TOL_SUM
+
+
+def test_active_channel_counts_change_mid_stream(H, oracle):
+    """process(ins, outs, numIns, numOuts) with counts that change between calls (Convolver.cpp:148-153): a pair that drops
+    out is muted at the sample, a pair that comes back restarts from silence — never stale history or stale pending output.
+    (The reference freezes an inactive pair's private state and resumes it later; the engine's semantics are the restart.)
+    Checked against float64 ground truth built per activation interval."""
+    from scipy.signal import fftconvolve
+    nin, nout, L, B = 3, 3, 14_000, 1000
+    plan = [(3, 3)] * 20 + [(2, 2)] * 9 + [(3, 3)] * 14 + [(1, 3)] * 7 + [(3, 1)] * 6 + [(3, 3)] * 20      # (numIns, numOuts) per call
+    S = B * len(plan)
+    xs = np.stack([oracle.synth_audio(130 + i, S) for i in range(nin)])
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    c = loaded(H, nin, nout, 0, irs)
+    y = np.zeros((nout, S), np.float32)
+    for k, (ni, no) in enumerate(plan):
+        blk = np.full((nout, B), 7.0, np.float32)
+        c.process(np.ascontiguousarray(xs[:, k * B:(k + 1) * B]), blk, numIns=ni, numOuts=no)
+        y[:no, k * B:(k + 1) * B] = blk[:no]
+        assert np.all(blk[no:] == 7.0)                              # rows beyond numOuts are not written
+    truth = np.zeros((nout, S))
+    for (i, o), h in irs.items():
+        active = [i < ni and o < no for ni, no in plan]
+        k = 0
+        while k < len(plan):
+            if not active[k]:
+                k += 1
+                continue
+            k1 = k
+            while k1 < len(plan) and active[k1]:
+                k1 += 1
+            a, b = k * B, k1 * B
+            x = xs[i].astype(np.float64).copy()
+            x[:a] = 0
+            truth[o, a:b] += fftconvolve(x, h.astype(np.float64))[a:b]
+            k = k1
+    peak = np.abs(truth).max()
+    for o in range(nout):
+        assert np.abs(y[o] - truth[o]).max() / peak < TOL_SUM, (o, int(np.abs(y[o] - truth[o]).argmax()))

@@ -17,6 +17,11 @@
 //     timeline [nout][OR] float (per stage)    output timeline ring; the stage ADDS its hop results at their
 //                                              emission time, emit() sums the stages' rings and clears the block
 //     taps     [nout][nin_alloc][2048] float   time-domain head taps, zero padded
+//     ghost spectra, pooled                    per restart of single pairs and stage: [inputs restarted][2][M] float2 (hcv_ghost.hip)
+//
+// Source files: hcv_engine.hip (set-up, IR loading, capacity growth), hcv_engine_block.hip (the per-block scheduler:
+// enqueue_chunk -> enqueue_stage, streams, serial blocks, deferred slices), hcv_engine_restart.hip (exact per-pair restart:
+// ghost spectra, retiring, resets, active-matrix changes); private structures in hcv_engine_impl.h.
 #pragma once
 
 #include "hcv_kernels.h"

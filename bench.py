@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — throughput + HBM roofline of the partitioned-convolution hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|c4|c3|c2|ns64] [--block B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|c4|c3|c2|ns64] [--block B] [--scaling weak|strong]
 
 One "step" = one Convolver::process call of B samples (default 8192 = one hop of the 16384-point tail stage) over
 the whole channel matrix, audio and IR spectra resident in HBM.  Metric (BASELINE.json): output-channel
@@ -15,16 +15,26 @@ Workloads (BASELINE.json configs; default c5 = the config the metric's HBM claus
     c2    PartitionedConvolve-shaped 1x1, 10 s IR, one 4096-point stage (cache resident, launch bound)
     ns64  64x64, 10 s @ 48 kHz IRs (north-star target shape),  zero latency     15.7 GB of spectra
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own block of `nout` output rows
-of an (N*nout) x nin system and receives the same inputs — output-row sharding, no collective on the data path —
-so per-GPU work is fixed: weak scaling.
+Inputs are SURVEY.md §8(d)'s generator: raw mt19937 draws, u = (r >> 8) * 2^-24; IR(in, out): seed 1000*in + out + 1,
+h[k] = (2u - 1) * 10^(-3k/L) scaled to unit L2 norm; audio(ch): seed 777 + ch, x[n] = 2u - 1.  The draws are made on the
+host (numpy's MT19937 seeded like std::mt19937), the float arithmetic of the IRs in float64 on the GPU; the audio is
+bit-identical to the CPU leg's, the IRs to within one float32 ulp on a few samples in ten million (libm pow vs the GPU's).
+After the timed region the run checks itself: the engine is reset and streams the CPU leg's sub-matrix inputs (the other
+inputs silent) through the same engine, same spectra, same 8192-sample steps, and the output rows the CPU leg computed
+with the unmodified reference are compared sample by sample (`config.self_check.max_rel_err`).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU):
+    --scaling weak   (default) every rank owns its own block of `nout` output rows of an (N*nout) x nin system and receives
+                     the same inputs — output-row sharding, no collective on the data path, per-GPU work fixed.
+    --scaling strong the workload's matrix is FIXED (c4 = 64x64 as BASELINE config 4 states it) and split over the ranks:
+                     output rows first (per GPU nin x nout/N, no collective); when there are fewer output rows than ranks
+                     (c3: 8 -> 1) the inputs are split as well and the partial output blocks of a row group are summed
+                     with one all-reduce per step (RCCL; the only exchange step the path has).
+`--sharding grid` forces the input split on weak scaling too ((N/2) x 2 ranks).  BENCH_BACKEND=gloo lets several ranks
+share one GPU to check the paths on a one-GPU box.
 
 The CPU baseline leg (rank 0, N = 1 only) times the UNMODIFIED reference (oracle/_ref, when the prebuilt library
 travelled with the repo; else the C port) on a bounded sub-matrix of the same workload on one host core.
-
-`--sharding grid` exercises the other half of SURVEY 8e instead: (N/2) x 2 ranks, the two ranks of a row group convolve half of
-the inputs each and sum their partial outputs with ONE all-reduce per step (RCCL; BENCH_BACKEND=gloo lets two ranks share a GPU to
-check the path on a one-GPU box).  The default stays output-row sharding.
 """
 import argparse
 import json
@@ -73,9 +83,78 @@ def algorithmic_bytes_per_hop(H, P, nin, nout):
     return 8 * H * P * nin * nout + 8 * H * P * nin + 8 * H * nin + 4 * H * (nin + nout)
 
 
+# ------------------------------------------------------------------------------------------- SURVEY §8(d) synthetic inputs
+
+def mt_raw(seed, n):
+    """n raw 32-bit draws of std::mt19937(seed) (numpy's MT19937 under the legacy init_genrand seeding), as uint32."""
+    import numpy as np
+    st = np.random.RandomState(seed).get_state()
+    bg = np.random.MT19937()
+    bg.state = {"bit_generator": "MT19937", "state": {"key": st[1], "pos": st[2]}}
+    return bg.random_raw(n).astype(np.uint32)
+
+
+def synth_audio(ch, n):
+    """audio(ch): seed 777 + ch, x[n] = 2u - 1 — float32, bit-identical to the oracle's generator"""
+    import numpy as np
+    r = mt_raw(777 + ch, n)
+    return (2.0 * ((r >> 8).astype(np.float64) * (1.0 / 16777216.0)) - 1.0).astype(np.float32)
+
+
+class IrSynth:
+    """IR(in, out): host threads draw the mt19937 words ahead of their use, the GPU finishes them in float64
+    (2u - 1, times the 60 dB decay, unit L2 norm) and rounds once to float32."""
+
+    def __init__(self, L, dev, pairs, workers=None):
+        import concurrent.futures as cf
+        import torch
+        self.torch, self.L, self.dev = torch, L, dev
+        self.decay = torch.pow(torch.tensor(10.0, device=dev, dtype=torch.float64), -3.0 * torch.arange(L, device=dev, dtype=torch.float64) / L)
+        self.pairs = list(pairs)                                    # (in, out) in the order they will be asked for
+        workers = workers or max(1, min(32, (os.cpu_count() or 2) - 1))
+        self.pool = cf.ThreadPoolExecutor(max_workers=workers)
+        self.ahead = max(2, min(2 * workers, (1 << 30) // max(1, 4 * L)))       # bounded look-ahead: at most ~1 GiB of words
+        self.futures = {}
+        self.next_submit = 0
+        self._fill()
+
+    def _fill(self):
+        while self.next_submit < len(self.pairs) and len(self.futures) < self.ahead:
+            i, o = self.pairs[self.next_submit]
+            self.futures[(i, o)] = self.pool.submit(mt_raw, 1000 * i + o + 1, self.L)
+            self.next_submit += 1
+
+    def get(self, i, o):
+        torch = self.torch
+        fut = self.futures.pop((i, o), None)
+        words = fut.result() if fut is not None else mt_raw(1000 * i + o + 1, self.L)
+        self._fill()
+        r = torch.from_numpy(words.view("int32")).to(self.dev).to(torch.int64) & 0xFFFFFFFF
+        t = (2.0 * ((r >> 8).to(torch.float64) * (1.0 / 16777216.0)) - 1.0) * self.decay
+        return (t * torch.rsqrt(torch.sum(t * t))).to(torch.float32)
+
+    def close(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)
+
+
+# ------------------------------------------------------------------------------------------- CPU legs (the only users of oracle/)
+
+def cpu_sub_matrix(workload):
+    """The bounded sub-matrix of a workload the one-core CPU leg (and therefore the self-check) runs on."""
+    nin, nout, L, fs, layout = WORKLOADS[workload]
+    tail, p_tail = stage_layout(L, layout)[-1]
+    max_pairs = max(1, min(32, 3000 // max(1, p_tail)))
+    sub_in = min(nin, 8)
+    while sub_in > 1 and sub_in > max_pairs:
+        sub_in //= 2
+    sub_out = max(1, min(nout, max_pairs // sub_in))
+    return sub_in, sub_out
+
+
 def cpu_baseline(workload, hops=64):
     """Reference CPU path on one host core, on a bounded sub-matrix of the same workload (steady state: the
-    stream is first run for as many hops as the tail has partitions so every partition is live, then timed)."""
+    stream is first run for as many hops as the tail has partitions so every partition is live, then timed).
+    `_outs` (popped by the caller before printing) is what it computed: [sub_out][warm + S] — the self-check's reference."""
     import numpy as np
     from oracle import oracle as O
 
@@ -83,11 +162,7 @@ def cpu_baseline(workload, hops=64):
     kind = "reference" if O.have_ref() else "port"
     backend = "ref" if kind == "reference" else "port"
     tail, p_tail = stage_layout(L, layout)[-1]
-    max_pairs = max(1, min(32, 3000 // max(1, p_tail)))
-    sub_in = min(nin, 8)
-    while sub_in > 1 and sub_in > max_pairs:
-        sub_in //= 2
-    sub_out = max(1, min(nout, max_pairs // sub_in))
+    sub_in, sub_out = cpu_sub_matrix(workload)
     hop = tail // 2
     warm, S = p_tail * hop, hops * hop
     block = 512
@@ -99,18 +174,20 @@ def cpu_baseline(workload, hops=64):
         p.setResetOffset(0)
         p.set(O.synth_ir(0, 0, L))
         t_set = time.perf_counter() - t_set
-        p.run(xs[0, :warm], block)
+        y0 = p.run(xs[0, :warm], block)
         t0 = time.perf_counter()
-        p.run(xs[0, warm:], block)
+        y1 = p.run(xs[0, warm:], block)
         secs = time.perf_counter() - t0
+        outs = np.concatenate([y0, y1])[None, :]
     else:
         c = O.Convolver(sub_in, sub_out, 0, backend=backend)
         for o in range(sub_out):
             for i in range(sub_in):
                 c.set(i, o, O.synth_ir(i, o, L), True)
         t_set = time.perf_counter() - t_set
-        c.stream_timed(np.ascontiguousarray(xs[:, :warm]), sub_out, block)
-        _, secs = c.stream_timed(np.ascontiguousarray(xs[:, warm:]), sub_out, block)
+        y0, _ = c.stream_timed(np.ascontiguousarray(xs[:, :warm]), sub_out, block)
+        y1, secs = c.stream_timed(np.ascontiguousarray(xs[:, warm:]), sub_out, block)
+        outs = np.concatenate([y0, y1], axis=1)
     pair_rate = sub_in * sub_out * S / secs                       # pair-samples / s on one core
     value = pair_rate / nin / 1e6                                 # == output-channel Msamples/s for the full matrix
     return {
@@ -120,6 +197,7 @@ def cpu_baseline(workload, hops=64):
                   f"output rate one core would sustain; IR load took {t_set:.1f} s",
         "pair_msamples_per_s": round(pair_rate / 1e6, 4),
         "seconds": round(secs, 3),
+        "_outs": outs, "_sub": (sub_in, sub_out, warm + S),
     }
 
 
@@ -169,6 +247,37 @@ def cpu_baseline_all_cores(workload, max_threads=64, hops=16):
     }
 
 
+# ------------------------------------------------------------------------------------------- sharding plan
+
+def split_range(n, parts, index):
+    """Contiguous balanced split of range(n) into `parts`; [lo, hi) of block `index`."""
+    base, rem = divmod(n, parts)
+    lo = index * base + min(index, rem)
+    return lo, lo + base + (1 if index < rem else 0)
+
+
+def shard_plan(nin, nout, world, rank, scaling, sharding):
+    """Which block of the (global) matrix this rank convolves.  Returns a dict: the global matrix size, this rank's
+    [in_lo, in_hi) x [out_lo, out_hi), the grid (row groups x column groups) and its position in it."""
+    if scaling == "strong":
+        go = min(world, nout)
+        while world % go:
+            go -= 1
+        gi = world // go
+        if gi > nin:
+            raise SystemExit(f"cannot split a {nin}x{nout} matrix over {world} ranks")
+        row, col = divmod(rank, gi)
+        o_lo, o_hi = split_range(nout, go, row)
+        i_lo, i_hi = split_range(nin, gi, col)
+        return {"nin_total": nin, "nout_total": nout, "go": go, "gi": gi, "row": row, "col": col, "in": (i_lo, i_hi), "out": (o_lo, o_hi)}
+    # weak: every row group brings its own `nout` rows
+    gi = 2 if sharding == "grid" else 1
+    go = world // gi
+    row, col = divmod(rank, gi)
+    i_lo, i_hi = split_range(nin, gi, col)
+    return {"nin_total": nin, "nout_total": nout * go, "go": go, "gi": gi, "row": row, "col": col, "in": (i_lo, i_hi), "out": (row * nout, (row + 1) * nout)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,12 +289,18 @@ def main():
     ap.add_argument("--tail-ratio", type=int, default=0, help="run the HEADLINE on the extended far-tail ladder (0 = reference partitioning)")
     ap.add_argument("--extended-ratio", type=int, default=8, help="also measure the extended far-tail ladder with this ratio (0 = skip)")
     ap.add_argument("--ir-file", default="", help="WAVE / AIFF / AIFC file with real impulse responses instead of the synthetic ones")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank brings its own nout output rows (per-GPU work fixed).  strong: the workload's matrix is fixed and split "
+                         "over the ranks — output rows first, inputs too when there are fewer rows than ranks (then one all-reduce per step)")
     ap.add_argument("--sharding", default="rows", choices=["rows", "grid"],
-                    help="rows: every rank owns output rows and all inputs, no data-path collective (default).  grid: (N/2) x 2 ranks — the two "
-                         "ranks of a row group each convolve half of the inputs and sum their partial outputs with one RCCL all-reduce per step "
-                         "(SURVEY 8e: the reduce path; needs an even N >= 2)")
+                    help="weak scaling only.  rows: every rank owns output rows and all inputs, no data-path collective (default).  grid: (N/2) x 2 "
+                         "ranks — the two ranks of a row group each convolve half of the inputs and sum their partial outputs with one RCCL "
+                         "all-reduce per step (SURVEY 8e: the reduce path; needs an even N >= 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-all-cores", action="store_true", help="skip the all-host-cores CPU leg")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the comparison with the CPU leg's output after the timed region")
+    ap.add_argument("--realtime-block", type=int, default=128,
+                    help="also measure paced real-time calls of this many samples through the host-pointer and device-pointer entry points (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,6 +310,7 @@ def main():
                "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -205,42 +321,37 @@ def main():
     local = local % torch.cuda.device_count()       # (several ranks may share a GPU when the reduce path is exercised with gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    grid = args.sharding == "grid"
-    if grid and (world < 2 or world % 2):
-        raise SystemExit("--sharding grid needs an even number of ranks (>= 2)")
+    if args.sharding == "grid" and (world < 2 or world % 2 or args.scaling != "weak"):
+        raise SystemExit("--sharding grid needs weak scaling and an even number of ranks (>= 2)")
 
     import hisstools_library_amd as H
 
-    nin, nout, L, fs, layout = WORKLOADS[args.workload]
+    nin_w, nout_w, L, fs, layout = WORKLOADS[args.workload]
     B = args.block
-    # grid sharding: rank = row * 2 + col; a row group of two ranks owns `nout` output rows, each rank half of the inputs
-    nin_total, row, col, row_group = nin, rank, 0, None
-    if grid:
-        if nin % 2:
-            raise SystemExit("--sharding grid needs an even number of inputs")
-        row, col = divmod(rank, 2)
-        nin = nin_total // 2
-        for r in range(world // 2):                     # every rank creates every group
-            grp = dist.new_group(ranks=[2 * r, 2 * r + 1])
-            if r == row:
+    plan = shard_plan(nin_w, nout_w, world, rank, args.scaling, args.sharding)
+    (in_lo, in_hi), (out_lo, out_hi) = plan["in"], plan["out"]
+    nin, nout = in_hi - in_lo, out_hi - out_lo                     # this rank's block
+    nin_total, nout_total = plan["nin_total"], plan["nout_total"]
+    reduce_path = plan["gi"] > 1
+    row_group = None
+    if reduce_path:
+        for r in range(plan["go"]):                                # every rank creates every group
+            grp = dist.new_group(ranks=[r * plan["gi"] + c for c in range(plan["gi"])])
+            if r == plan["row"]:
                 row_group = grp
     stages = stage_layout(L, layout)
 
     BB = max(args.batched_block, 0)
-    g = torch.Generator(device=dev)
-    decay = torch.pow(torch.tensor(10.0, device=dev), -3.0 * torch.arange(L, device=dev, dtype=torch.float32) / L)
     nring = max(8, -(-BB // B))
-    g.manual_seed(777)
-    xs = torch.rand((nin_total, nring * B), generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0     # same audio on every rank
-    xs = xs[col * nin:(col + 1) * nin].contiguous()                                                    # (grid: this rank's inputs)
-    yb = torch.zeros((nout, B), device=dev, dtype=torch.float32) if grid else None                     # contiguous block for the all-reduce
+    xs = torch.from_numpy(np.stack([synth_audio(i, nring * B) for i in range(in_lo, in_hi)])).to(dev)   # (every rank: the same audio)
+    yb = torch.zeros((nout, B), device=dev, dtype=torch.float32) if reduce_path else None           # contiguous block for the all-reduce
     ys = torch.zeros((nout, nring * B), device=dev, dtype=torch.float32)
 
     file_irs = None
@@ -252,32 +363,33 @@ def main():
         buf[:, :take] = torch.from_numpy(data[:, :take]).to(dev)
         file_irs = buf
 
-    def run(tail_ratio, steps, warmup, batched_block):
-        """Build an engine (reference partitioning, or the extended far-tail ladder), load the synthetic IRs straight
-        into HBM (decaying noise, unit L2 norm), reach steady state, then time `steps` process calls of B samples."""
+    def run(tail_ratio, steps, warmup, batched_block, keep=False):
+        """Build an engine (reference partitioning, or the extended far-tail ladder), load the synthetic IRs (decaying
+        noise, unit L2 norm) into HBM, reach steady state, then time `steps` process calls of B samples."""
         conv = H.Convolver(nin, nout, 0, device=local, maxBlock=max(B, batched_block), tailRatio=tail_ratio,
                            custom=(L, layout[0], layout[1], layout[2], layout[3], layout[4]))
         t_load = time.perf_counter()
+        synth = None if file_irs is not None else IrSynth(L, dev, [(in_lo + i, out_lo + o) for o in range(nout) for i in range(nin)])
         for o in range(nout):
             for i in range(nin):
                 if file_irs is not None:
                     # real impulse responses (--ir-file): pair (i, o) takes channel (i * nout + o) mod channels, cut or
                     # zero-padded to the workload's IR length
-                    h = file_irs[((col * nin + i) * nout + row * nout + o) % file_irs.shape[0]]
+                    h = file_irs[((in_lo + i) * nout_total + out_lo + o) % file_irs.shape[0]]
                 else:
-                    g.manual_seed(1000 * (col * nin + i) + (row * nout + o) + 1)
-                    h = (torch.rand(L, generator=g, device=dev, dtype=torch.float32) * 2.0 - 1.0) * decay
-                    h = h / torch.linalg.vector_norm(h)
+                    h = synth.get(in_lo + i, out_lo + o)
                 torch.cuda.synchronize()
                 rc = conv.set_dev(i, o, h.data_ptr(), L, True)
                 if rc != 0:
                     raise SystemExit(f"set_dev failed with ConvolveError {rc}")
+        if synth is not None:
+            synth.close()
         t_load = time.perf_counter() - t_load
         torch.cuda.synchronize()
 
         def step(k):
             off = 4 * (k % nring) * B
-            if not grid:
+            if not reduce_path:
                 conv.process_dev(xs.data_ptr() + off, nring * B, ys.data_ptr() + off, nring * B, nin, nout, B)
                 return
             # reduce path: this rank's partial block, then ONE all-reduce over the row group (the only exchange step)
@@ -301,8 +413,8 @@ def main():
             conv.synchronize()
             tp = time.perf_counter() - tp
             settled = prev is not None and abs(tp - prev) <= 0.05 * prev
-            if grid:
-                # every step holds a collective: all ranks must leave the probe loop together
+            if world > 1:
+                # (the reduce path holds a collective per step: all ranks must leave the probe loop together)
                 flag = torch.tensor([1.0 if settled else 0.0], device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 settled = bool(flag.item() > 0.5)
@@ -336,11 +448,13 @@ def main():
         # offline-style calls: one process() of `batched_block` samples spans several tail hops, so spectral_mac re-uses
         # every IR spectrum across the hops of the call (hop tiling) instead of re-reading it per hop
         batched = None
-        if batched_block > B and not grid:
+        if batched_block > B and not reduce_path:
             ksteps = max(2, min(steps, 8))
             for _ in range(2):
                 conv.process_dev(xs.data_ptr(), nring * B, ys.data_ptr(), nring * B, nin, nout, batched_block)
             conv.synchronize()
+            conv.clear_stats()
+            conv.set_profiling(True)
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -352,27 +466,88 @@ def main():
             tb = torch.tensor([time.perf_counter() - tb], device=dev, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-            batched = {"block": batched_block, "steps": ksteps, "msamples_per_s": round(nout * world * batched_block * ksteps / float(tb.item()) / 1e6, 2)}
-        del conv
-        return float(tmax.item()), stats, finite, batched, t_load
+            bstats = conv.stage_stats()
+            conv.set_profiling(False)
+            batched = {"block": batched_block, "steps": ksteps,
+                       "msamples_per_s": round(nout_total * batched_block * ksteps / float(tb.item()) / 1e6, 2), "_stats": bstats}
+        if not keep:
+            del conv
+            conv = None
+        return float(tmax.item()), stats, finite, batched, t_load, conv
 
-    elapsed, stats, finite, batched, t_load = run(args.tail_ratio, args.steps, args.warmup, BB)
+    elapsed, stats, finite, batched, t_load, conv = run(args.tail_ratio, args.steps, args.warmup, BB, keep=True)
+
+    # ---- CPU legs (rank 0, one GPU): the unmodified reference on the box's host cores; the one-core leg's output is the
+    # reference of the self-check below
+    cpu, cpu_all = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.workload)
+        except Exception as e:      # the baseline must never take the GPU number down with it
+            cpu = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+
+    # ---- self-check: the same engine, reset, streams the CPU leg's inputs (the other inputs silent) in the same B-sample
+    # steps as the timed region — through the ramp-up (partition bounds checked) into the steady state (the timed kernel
+    # instantiation) — and the CPU leg's output rows are compared sample by sample
+    self_check = None
+    if cpu is not None and cpu.get("_outs") is not None and not args.no_self_check and not args.tail_ratio:
+        try:
+            sub_in, sub_out, S_chk = cpu["_sub"]
+            ref = cpu["_outs"]
+            S_run = -(-S_chk // B) * B
+            xc = torch.zeros((nin, S_run), device=dev, dtype=torch.float32)
+            for i in range(sub_in):
+                xc[i, :S_chk] = torch.from_numpy(synth_audio(i, S_chk)).to(dev)
+            yc = torch.zeros((nout, S_run), device=dev, dtype=torch.float32)
+            conv.reset()
+            conv.clear_stats()
+            for pos in range(0, S_run, B):
+                conv.process_dev(xc.data_ptr() + 4 * pos, S_run, yc.data_ptr() + 4 * pos, S_run, nin, nout, B)
+            conv.synchronize()
+            got = yc[:sub_out, :S_chk].cpu().numpy().astype(np.float64)
+            st_chk = conv.stage_stats()[-1]
+            errs = [float(np.abs(got[o] - ref[o]).max() / np.abs(ref[o]).max()) for o in range(sub_out)]
+            tail_span = slice(S_chk - 64 * (stages[-1][0] // 2), S_chk)       # the span the CPU leg timed: every partition live
+            err_tail = max(float(np.abs(got[o][tail_span] - ref[o][tail_span]).max() / np.abs(ref[o]).max()) for o in range(sub_out))
+            self_check = {"max_rel_err": float(f"{max(errs):.3e}"), "max_rel_err_steady_span": float(f"{err_tail:.3e}"),
+                          "against": f"{cpu['kind']} CPU leg: output rows 0..{sub_out - 1} from inputs 0..{sub_in - 1} (the other inputs silent), "
+                                     f"{S_chk} samples in {B}-sample steps after a reset, on the timed engine and spectra",
+                          "tolerance": 1e-5, "ok": bool(max(errs) <= 1e-5),
+                          "mac_launches": int(st_chk["mac_launches"]), "mac_steady_launches": int(st_chk["mac_steady_launches"])}
+            del xc, yc
+        except Exception as e:
+            self_check = {"max_rel_err": None, "error": str(e)}
+
+    # ---- paced real-time calls (what a plug-in host does): `realtime-block` samples per call at the workload's sample rate,
+    # through the host-pointer entry point (hcv_convolver_process_f32: what the C++ drop-in calls) and the device-pointer one
+    realtime = None
+    if args.realtime_block and world == 1 and not args.tail_ratio:
+        try:
+            realtime = realtime_leg(conv, np, torch, dev, nin, nout, fs, args.realtime_block, stages)
+        except Exception as e:
+            realtime = {"error": str(e)}
+    del conv
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_all_cores:
+        try:
+            cpu_all = cpu_baseline_all_cores(args.workload)
+        except Exception as e:
+            cpu_all = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
 
     # the same workload on the extended far-tail ladder (MI355X extension, not the reference's partitioning): reported
     # beside the headline, never as it
     extended = None
-    if args.extended_ratio and not args.tail_ratio and not grid:
+    if args.extended_ratio and not args.tail_ratio and not reduce_path:
         try:
-            e_el, e_stats, e_fin, _, _ = run(args.extended_ratio, args.steps, args.warmup, 0)
+            e_el, e_stats, e_fin, _, _, _ = run(args.extended_ratio, args.steps, args.warmup, 0)
             extended = {"tail_ratio": args.extended_ratio, "stages": [(s_["fft_size"], s_["partitions"]) for s_ in e_stats],
-                        "msamples_per_s": round(nout * world * B * args.steps / e_el / 1e6, 2), "ms_per_step": round(1e3 * e_el / args.steps, 4),
+                        "msamples_per_s": round(nout_total * B * args.steps / e_el / 1e6, 2), "ms_per_step": round(1e3 * e_el / args.steps, 4),
                         "finite_output": e_fin}
         except Exception as e:      # never let the side measurement take the headline down
             extended = {"error": str(e)}
 
     if rank == 0:
-        total_out = nout * (world // 2 if grid else world)
-        value = total_out * B * args.steps / elapsed / 1e6
+        value = nout_total * B * args.steps / elapsed / 1e6
         tail = stats[-1]
         Hh = tail["fft_size"] // 2
         launches = max(1, tail["mac_launches"])
@@ -380,13 +555,43 @@ def main():
         alg_bytes = algorithmic_bytes_per_hop(Hh, tail["partitions"], nin, nout) * hops_per_launch
         avg_ms = tail["mac_ms"] / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # a working set that fits the 256 MiB Infinity Cache is not an HBM test (SURVEY §8d on c2): the step is bound by its
+        # launches, and the "achieved" rate is cache bandwidth
+        live_bytes = 8 * Hh * tail["partitions"] * nin * nout
+        bound = "hbm" if live_bytes > (256 << 20) else "launch"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        roofline_batched = None
+        if batched is not None:
+            bst = batched.pop("_stats")[-1]
+            bl = max(1, bst["mac_launches"])
+            bh = bst["mac_hops"] / bl
+            ot = max(1, bst["out_tile"])
+            # one launch covers `bh` hops: H is read once per hop tile (ceil(bh / hop_tile) times), X once per output tile
+            tiles = -(-int(round(bh)) // max(1, bst["hop_tile"]))
+            b_bytes = (8 * Hh * bst["partitions"] * nin * nout * tiles + 8 * Hh * (bst["partitions"] + bh) * nin * (-(-nout // ot))
+                       + 8 * Hh * nout * bh * max(1, bst["ksplit"]))
+            b_flops = 8.0 * Hh * bst["partitions"] * nin * nout * bh
+            b_ms = bst["mac_ms"] / bl
+            roofline_batched = {
+                "kernel": f"spectral_mac (tail stage, hop tile {bst['hop_tile']}, out tile {ot}, ksplit {bst['ksplit']}), {batched['block']}-sample calls",
+                "bytes_per_launch": int(b_bytes), "flops_per_launch": int(b_flops), "avg_launch_ms": round(b_ms, 5),
+                "hbm_gbs": round(b_bytes / (b_ms * 1e-3) / 1e9, 1) if b_ms > 0 else None,
+                "hbm_frac": round(b_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b_ms > 0 else None,
+                "tflops": round(b_flops / (b_ms * 1e-3) / 1e12, 2) if b_ms > 0 else None,
+                "f32_valu_frac": round(b_flops / (b_ms * 1e-3) / 1e12 / 157.3, 4) if b_ms > 0 else None,
+            }
+        for d in (batched,):
+            if d is not None:
+                d.pop("_stats", None)
+        sharding_txt = ("output rows per rank, no data-path collective" if not reduce_path else
+                        f"grid {plan['go']} x {plan['gi']}: the {plan['gi']} ranks of a row group take a share of the inputs each and sum their partial "
+                        f"outputs with one all-reduce per step ({backend})")
         line = {
             "metric": "Msamples/sec/node partitioned conv + achieved HBM GB/s vs peak",
             "value": round(value, 4),
@@ -396,52 +601,106 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not args.ir_file else "synthetic audio, impulse responses from " + os.path.basename(args.ir_file),
             "config": {
-                "workload": f"{args.workload}: Convolver {nin}x{nout} per GPU ({nin_total}x{total_out} over {world} GPU), IR {L} samples @ {fs} Hz, "
+                "workload": f"{args.workload}: Convolver {nin}x{nout} per GPU ({nin_total}x{nout_total} over {world} GPU), IR {L} samples @ {fs} Hz, "
                             f"stages {stages}, process block {B} samples, audio + spectra resident in HBM",
-                "sharding": ("output rows per rank, no data-path collective" if not grid else
-                             f"grid {world // 2} x 2: a row group's two ranks take half of the inputs each and sum their partial outputs with one "
-                             f"all-reduce per step ({os.environ.get('BENCH_BACKEND', 'nccl')})"),
+                "inputs": "SURVEY 8d generator (mt19937; IR seed 1000*in+out+1, 60 dB decaying noise of unit norm; audio seed 777+ch)"
+                          if not args.ir_file else "audio: SURVEY 8d generator",
+                "sharding": sharding_txt,
                 "realtime_factor": round(B * args.steps / elapsed / fs, 3),
                 "pair_msamples_per_s": round(value * nin_total, 2),
                 "ir_load_s": round(t_load, 2),
                 "finite_output": finite,
+                "self_check": self_check,
+                "max_rel_err": None if self_check is None else self_check.get("max_rel_err"),
                 "batched": batched,
+                "realtime": realtime,
                 "extended_layout": extended,
                 "tail_ratio": args.tail_ratio,
             },
             "roofline": {
-                "bound": "hbm",
+                "bound": bound,
                 "kernel": f"spectral_mac (tail stage, FFT {tail['fft_size']}, P={tail['partitions']}, ksplit={tail['ksplit']}, out_tile={tail['out_tile']})",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": None if traffic is None else f"static: profiles/traffic_{args.workload}.json (rocprofv3 --pmc passes of an earlier run of this "
+                                                               f"command, tools/pmc_traffic.sh), not measured in this run",
                 "alg_bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(avg_ms, 5),
                 "launches": int(tail["mac_launches"]),
+                "steady_launches": int(tail["mac_steady_launches"]),
                 "all_stage_mac_ms": {str(s["fft_size"]): round(s["mac_ms"], 3) for s in stats},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(args.workload)
-            except Exception as e:      # the baseline must never take the GPU number down with it
-                line["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-            if not args.no_all_cores:
-                try:
-                    line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.workload)
-                except Exception as e:
-                    line["cpu_baseline_all_cores"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if bound == "launch":
+            line["roofline"]["note"] = (f"{live_bytes / 1048576.0:.1f} MiB of live spectra stay in the 256 MiB Infinity Cache: the step is bound by its "
+                                        f"kernel launches, not by HBM; `achieved` is cache bandwidth and `frac` is not an HBM fraction")
+        if roofline_batched is not None:
+            line["roofline_batched"] = roofline_batched
+        if cpu is not None:
+            cpu.pop("_outs", None)
+            cpu.pop("_sub", None)
+            line["cpu_baseline"] = cpu
+        if cpu_all is not None:
+            line["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6):
+    """Paced real-time calls on the engine the headline ran on (every partition live): call k is issued no earlier than
+    k * RB / fs.  `host`: hcv_convolver_process_f32 (host pointers in, host pointers out — what HISSTools::Convolver::process
+    does); `device`: hcv_convolver_process_f32_dev with sync (HBM-resident audio).  Milliseconds per call."""
+    import ctypes as C
+    import hisstools_library_amd as H
+    from hisstools_library_amd._lib import f32p
+    L = H.load()
+    ncalls = max(64, int(seconds * fs / RB))
+    rng = np.random.RandomState(11)
+    xin = rng.uniform(-1, 1, size=(nin, RB)).astype(np.float32)
+    yout = np.zeros((nout, RB), np.float32)
+    ip = (f32p * nin)(*[xin[i].ctypes.data_as(f32p) for i in range(nin)])
+    op = (f32p * nout)(*[yout[o].ctypes.data_as(f32p) for o in range(nout)])
+    xd, yd = torch.from_numpy(xin).to(dev), torch.zeros((nout, RB), device=dev)
+    budget = 1e3 * RB / fs
+    out = {"block": RB, "budget_ms": round(budget, 4), "calls": ncalls}
+
+    def paced(call):
+        ts = np.zeros(ncalls)
+        for _ in range(8):
+            call()
+        t_start = time.perf_counter()
+        for k in range(ncalls):
+            while time.perf_counter() < t_start + k * RB / fs:
+                pass
+            t0 = time.perf_counter()
+            call()
+            ts[k] = time.perf_counter() - t0
+        ts *= 1e3
+        return {"p50_ms": round(float(np.percentile(ts, 50)), 4), "p99_ms": round(float(np.percentile(ts, 99)), 4),
+                "max_ms": round(float(ts.max()), 4), "realtime_factor": round(float(ncalls * budget / ts.sum()), 2),
+                "over_budget": int((ts > budget).sum())}
+
+    def host_call():
+        if L.hcv_convolver_process_f32(conv.h, ip, op, nin, nout, RB) != 0:
+            raise RuntimeError("process_f32 failed")
+
+    def dev_call():
+        conv.process_dev(xd.data_ptr(), RB, yd.data_ptr(), RB, nin, nout, RB, sync=True)
+
+    out["host_pointers"] = paced(host_call)
+    out["device_pointers"] = paced(dev_call)
+    out["finite"] = bool(np.isfinite(yout).all() and torch.isfinite(yd).all().item())
+    return out
 
 
 if __name__ == "__main__":

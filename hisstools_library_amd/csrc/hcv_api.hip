@@ -764,6 +764,9 @@ extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_
     out->mac_ms = s.mac_ms;
     out->ksplit = s.ksplit;
     out->out_tile = s.out_tile;
+    out->mac_steady_launches = s.mac_steady_launches;
+    out->hop_tile = s.hop_tile;
+    out->reserved = 0;
     return 0;
 }
 

@@ -58,6 +58,8 @@ namespace hcv
         uint64_t mac_launches, mac_hops;
         double mac_ms;              // summed HIP-event time of this stage's spectral_mac launches (profiling on)
         uint32_t ksplit, out_tile;
+        uint64_t mac_steady_launches;   // of mac_launches: the unchecked instantiation with nontemporal IR loads
+        uint32_t hop_tile;
     };
 
     class Engine

@@ -683,6 +683,8 @@ bool Engine::stage_stats(size_t s, StageStats *out)
     out->mac_ms = st.ms;
     out->ksplit = st.last_ksplit;
     out->out_tile = st.last_ot;
+    out->mac_steady_launches = st.steady_launches;
+    out->hop_tile = st.last_tt;
     return true;
 }
 
@@ -691,7 +693,7 @@ void Engine::clear_stats()
     std::lock_guard<std::mutex> g(mMutex);
     for (Stage *st : mStages)
     {
-        st->launches = st->hops = 0;
+        st->launches = st->hops = st->steady_launches = 0;
         st->ms = 0.0;
     }
 }

@@ -227,6 +227,8 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             st.hops += (uint64_t) T;
             st.last_ksplit = (uint32_t) pl.ksplit;
             st.last_ot = (uint32_t) pl.ot;
+            st.last_tt = (uint32_t) pl.tt;
+            if (!check && pl.nt) st.steady_launches++;
         }
     }
     if (tail_gate && sj == 0 && mStages.size() > 1 && !mOneStream && st.P && !defer && !have_pre)

@@ -80,7 +80,8 @@ struct Engine::Stage
     // stats
     uint64_t launches = 0, hops = 0;
     double ms = 0.0;
-    uint32_t last_ksplit = 0, last_ot = 0;
+    uint32_t last_ksplit = 0, last_ot = 0, last_tt = 0;
+    uint64_t steady_launches = 0;
 };
 
 struct Engine::GhostEvent

@@ -100,9 +100,16 @@ class IAudioFile(BaseAudioFile):
         self.close()
         self.h = self.L.hcv_iaudiofile_open(str(path).encode())
 
+    @staticmethod
+    def _sample_dtype(dtype):
+        dt = np.dtype(dtype)
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError(f"IAudioFile: samples are read as float32 or float64, not {dt}")
+        return dt
+
     def readInterleaved(self, numFrames: int, dtype=np.float32):
         """Returns [numFrames][channels]."""
-        out = np.zeros((numFrames, self.getChannels()), dtype)
+        out = np.zeros((numFrames, self.getChannels()), self._sample_dtype(dtype))
         if out.size:
             if out.dtype == np.float32:
                 self.L.hcv_iaudiofile_read_interleaved_f32(self.h, out.ctypes.data_as(_lib.f32p), numFrames)
@@ -111,7 +118,7 @@ class IAudioFile(BaseAudioFile):
         return out
 
     def readChannel(self, numFrames: int, channel: int, dtype=np.float32):
-        out = np.zeros(numFrames, dtype)
+        out = np.zeros(numFrames, self._sample_dtype(dtype))
         if out.size:
             if out.dtype == np.float32:
                 self.L.hcv_iaudiofile_read_channel_f32(self.h, out.ctypes.data_as(_lib.f32p), numFrames, channel)

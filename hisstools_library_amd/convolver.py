@@ -398,11 +398,30 @@ class Convolver:
         ir = _f32(ir)
         return self.L.hcv_convolver_set_f32(self.h, inChan, outChan, _fp(ir), ir.size if length is None else length, int(resize))
 
+    @staticmethod
+    def _rows(a, what):
+        """Validate a [channels][n] block handed to the C ABI as raw row pointers: float32 or float64, 2-D, rows contiguous."""
+        if not isinstance(a, np.ndarray) or a.ndim != 2:
+            raise ValueError(f"Convolver.process: {what} must be a 2-D numpy array [channels][samples]")
+        if a.dtype not in (np.float32, np.float64):
+            raise TypeError(f"Convolver.process: {what} must be float32 or float64, not {a.dtype}")
+        if a.shape[1] > 1 and a.strides[1] != a.itemsize:
+            raise ValueError(f"Convolver.process: the rows of {what} must be contiguous (stride {a.strides[1]} bytes between samples)")
+        return a
+
     def process(self, ins, outs, numIns=None, numOuts=None):
-        """ins: [numIns][n], outs: [numOuts][n] written in place; float32 or float64."""
+        """ins: [numIns][n], outs: [numOuts][n] written in place; both float32 or both float64 (Convolver.cpp:138-183).
+        numIns / numOuts beyond the arrays' row counts are clamped: the C side reads that many row pointers."""
+        ins, outs = self._rows(ins, "ins"), self._rows(outs, "outs")
+        if ins.dtype != outs.dtype:
+            raise TypeError(f"Convolver.process: ins ({ins.dtype}) and outs ({outs.dtype}) must share a dtype")
+        if outs.shape[1] < ins.shape[1]:
+            raise ValueError("Convolver.process: outs holds fewer samples per row than ins")
+        if not outs.flags.writeable:
+            raise ValueError("Convolver.process: outs is read-only")
         n = ins.shape[1]
-        ni = ins.shape[0] if numIns is None else numIns
-        no = outs.shape[0] if numOuts is None else numOuts
+        ni = ins.shape[0] if numIns is None else min(int(numIns), ins.shape[0])
+        no = outs.shape[0] if numOuts is None else min(int(numOuts), outs.shape[0])
         if ins.dtype == np.float64:
             rc = self.L.hcv_convolver_process_f64(self.h, _ptr_array(list(ins), f64p), _ptr_array(list(outs), f64p), ni, no, n)
         else:
@@ -411,6 +430,10 @@ class Convolver:
 
     def run(self, ins, numOuts, block=512):
         ins = np.ascontiguousarray(ins)
+        if ins.dtype != np.float64:
+            ins = ins.astype(np.float32, copy=False)
+        if ins.ndim != 2:
+            raise ValueError("Convolver.run: ins must be [channels][samples]")
         nin, total = ins.shape
         outs = np.zeros((numOuts, total), ins.dtype)
         dbl = ins.dtype == np.float64

@@ -165,7 +165,8 @@ namespace
             else if (!std::memcmp(head, "COMM", 4))
             {
                 seen |= T_COMM;
-                const long want = size > 22 ? 22 : (size < 18 ? 18 : size);
+                // plain AIFF: 18 bytes; AIFC adds the 4-byte compression tag, which must be there to be compared
+                const long want = aifc ? 22 : 18;
                 if (want > size || !read_bytes(c, chunk, (size_t) want)) { c.errors |= E_BAD_FORMAT; return; }
                 c.channels = (uint32_t) get_uint(chunk, 2, BIG);
                 c.frames = (uint32_t) get_uint(chunk + 2, 4, BIG);

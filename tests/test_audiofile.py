@@ -128,6 +128,16 @@ def test_errors_are_reported_like_the_reference(tmp_path):
     p = tmp_path / "c.aifc"
     p.write_bytes(bytes(c))
     assert A.IAudioFile(str(p)).getErrors() == [A.Error.ERR_AIFC_UNSUPPORTED_FORMAT]
+    # AIFC whose COMM chunk stops before the compression tag (18..21 bytes): rejected, never classified from stale bytes
+    import struct
+    t = bytearray(aifc)
+    comm = bytes(t).index(b"COMM")
+    t[comm + 4:comm + 8] = struct.pack(">I", 20)
+    p = tmp_path / "t.aifc"
+    p.write_bytes(bytes(t))
+    assert A.IAudioFile(str(p)).getErrors() == [A.Error.ERR_FILE_BAD_FORMAT]
+    with pytest.raises(TypeError):
+        A.IAudioFile(os.path.join(AUDIO, "i16_2ch.wav")).readInterleaved(2, np.int16)
     # unwritable path
     w = A.OAudioFile(str(tmp_path / "no" / "such" / "dir.wav"), A.FileType.kAudioFileWAVE, A.PCMFormat.kAudioFileInt16, 1, 48000.0)
     assert not w.isOpen() and w.getErrors() == [A.Error.ERR_FILE_COULDNT_OPEN]

@@ -726,3 +726,38 @@ def test_create_destroy_cycles_do_not_leak(H, oracle):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned after 300 create/destroy cycles"
+
+
+def test_process_rejects_buffers_the_c_side_would_misread(H, oracle):
+    """Convolver.process hands raw row pointers to the C ABI: mixed precisions, integer data, transposed / strided views
+    and over-long channel counts must be refused or clamped at the Python boundary, never reinterpreted."""
+    c = H.Convolver(2, 2, 0)
+    h = oracle.synth_ir(0, 0, 3000)
+    for i in range(2):
+        assert c.set(i, i, h, True) == 0
+    x32 = np.stack([oracle.synth_audio(i, 1024) for i in range(2)])
+    y32 = np.zeros((2, 1024), np.float32)
+    with pytest.raises(TypeError):
+        c.process(x32.astype(np.float64), y32)                       # f64 in, f32 out would overflow the f32 rows
+    with pytest.raises(TypeError):
+        c.process((x32 * 1000).astype(np.int32), y32)
+    with pytest.raises(ValueError):
+        c.process(np.asfortranarray(x32), y32)                        # samples of a row are not contiguous
+    with pytest.raises(ValueError):
+        c.process(x32[:, ::2], y32)
+    with pytest.raises(ValueError):
+        c.process(x32, np.zeros((2, 100), np.float32))
+    c.process(x32, y32, numIns=7, numOuts=9)                          # clamped to the arrays' rows
+    ref = oracle.Convolver(2, 2, 0)
+    ref.setResetOffset(0)
+    for i in range(2):
+        ref.set(i, i, h, True)
+    y_ref = ref.run(x32, 2, 1024)
+    for o in range(2):
+        assert rel_err(y32[o], y_ref[o]) < TOL
+    # a strided ROW layout (rows far apart, samples contiguous) is fine: only row pointers cross the boundary
+    big = np.zeros((4, 2048), np.float32)
+    c.reset()
+    c.process(x32, big[::2, :1024])
+    for o in range(2):
+        assert rel_err(big[2 * o, :1024], y_ref[o]) < TOL

@@ -5,11 +5,11 @@ The package holds only what the hot path needs:
   _lib.py        ctypes loader of the in-tree shared library (no CPU fallback)
   convolver.py   Python mirror of the reference classes over the C ABI
   fft.py, spectral_functions.py   Python mirror of the hisstools_* FFT functions and the spectral IR functions
-  sharded.py     one-process-per-GPU output-row sharding (torch.distributed plumbing)
+  sharded.py     one-process-per-GPU sharding (torch.distributed plumbing; the single-process form is Convolver(devices=[...]))
 """
 from ._lib import LIB_PATH, load, last_error  # noqa: F401
 from .convolver import (  # noqa: F401
     Convolver, NToMonoConvolve, MonoConvolve, PartitionedConvolve, TimeDomainConvolve,
     LatencyMode, kLatencyZero, kLatencyShort, kLatencyMedium, ConvolveError,
-    hisstools_rfft, hisstools_rifft, spectral_processor, EdgeMode,
+    hisstools_rfft, hisstools_rifft, spectral_processor, EdgeMode, rccl_unique_id,
 )

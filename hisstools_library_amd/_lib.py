@@ -27,6 +27,10 @@ class StageStats(C.Structure):
                 ("ksplit", u32), ("out_tile", u32), ("mac_steady_launches", C.c_uint64), ("hop_tile", u32), ("reserved", u32)]
 
 
+class RtStats(C.Structure):          # hcv_rt_stats
+    _fields_ = [("lock_contended", C.c_uint64), ("lock_wait_ns_max", C.c_uint64), ("blocks_muted", C.c_uint64)]
+
+
 class FFTCall(C.Structure):          # hcv_fft_call
     _fields_ = [("op", C.c_int), ("precision", C.c_int), ("log2n", C.c_uint), ("batch", usz),
                 ("src_a", vp), ("src_b", vp), ("dst_a", vp), ("dst_b", vp),
@@ -103,6 +107,12 @@ SIGNATURES = {
     "hcv_convolver_process_f32_dev": (C.c_int, [vp, vp, usz, vp, usz, usz, usz, usz, C.c_int]),
     "hcv_convolver_synchronize": (C.c_int, [vp]),
     "hcv_convolver_device": (C.c_int, [vp]),
+    "hcv_convolver_create_sharded": (vp, [u32, u32, C.c_int, uptr, C.c_int, u32, u32, u32, u32, C.POINTER(C.c_int), C.c_int, u32]),
+    "hcv_convolver_num_shards": (C.c_int, [vp]),
+    "hcv_rccl_unique_id": (C.c_int, [vp]),
+    "hcv_convolver_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "hcv_convolver_process_f32_dev_allreduce": (C.c_int, [vp, vp, usz, vp, usz, usz, usz, usz, C.c_int]),
+    "hcv_convolver_rt_stats": (C.c_int, [vp, C.POINTER(RtStats)]),
     "hcv_convolver_set_profiling": (None, [vp, C.c_int]),
     "hcv_convolver_num_stages": (C.c_int, [vp]),
     "hcv_convolver_stage_stats": (C.c_int, [vp, C.c_int, C.POINTER(StageStats)]),

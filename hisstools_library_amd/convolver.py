@@ -198,6 +198,13 @@ class spectral_processor:
         return out
 
 
+def rccl_unique_id() -> bytes:
+    """128 bytes (ncclUniqueId) for hcv_convolver_comm_init, made on ONE rank of a row group and handed to the others."""
+    buf = C.create_string_buffer(128)
+    _check(_lib.load().hcv_rccl_unique_id(buf), "rccl_unique_id")
+    return buf.raw
+
+
 # ------------------------------------------------------------------------------------------- classes
 
 class PartitionedConvolve:
@@ -353,9 +360,21 @@ class NToMonoConvolve:
 class Convolver:
     """Convolver(numIns, numOuts, latency) — N x M matrix; Convolver(numIO, latency=...) — parallel (diagonal)."""
 
-    def __init__(self, numIns, numOuts=None, latency=kLatencyZero, device=-1, maxBlock=0, custom=None, tailRatio=0):
+    def __init__(self, numIns, numOuts=None, latency=kLatencyZero, device=-1, maxBlock=0, custom=None, tailRatio=0, devices=None):
         self.L = _lib.load()
-        if custom is not None:
+        if devices is not None:
+            # MI355X extension: ONE object sharded over several devices (hcv_convolver_create_sharded) — output rows first,
+            # inputs too when there are fewer rows than devices
+            parallel = numOuts is None
+            if custom is not None:
+                maxLength, zero, A, B, C_, D = custom
+            else:
+                maxLength, (zero, A, B, C_, D) = 16384, {0: (True, 256, 1024, 4096, 16384), 1: (False, 256, 1024, 4096, 16384)}.get(
+                    int(latency), (False, 1024, 4096, 16384, 0))
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            self.h = _need(self.L.hcv_convolver_create_sharded(numIns, numIns if parallel else numOuts, int(parallel), maxLength, int(bool(zero)),
+                                                               A, B, C_, D, devs, len(devices), maxBlock), "Convolver (sharded)")
+        elif custom is not None:
             # MI355X extension: custom partitioning / capacity (maxLength, zeroLatency, A, B, C, D) and, with tailRatio,
             # the extended far-tail ladder (hcv_convolver_create_extended)
             maxLength, zero, A, B, C_, D = custom
@@ -456,6 +475,26 @@ class Convolver:
 
     def synchronize(self):
         _check(self.L.hcv_convolver_synchronize(self.h), "Convolver.synchronize")
+
+    def num_shards(self) -> int:
+        return self.L.hcv_convolver_num_shards(self.h)
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        """One process per GPU: join this object to its row group's RCCL communicator (hcv_convolver_comm_init).  `unique_id` =
+        the 128 bytes rccl_unique_id() returned on one rank of the group, distributed by the caller."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(self.L.hcv_convolver_comm_init(self.h, buf, rank, nranks), "Convolver.comm_init")
+
+    def process_dev_allreduce(self, ins_ptr: int, in_stride: int, outs_ptr: int, out_stride: int, numIns: int, numOuts: int, n: int, sync=False):
+        """process_dev + ONE in-place ncclAllReduce(sum) of the output block over the row group, on the engine's stream."""
+        _check(self.L.hcv_convolver_process_f32_dev_allreduce(self.h, ins_ptr, in_stride, outs_ptr, out_stride, numIns, numOuts, n, int(sync)),
+               "Convolver.process_dev_allreduce")
+
+    def rt_stats(self):
+        """Audio-thread contract counters since the last clear_stats(): {lock_contended, lock_wait_ns_max, blocks_muted}"""
+        st = _lib.RtStats()
+        _check(self.L.hcv_convolver_rt_stats(self.h, C.byref(st)), "Convolver.rt_stats")
+        return {k: getattr(st, k) for k, _ in _lib.RtStats._fields_}
 
     def device(self) -> int:
         return self.L.hcv_convolver_device(self.h)

@@ -7,8 +7,10 @@
 #include "../../include/hisstools_amd.h"
 #include "hcv_engine.h"
 #include "hcv_api_common.h"
+#include "hcv_rccl.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -372,9 +374,12 @@ namespace
             }
         }
 
+        // MonoConvolve::process, .cpp:181-183: mPart4.attempt() — while a control call holds the pair (set / resize in
+        // progress) the audio thread does not wait, the pair is silent for the block
         bool active(size_t p) const
         {
-            std::lock_guard<std::mutex> g(stateMutex);
+            std::unique_lock<std::mutex> g(stateMutex, std::try_to_lock);
+            if (!g.owns_lock()) return false;
             return mLength[p] && mLength[p] <= part4Size[p];
         }
 
@@ -446,10 +451,52 @@ namespace
 
 struct hcv_mono { std::unique_ptr<Matrix> m; };
 struct hcv_ntomono { std::unique_ptr<Matrix> m; };
-struct hcv_convolver
+// One block of a sharded Convolver: its own Matrix (engine) on its own device, owning outputs [out_lo, out_hi) of inputs
+// [in_lo, in_hi) of the caller's matrix
+struct hcv_shard
 {
     std::unique_ptr<Matrix> m;
+    uint32_t in_lo = 0, in_hi = 0, out_lo = 0, out_hi = 0;
+    int row = 0, col = 0, device = 0;
+    float *part = nullptr;              // input-split layouts: this shard's partial output block [nout_local][maxBlock], on its device
+    hipEvent_t evPart = nullptr;        // ... of the current call is complete
+    hipEvent_t evDone = nullptr;        // row root: the sum of the current call has read every partial block of the row group
+};
+
+struct hcv_shards
+{
+    std::vector<hcv_shard> s;           // rank order: row-major, the root (col 0) of a row group first
+    int go = 1, gi = 1, home = 0;
+    uint32_t nin = 1, nout = 1, maxBlock = 0;
+    bool diag = false;
+
+    hcv_shard *owner(uint32_t in, uint32_t out)
+    {
+        for (hcv_shard &x : s)
+            if (out >= x.out_lo && out < x.out_hi && (diag || (in >= x.in_lo && in < x.in_hi))) return &x;
+        return nullptr;
+    }
+    ~hcv_shards()
+    {
+        for (hcv_shard &x : s)
+        {
+            (void) hipSetDevice(x.device);
+            if (x.m && x.m->engine) x.m->engine->synchronize();
+            if (x.part) (void) hipFree(x.part);
+            if (x.evPart) (void) hipEventDestroy(x.evPart);
+            if (x.evDone) (void) hipEventDestroy(x.evDone);
+        }
+    }
+};
+
+struct hcv_convolver
+{
+    std::unique_ptr<Matrix> m;                 // one engine on one GPU ...
+    std::unique_ptr<hcv_shards> sh;            // ... or one per device of a sharded object (then m is empty)
     std::vector<float> tmpIn, tmpOut;          // float staging of the double overloads
+    hcv::RcclComm *comm = nullptr;             // one-process-per-GPU deployments: this rank's communicator of its row group
+    ~hcv_convolver() { hcv::rccl_comm_destroy(comm); }
+    Engine *engine0() { return sh ? sh->s[0].m->engine.get() : m->engine.get(); }
 };
 
 // ---- MonoConvolve
@@ -563,12 +610,118 @@ static hcv_convolver *wrap(Matrix *m)
     return h;
 }
 
+// ---- sharded Convolver: ONE host object, one engine per listed device.  Output rows are split over the devices
+// first (no exchange); with fewer rows than devices the inputs are split too and a row group's partial blocks are summed on
+// the group's first device — the per-output sum of NToMonoConvolve.cpp:39-42 taken across GPUs.
+
+static void split_range(uint32_t n, uint32_t parts, uint32_t index, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t base = n / parts, rem = n % parts;
+    lo = index * base + std::min(index, rem);
+    hi = lo + base + (index < rem ? 1 : 0);
+}
+
+static hcv_convolver *make_sharded(uint32_t numIns, uint32_t numOuts, bool parallel, uint64_t maxLength, bool zeroLatency, uint32_t A, uint32_t B,
+                                   uint32_t C, uint32_t D, const int *devices, int n, uint32_t maxBlock)
+{
+    if (!devices || n < 1 || !numOuts)
+    {
+        set_error("sharded Convolver: needs at least one device and one output");
+        return nullptr;
+    }
+    const int count = hcv_device_count();
+    for (int k = 0; k < n; k++)
+        if (devices[k] < 0 || devices[k] >= count)
+        {
+            set_error("sharded Convolver: device index out of range");
+            return nullptr;
+        }
+    numIns = parallel ? numOuts : (numIns < 1 ? 1 : numIns);
+    // rows first; what is left of the devices splits the inputs (never more column groups than inputs, none in parallel mode)
+    uint32_t go = std::min<uint32_t>((uint32_t) n, numOuts);
+    uint32_t gi = parallel ? 1 : std::min<uint32_t>(std::max<uint32_t>(1, (uint32_t) n / go), numIns);
+    if (gi > (uint32_t) hcv::kMaxParts) gi = hcv::kMaxParts;
+    std::unique_ptr<hcv_convolver> h(new hcv_convolver());
+    h->sh.reset(new hcv_shards());
+    hcv_shards &sh = *h->sh;
+    sh.go = (int) go;
+    sh.gi = (int) gi;
+    sh.nin = numIns;
+    sh.nout = numOuts;
+    sh.diag = parallel;
+    sh.home = devices[0];
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    bool ok = true;
+    for (uint32_t r = 0; r < go && ok; r++)
+        for (uint32_t c = 0; c < gi && ok; c++)
+        {
+            sh.s.emplace_back();
+            hcv_shard &x = sh.s.back();
+            x.row = (int) r;
+            x.col = (int) c;
+            x.device = devices[r * gi + c];
+            split_range(numOuts, go, r, x.out_lo, x.out_hi);
+            if (parallel) { x.in_lo = x.out_lo; x.in_hi = x.out_hi; }
+            else split_range(numIns, gi, c, x.in_lo, x.in_hi);
+            x.m.reset(make_matrix(x.in_hi - x.in_lo, x.out_hi - x.out_lo, parallel, maxLength, zeroLatency, A, B, C, D, x.device, maxBlock, nullptr));
+            if (!x.m) { ok = false; break; }
+            sh.maxBlock = x.m->engine->max_block();
+            ok = hipSetDevice(x.device) == hipSuccess;
+            // every device reads the caller's buffers (on the home device) and the row root reads its group's partial blocks
+            // directly, over xGMI: peer access both ways between the devices in play
+            for (int k = 0; k < n && ok; k++)
+                if (devices[k] != x.device)
+                {
+                    const hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                    (void) hipGetLastError();
+                }
+            if (ok && gi > 1)
+            {
+                ok = hipMalloc(&x.part, sizeof(float) * (size_t) (x.out_hi - x.out_lo) * sh.maxBlock) == hipSuccess &&
+                     hipEventCreateWithFlags(&x.evPart, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&x.evDone, hipEventDisableTiming) == hipSuccess &&
+                     hipEventRecord(x.evDone, x.m->engine->main_stream()) == hipSuccess;
+            }
+            if (!ok) set_error("sharded Convolver: device set-up failed (peer access / allocation)");
+        }
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (!ok) return nullptr;
+    return h.release();
+}
+
+extern "C" hcv_convolver *hcv_convolver_create_sharded(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency, uint32_t A,
+                                                       uint32_t B, uint32_t C, uint32_t D, const int *devices, int numDevices, uint32_t maxBlock)
+{
+    return make_sharded(numIns, numOuts, parallel != 0, maxLength, zeroLatency != 0, A, B, C, D, devices, numDevices, maxBlock);
+}
+
+// HCV_DEVICES="0,1,2,3": objects made by the reference-shaped constructors (HISSTools::Convolver, hcv_convolver_create / _parallel)
+// are sharded over these devices, so a C++ caller that recompiles unchanged gets every GPU it lists
+static bool env_devices(std::vector<int> &out)
+{
+    const char *env = std::getenv("HCV_DEVICES");
+    if (!env || !*env) return false;
+    for (const char *p = env; *p;)
+    {
+        char *end = nullptr;
+        const long v = std::strtol(p, &end, 10);
+        if (end == p) break;
+        out.push_back((int) v);
+        p = (*end == ',') ? end + 1 : end;
+    }
+    return out.size() > 1 || (out.size() == 1 && std::getenv("HCV_DEVICES_FORCE"));
+}
+
 extern "C" hcv_convolver *hcv_convolver_create_on(uint32_t numIns, uint32_t numOuts, int latency, int device, uint32_t maxBlock)
 {
     bool zero;
     uint32_t A, B, C, D;
     latency_sizes(latency, zero, A, B, C, D);
     numIns = numIns < 1 ? 1 : numIns;                       // Convolver.cpp:8
+    std::vector<int> devs;
+    if (device < 0 && env_devices(devs)) return make_sharded(numIns, numOuts, false, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), maxBlock);
     return wrap(make_matrix(numIns, numOuts, false, 16384, zero, A, B, C, D, device < 0 ? gDefaultDevice : device, maxBlock, nullptr));
 }
 
@@ -583,6 +736,8 @@ extern "C" hcv_convolver *hcv_convolver_create_parallel(uint32_t numIO, int late
     uint32_t A, B, C, D;
     latency_sizes(latency, zero, A, B, C, D);
     numIO = numIO < 1 ? 1 : numIO;                          // Convolver.cpp:27
+    std::vector<int> devs;
+    if (env_devices(devs)) return make_sharded(numIO, numIO, true, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), 0);
     return wrap(make_matrix(numIO, numIO, true, 16384, zero, A, B, C, D, gDefaultDevice, 0, nullptr));
 }
 
@@ -610,18 +765,41 @@ extern "C" hcv_convolver *hcv_convolver_create_extended(uint32_t numIns, uint32_
 extern "C" void hcv_convolver_destroy(hcv_convolver *h) { delete h; }
 
 // parallel mode: "inChan -= outChan" in unsigned arithmetic, then the 1-input NToMonoConvolve range check (Convolver.cpp:92,106,118)
-static bool conv_in_ok(const Matrix &m, uint32_t &inChan, uint32_t outChan)
+static bool conv_in_ok(bool diag, uint32_t nin, uint32_t &inChan, uint32_t outChan)
 {
-    if (m.diag)
+    if (diag)
     {
         inChan -= outChan;
         return inChan < 1;
     }
-    return inChan < m.nin;
+    return inChan < nin;
+}
+static bool conv_in_ok(const Matrix &m, uint32_t &inChan, uint32_t outChan) { return conv_in_ok(m.diag, m.nin, inChan, outChan); }
+
+// the pair's place in a sharded object: range checks on the caller's matrix (same codes as the single-device object), then the
+// owning shard and the pair's indices inside it.  Returns an error code, or -1 with `x` set.
+static int shard_pair(hcv_convolver *h, uint32_t &inChan, uint32_t &outChan, int outRangeCode, hcv_shard *&x)
+{
+    hcv_shards &sh = *h->sh;
+    const bool inOk = conv_in_ok(sh.diag, sh.nin, inChan, outChan);
+    if (outChan >= sh.nout) return outRangeCode;
+    if (!inOk) return HCV_ERR_IN_CHAN_OUT_OF_RANGE;
+    if (sh.diag) inChan = outChan;
+    x = sh.owner(inChan, outChan);
+    if (!x) return HCV_ERR_IN_CHAN_OUT_OF_RANGE;
+    outChan -= x->out_lo;
+    inChan = sh.diag ? outChan : inChan - x->in_lo;
+    return -1;
 }
 
 extern "C" int hcv_convolver_set_f32(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const float *input, uintptr_t length, int resize)
 {
+    if (h->sh)
+    {
+        hcv_shard *x = nullptr;
+        const int rc = shard_pair(h, inChan, outChan, HCV_ERR_OUT_CHAN_OUT_OF_RANGE, x);
+        return rc >= 0 ? rc : x->m->set(inChan, outChan, input, length, resize != 0, false);
+    }
     Matrix &m = *h->m;
     const bool inOk = conv_in_ok(m, inChan, outChan);
     if (outChan >= m.nout) return HCV_ERR_OUT_CHAN_OUT_OF_RANGE;
@@ -631,6 +809,13 @@ extern "C" int hcv_convolver_set_f32(hcv_convolver *h, uint32_t inChan, uint32_t
 
 extern "C" int hcv_convolver_set_f32_dev(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const float *input_dev, uintptr_t length, int resize)
 {
+    if (h->sh)
+    {
+        // (the IR lies on the home device; a shard elsewhere reads it over the peer mapping)
+        hcv_shard *x = nullptr;
+        const int rc = shard_pair(h, inChan, outChan, HCV_ERR_OUT_CHAN_OUT_OF_RANGE, x);
+        return rc >= 0 ? rc : x->m->set(inChan, outChan, input_dev, length, resize != 0, true);
+    }
     Matrix &m = *h->m;
     const bool inOk = conv_in_ok(m, inChan, outChan);
     if (outChan >= m.nout) return HCV_ERR_OUT_CHAN_OUT_OF_RANGE;
@@ -652,7 +837,7 @@ extern "C" void hcv_convolver_clear_chan(hcv_convolver *h, uint32_t inChan, uint
 
 extern "C" void hcv_convolver_clear(hcv_convolver *h, int resize)
 {
-    Matrix &m = *h->m;
+    struct { uint32_t nin, nout; bool diag; } m = { h->sh ? h->sh->nin : h->m->nin, h->sh ? h->sh->nout : h->m->nout, h->sh ? h->sh->diag : h->m->diag };
     for (uint32_t o = 0; o < m.nout; o++)
     {
         if (!m.diag)
@@ -664,6 +849,14 @@ extern "C" void hcv_convolver_clear(hcv_convolver *h, int resize)
 
 extern "C" int hcv_convolver_reset_chan(hcv_convolver *h, uint32_t inChan, uint32_t outChan)
 {
+    if (h->sh)
+    {
+        hcv_shard *x = nullptr;
+        const int rc = shard_pair(h, inChan, outChan, HCV_ERR_OUT_CHAN_OUT_OF_RANGE, x);
+        if (rc >= 0) return rc;
+        x->m->engine->reset_pair(inChan, outChan);
+        return HCV_ERR_NONE;
+    }
     Matrix &m = *h->m;
     const bool inOk = conv_in_ok(m, inChan, outChan);
     if (outChan >= m.nout) return HCV_ERR_OUT_CHAN_OUT_OF_RANGE;
@@ -672,10 +865,22 @@ extern "C" int hcv_convolver_reset_chan(hcv_convolver *h, uint32_t inChan, uint3
     return HCV_ERR_NONE;
 }
 
-extern "C" void hcv_convolver_reset(hcv_convolver *h) { h->m->engine->reset_all(); }
+extern "C" void hcv_convolver_reset(hcv_convolver *h)
+{
+    if (h->sh)
+        for (hcv_shard &x : h->sh->s) x.m->engine->reset_all();
+    else
+        h->m->engine->reset_all();
+}
 
 extern "C" int hcv_convolver_resize(hcv_convolver *h, uint32_t inChan, uint32_t outChan, uintptr_t length)
 {
+    if (h->sh)
+    {
+        hcv_shard *x = nullptr;
+        const int rc = shard_pair(h, inChan, outChan, HCV_ERR_IN_CHAN_OUT_OF_RANGE /* sic, as below */, x);
+        return rc >= 0 ? rc : x->m->resize(inChan, outChan, length);
+    }
     Matrix &m = *h->m;
     const bool inOk = conv_in_ok(m, inChan, outChan);
     if (outChan >= m.nout) return HCV_ERR_IN_CHAN_OUT_OF_RANGE;          // sic: Convolver.cpp:108-111 returns the IN code here
@@ -683,8 +888,56 @@ extern "C" int hcv_convolver_resize(hcv_convolver *h, uint32_t inChan, uint32_t 
     return m.resize(m.diag ? outChan : inChan, outChan, length);
 }
 
+// One call of a sharded object, host pointers: every shard's block is begun (inputs staged, kernels and download enqueued on
+// its own device) before the first is waited for, so the devices run side by side; an input-split row group's partial blocks
+// are added up as they are delivered (root first, which overwrites).
+static int sharded_process_host(hcv_convolver *h, const float *const *ins, float *const *outs, size_t numIns, size_t numOuts, size_t numSamples)
+{
+    hcv_shards &sh = *h->sh;
+    const uint32_t no = (uint32_t) std::min<size_t>(numOuts, sh.nout);
+    const uint32_t ni = sh.diag ? no : (uint32_t) std::min<size_t>(numIns, sh.nin);
+    std::vector<const float *> ip(std::max<uint32_t>(sh.nin, 1));
+    std::vector<float *> op(std::max<uint32_t>(sh.nout, 1));
+    struct Act { uint32_t ni, no; };
+    std::vector<Act> act(sh.s.size());
+    for (size_t k = 0; k < sh.s.size(); k++)
+    {
+        const hcv_shard &x = sh.s[k];
+        act[k].no = no > x.out_lo ? std::min(no, x.out_hi) - x.out_lo : 0;
+        act[k].ni = sh.diag ? act[k].no : (ni > x.in_lo ? std::min(ni, x.in_hi) - x.in_lo : 0);
+    }
+    for (size_t pos = 0; pos < numSamples; pos += sh.maxBlock)
+    {
+        const uint32_t B = (uint32_t) std::min<size_t>(sh.maxBlock, numSamples - pos);
+        for (size_t k = 0; k < sh.s.size(); k++)
+        {
+            hcv_shard &x = sh.s[k];
+            if (!act[k].no || (x.col > 0 && !act[k].ni)) continue;
+            for (uint32_t i = 0; i < act[k].ni; i++) ip[i] = ins[x.in_lo + i] + pos;
+            if (!x.m->engine->process_begin(ip.data(), act[k].ni, act[k].no, B))
+            {
+                set_error(x.m->engine->last_error());
+                return -1;
+            }
+        }
+        for (size_t k = 0; k < sh.s.size(); k++)
+        {
+            hcv_shard &x = sh.s[k];
+            if (!act[k].no || (x.col > 0 && !act[k].ni)) continue;
+            for (uint32_t o = 0; o < act[k].no; o++) op[o] = outs[x.out_lo + o] + pos;
+            if (!x.m->engine->process_end(op.data(), act[k].no, B, /* accumulate */ x.col > 0))
+            {
+                set_error(x.m->engine->last_error());
+                return -1;
+            }
+        }
+    }
+    return 0;
+}
+
 extern "C" int hcv_convolver_process_f32(hcv_convolver *h, const float *const *ins, float **outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
+    if (h->sh) return sharded_process_host(h, ins, outs, numIns, numOuts, numSamples);
     Matrix &m = *h->m;
     const uint32_t no = (uint32_t) std::min<size_t>(numOuts, m.nout);
     const uint32_t ni = m.diag ? no : (uint32_t) std::min<size_t>(numIns, m.nin);
@@ -698,7 +951,7 @@ extern "C" int hcv_convolver_process_f32(hcv_convolver *h, const float *const *i
 
 extern "C" int hcv_convolver_process_f64(hcv_convolver *h, const double *const *ins, double **outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
-    Matrix &m = *h->m;
+    struct { uint32_t nin, nout; bool diag; } m = { h->sh ? h->sh->nin : h->m->nin, h->sh ? h->sh->nout : h->m->nout, h->sh ? h->sh->diag : h->m->diag };
     const uint32_t no = (uint32_t) std::min<size_t>(numOuts, m.nout);
     const uint32_t ni = m.diag ? no : (uint32_t) std::min<size_t>(numIns, m.nin);
     h->tmpIn.resize((size_t) std::max<uint32_t>(ni, 1) * numSamples);
@@ -712,9 +965,13 @@ extern "C" int hcv_convolver_process_f64(hcv_convolver *h, const double *const *
         ip[i] = dst;
     }
     for (uint32_t o = 0; o < no; o++) op[o] = h->tmpOut.data() + (size_t) o * numSamples;
-    if (!m.engine->process(ip.data(), op.data(), ni, no, numSamples, false))
+    if (h->sh)
     {
-        set_error(m.engine->last_error());
+        if (sharded_process_host(h, ip.data(), op.data(), ni, no, numSamples) != 0) return -1;
+    }
+    else if (!h->m->engine->process(ip.data(), op.data(), ni, no, numSamples, false))
+    {
+        set_error(h->m->engine->last_error());
         return -1;
     }
     for (uint32_t o = 0; o < no; o++)
@@ -722,9 +979,76 @@ extern "C" int hcv_convolver_process_f64(hcv_convolver *h, const double *const *
     return 0;
 }
 
+// One call of a sharded object, device pointers (both buffers on the home device).  Every shard's kernels read their input rows
+// and write their output rows in the caller's buffers directly (peer access over xGMI for the shards on other devices): no
+// staging copies.  Input-split layouts: each shard of a row group emits its partial block into a buffer of its own, the
+// group's root waits for them (events across devices) and one kernel on the root's stream writes their sum to the caller's rows.
+static int sharded_process_dev(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride, size_t numIns, size_t numOuts,
+                               size_t numSamples, int sync)
+{
+    hcv_shards &sh = *h->sh;
+    const uint32_t no = (uint32_t) std::min<size_t>(numOuts, sh.nout);
+    const uint32_t ni = sh.diag ? no : (uint32_t) std::min<size_t>(numIns, sh.nin);
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    bool ok = true;
+    for (size_t pos = 0; pos < numSamples && ok; pos += sh.maxBlock)
+    {
+        const size_t B = std::min<size_t>(sh.maxBlock, numSamples - pos);
+        for (size_t k = 0; k < sh.s.size() && ok; k++)
+        {
+            hcv_shard &x = sh.s[k];
+            const uint32_t a_no = no > x.out_lo ? std::min(no, x.out_hi) - x.out_lo : 0;
+            const uint32_t a_ni = sh.diag ? a_no : (ni > x.in_lo ? std::min(ni, x.in_hi) - x.in_lo : 0);
+            if (!a_no) continue;
+            Engine &e = *x.m->engine;
+            const float *src = ins_dev + (size_t) x.in_lo * in_stride + pos;
+            if (sh.gi == 1)
+            {
+                ok = e.process_dev(src, (int64_t) in_stride, outs_dev + (size_t) x.out_lo * out_stride + pos, (int64_t) out_stride, a_ni, a_no, B, false);
+                continue;
+            }
+            hcv_shard &root = sh.s[k - (size_t) x.col];
+            ok = hipSetDevice(x.device) == hipSuccess;
+            // the root's sum of the previous block must have read this shard's partial block before emit overwrites it
+            ok = ok && hipStreamWaitEvent(e.main_stream(), root.evDone, 0) == hipSuccess;
+            ok = ok && e.process_dev(src, (int64_t) in_stride, x.part, (int64_t) sh.maxBlock, a_ni, a_no, B, false);
+            ok = ok && hipEventRecord(x.evPart, e.main_stream()) == hipSuccess;
+        }
+        if (sh.gi > 1)
+            for (size_t k = 0; k < sh.s.size() && ok; k += (size_t) sh.gi)
+            {
+                hcv_shard &root = sh.s[k];
+                const uint32_t a_no = no > root.out_lo ? std::min(no, root.out_hi) - root.out_lo : 0;
+                if (!a_no) continue;
+                hipStream_t rs = root.m->engine->main_stream();
+                ok = hipSetDevice(root.device) == hipSuccess;
+                hcv::PartSources ps;
+                ps.count = sh.gi;
+                for (int c = 0; c < sh.gi && ok; c++)
+                {
+                    ps.part[c] = sh.s[k + (size_t) c].part;
+                    if (c) ok = hipStreamWaitEvent(rs, sh.s[k + (size_t) c].evPart, 0) == hipSuccess;
+                }
+                ok = ok && hcv::launch_sum_parts(ps, (long long) sh.maxBlock, (int) B, (int) a_no, outs_dev + (size_t) root.out_lo * out_stride + pos,
+                                                 (long long) out_stride, rs) == hipSuccess;
+                ok = ok && hipEventRecord(root.evDone, rs) == hipSuccess;
+            }
+    }
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (!ok)
+    {
+        (void) hipGetLastError();
+        set_error("sharded Convolver: a device call failed in process_dev");
+        return -1;
+    }
+    return sync ? hcv_convolver_synchronize(h) : 0;
+}
+
 extern "C" int hcv_convolver_process_f32_dev(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride, size_t numIns,
                                              size_t numOuts, size_t numSamples, int sync)
 {
+    if (h->sh) return sharded_process_dev(h, ins_dev, in_stride, outs_dev, out_stride, numIns, numOuts, numSamples, sync);
     Matrix &m = *h->m;
     const uint32_t no = (uint32_t) std::min<size_t>(numOuts, m.nout);
     const uint32_t ni = m.diag ? no : (uint32_t) std::min<size_t>(numIns, m.nin);
@@ -738,6 +1062,16 @@ extern "C" int hcv_convolver_process_f32_dev(hcv_convolver *h, const float *ins_
 
 extern "C" int hcv_convolver_synchronize(hcv_convolver *h)
 {
+    if (h->sh)
+    {
+        for (hcv_shard &x : h->sh->s)
+            if (!x.m->engine->synchronize())
+            {
+                set_error(x.m->engine->last_error());
+                return -1;
+            }
+        return 0;
+    }
     if (!h->m->engine->synchronize())
     {
         set_error(h->m->engine->last_error());
@@ -746,15 +1080,107 @@ extern "C" int hcv_convolver_synchronize(hcv_convolver *h)
     return 0;
 }
 
-extern "C" int hcv_convolver_device(hcv_convolver *h) { return h->m->engine->device(); }
-extern "C" void hcv_convolver_set_profiling(hcv_convolver *h, int on) { h->m->engine->set_profiling(on != 0); }
-extern "C" int hcv_convolver_num_stages(hcv_convolver *h) { return (int) h->m->engine->num_stages(); }
-extern "C" void hcv_convolver_clear_stats(hcv_convolver *h) { h->m->engine->clear_stats(); }
+extern "C" int hcv_convolver_device(hcv_convolver *h) { return h->sh ? h->sh->home : h->m->engine->device(); }
+extern "C" int hcv_convolver_num_shards(hcv_convolver *h) { return h->sh ? (int) h->sh->s.size() : 1; }
+// (the statistics of a sharded object are those of its first shard)
+extern "C" void hcv_convolver_set_profiling(hcv_convolver *h, int on)
+{
+    if (h->sh)
+        for (hcv_shard &x : h->sh->s) x.m->engine->set_profiling(on != 0);
+    else
+        h->m->engine->set_profiling(on != 0);
+}
+extern "C" int hcv_convolver_num_stages(hcv_convolver *h) { return (int) h->engine0()->num_stages(); }
+extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
+{
+    if (h->sh)
+        for (hcv_shard &x : h->sh->s) { x.m->engine->clear_stats(); x.m->engine->clear_rt_stats(); }
+    else
+    {
+        h->m->engine->clear_stats();
+        h->m->engine->clear_rt_stats();
+    }
+}
+
+extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
+{
+    if (!out) return -1;
+    out->lock_contended = out->lock_wait_ns_max = out->blocks_muted = 0;
+    auto add = [&](Engine &e)
+    {
+        const Engine::RtStats r = e.rt_stats();
+        out->lock_contended += r.lock_contended;
+        out->lock_wait_ns_max = std::max<uint64_t>(out->lock_wait_ns_max, r.lock_wait_ns_max);
+        out->blocks_muted += r.blocks_muted;
+    };
+    if (h->sh)
+        for (hcv_shard &x : h->sh->s) add(*x.m->engine);
+    else
+        add(*h->m->engine);
+    return 0;
+}
+
+// ---- one process per GPU (torch.distributed, MPI, ...): the sum over an input-split row group as ONE RCCL all-reduce on the
+// engine's own stream, behind the block's emit — no host synchronisation between the convolution and the collective
+
+extern "C" int hcv_rccl_unique_id(void *out128)
+{
+    std::string err;
+    if (!hcv::rccl_unique_id(out128, &err))
+    {
+        set_error(err);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int hcv_convolver_comm_init(hcv_convolver *h, const void *unique_id128, int rank, int nranks)
+{
+    if (h->sh)
+    {
+        set_error("hcv_convolver_comm_init: a sharded object sums inside the process; communicators are for one-object-per-GPU deployments");
+        return -1;
+    }
+    std::string err;
+    hcv::RcclComm *c = hcv::rccl_comm_create(unique_id128, rank, nranks, h->m->engine->device(), &err);
+    if (!c)
+    {
+        set_error(err);
+        return -1;
+    }
+    hcv::rccl_comm_destroy(h->comm);
+    h->comm = c;
+    return 0;
+}
+
+extern "C" int hcv_convolver_process_f32_dev_allreduce(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride,
+                                                       size_t numIns, size_t numOuts, size_t numSamples, int sync)
+{
+    if (!h->comm || h->sh)
+    {
+        set_error("hcv_convolver_process_f32_dev_allreduce: no communicator (hcv_convolver_comm_init)");
+        return -1;
+    }
+    if (hcv_convolver_process_f32_dev(h, ins_dev, in_stride, outs_dev, out_stride, numIns, numOuts, numSamples, 0) != 0) return -1;
+    const size_t no = std::min<size_t>(numOuts, h->m->nout);
+    std::string err;
+    int prev = -1;
+    (void) hipGetDevice(&prev);
+    (void) hipSetDevice(h->m->engine->device());
+    const bool ok = hcv::rccl_all_reduce_sum(h->comm, outs_dev, no, numSamples, out_stride, h->m->engine->main_stream(), &err);
+    if (prev >= 0) (void) hipSetDevice(prev);
+    if (!ok)
+    {
+        set_error(err);
+        return -1;
+    }
+    return sync ? hcv_convolver_synchronize(h) : 0;
+}
 
 extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_stats *out)
 {
     hcv::StageStats s;
-    if (stage < 0 || !out || !h->m->engine->stage_stats((size_t) stage, &s)) return -1;
+    if (stage < 0 || !out || !h->engine0()->stage_stats((size_t) stage, &s)) return -1;
     out->fft_size = s.fft_size;
     out->partitions = s.partitions;
     out->num_ins = s.nin;

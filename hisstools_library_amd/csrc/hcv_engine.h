@@ -26,6 +26,7 @@
 
 #include "hcv_kernels.h"
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -92,10 +93,25 @@ namespace hcv
 
         // host-pointer streaming call.  outs[o] is overwritten (accumulate=false) or added to.
         bool process(const float *const *ins, float *const *outs, uint32_t nin_act, uint32_t nout_act, uint64_t n, bool accumulate);
+        // the same in two halves for one block of at most max_block() samples, so that several engines (shards) overlap:
+        // begin = stage the inputs, enqueue the block and its download; end = wait for the download, deliver the samples
+        bool process_begin(const float *const *ins, uint32_t nin_act, uint32_t nout_act, uint32_t B);
+        bool process_end(float *const *outs, uint32_t nout_act, uint32_t B, bool accumulate);
         // device-resident call: ins/outs are [rows][stride] float on this GPU.  Asynchronous unless sync=true.
         bool process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
                          bool sync);
         bool synchronize();
+        // for the layers that combine several engines (shards, collectives): the stream every block's emit — the only writer of
+        // the caller's output buffer — runs on
+        hipStream_t main_stream() const { return mStream; }
+
+        // The audio-thread contract (MemorySwap::attempt, MonoConvolve.cpp:181-183): process never waits for a control call's
+        // upload, allocation or device work — only, at most, for the short host-only section in which a control call swaps
+        // its staged result in.  These count what that cost: calls that found the engine lock taken, the longest such wait,
+        // and blocks given up as silence after kAudioLockBudgetNs (never observed; the reference mutes the pair instead).
+        struct RtStats { uint64_t lock_contended, lock_wait_ns_max, blocks_muted; };
+        RtStats rt_stats() const { return { mLockContended.load(), mLockWaitNsMax.load(), mBlocksMuted.load() }; }
+        void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; }
 
         void set_profiling(bool on);
         bool stage_stats(size_t s, StageStats *out);
@@ -115,6 +131,8 @@ namespace hcv
         void free_stage(Stage &st);
         bool global_reset();
         bool fence_background(bool keep_plan = false);
+        bool ensure_staging(Stage &st, uint32_t parts);
+        bool lock_for_audio(std::unique_lock<std::mutex> &lk);
         bool apply_pending_resets();
         bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
         struct Block;
@@ -151,6 +169,14 @@ namespace hcv
         hipStream_t mStream = nullptr, mInStream = nullptr, mTdStream = nullptr;
         hipEvent_t mEvInput[2] = { nullptr, nullptr }, mEvTd[2] = { nullptr, nullptr }, mEvEmit[2] = { nullptr, nullptr };
         hipEvent_t mEvCtl = nullptr;
+        hipStream_t mCtlStream = nullptr;   // control work beside the audio streams: IR upload + FFTs into staging, capacity growth
+        hipEvent_t mEvSwapDone = nullptr;   // the last swap's device-to-device copies (main stream) have read the staging buffers
+        hipEvent_t mEvSnap = nullptr;       // capacity growth: "everything enqueued so far"
+        hipEvent_t mEvHostDone = nullptr;   // host path: the block's download has landed in the pinned buffer
+        bool mHostMuted = false;            // host path: the block between process_begin and process_end was given up
+        float *mStageTaps = nullptr;        // staging of set_ir: head taps, head spectrum, tail-head spectrum
+        float2 *mStageHead = nullptr, *mStageTailHead = nullptr;
+        std::atomic<uint64_t> mLockContended { 0 }, mLockWaitNsMax { 0 }, mBlocksMuted { 0 };
         hipEvent_t mEvSerial = nullptr;     // end of a run of serial blocks (see enqueue_chunk)
         bool mPrevSerial = false;           // the previous block ran serially on the main stream
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
@@ -161,6 +187,7 @@ namespace hcv
         float *mTdOut[2] = { nullptr, nullptr };   // FIR output, double-buffered by block parity
         float *mDevIn = nullptr, *mDevOut = nullptr;
         float *mPinIn = nullptr, *mPinOut = nullptr;
+        float *mPinInDev = nullptr, *mPinOutDev = nullptr;      // device mappings of the pinned buffers (zero-copy small blocks)
         float *mIrBuf = nullptr;    uint64_t mIrCap = 0;
 
         // time-domain head

@@ -131,7 +131,7 @@ bool Engine::init(const EngineCfg &cfg)
         mErr = "HIP device index out of range";
         return false;
     }
-    HCV_TRY(hipSetDevice(mDevice));
+    DeviceGuard dg(mDevice);
 
     mMaxBlock = cfg.max_block;
     if (!mMaxBlock)
@@ -175,6 +175,12 @@ bool Engine::init(const EngineCfg &cfg)
     }
     HCV_TRY(hipEventCreateWithFlags(&mEvCtl, hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvSerial, hipEventDisableTiming));
+    // control work that must not delay the audio thread (IR upload + FFTs into staging, capacity growth) has its own stream
+    HCV_TRY(hipStreamCreateWithFlags(&mCtlStream, hipStreamNonBlocking));
+    HCV_TRY(hipEventCreateWithFlags(&mEvSwapDone, hipEventDisableTiming));
+    HCV_TRY(hipEventCreateWithFlags(&mEvSnap, hipEventDisableTiming));
+    HCV_TRY(hipEventCreateWithFlags(&mEvHostDone, hipEventDisableTiming));
+    HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
 
     // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
     mHistLen = pow2ceil(3LL * mMaxBlock + std::max<long long>(nmax, 4096));
@@ -184,8 +190,13 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipMemset(mHist, 0, sizeof(float) * mCfg.nin * mHistLen));
     HCV_TRY(hipMalloc(&mDevIn, sizeof(float) * mCfg.nin * mMaxBlock));
     HCV_TRY(hipMalloc(&mDevOut, sizeof(float) * mCfg.nout * mMaxBlock));
-    HCV_TRY(hipHostMalloc(&mPinIn, sizeof(float) * mCfg.nin * mMaxBlock, hipHostMallocDefault));
-    HCV_TRY(hipHostMalloc(&mPinOut, sizeof(float) * mCfg.nout * mMaxBlock, hipHostMallocDefault));
+    HCV_TRY(hipHostMalloc(&mPinIn, sizeof(float) * mCfg.nin * mMaxBlock, hipHostMallocMapped));
+    HCV_TRY(hipHostMalloc(&mPinOut, sizeof(float) * mCfg.nout * mMaxBlock, hipHostMallocMapped));
+    if (hipHostGetDevicePointer((void **) &mPinInDev, mPinIn, 0) != hipSuccess || hipHostGetDevicePointer((void **) &mPinOutDev, mPinOut, 0) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        mPinInDev = mPinOutDev = nullptr;                       // no mapping: every block takes the copy path
+    }
     if (mCfg.has_td)
     {
         for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTdOut[k], sizeof(float) * mCfg.nout * mMaxBlock));
@@ -193,6 +204,7 @@ bool Engine::init(const EngineCfg &cfg)
         HCV_TRY(hipMemset(mTaps, 0, sizeof(float) * pairs * 2048));
         HCV_TRY(hipMalloc(&mTdValid, sizeof(long long) * pairs));
         HCV_TRY(hipMemset(mTdValid, 0, sizeof(long long) * pairs));
+        HCV_TRY(hipMalloc(&mStageTaps, sizeof(float) * 2048));
         mTdCount.assign(pairs, 0);
     }
     mPending.assign(pairs, 0);
@@ -228,6 +240,7 @@ bool Engine::init(const EngineCfg &cfg)
             HCV_TRY(hipMalloc(&mHeadSpec, sizeof(float2) * pairs * s0.M));
             HCV_TRY(hipMemset(mHeadSpec, 0, sizeof(float2) * pairs * s0.M));
             for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mHeadYq[k], sizeof(float2) * (size_t) s0.Tmax * mCfg.nout * s0.M));
+            HCV_TRY(hipMalloc(&mStageHead, sizeof(float2) * s0.M));
         }
     }
     // Whole-hop mode (see enqueue_chunk): needs the zero-latency ladder — head at [0, a), every shorter stage continuing
@@ -255,6 +268,7 @@ bool Engine::init(const EngineCfg &cfg)
             mTailHead = true;
             HCV_TRY(hipMalloc(&mTailHeadSpec, sizeof(float2) * pairs * tl.M));
             HCV_TRY(hipMemset(mTailHeadSpec, 0, sizeof(float2) * pairs * tl.M));
+            HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * tl.M));
             // (room for kTailHeadSplit k-slices: with one partition the MAC has only the input axis to split)
             for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTailHeadYq[k], sizeof(float2) * (size_t) tl.Tmax * kTailHeadSplit * mCfg.nout * tl.M));
         }
@@ -296,6 +310,9 @@ bool Engine::alloc_stage(Stage &st)
         st.big.elems = batch * st.M;
         HCV_TRY(hipMalloc(&st.big.a, sizeof(float2) * st.big.elems));
         HCV_TRY(hipMalloc(&st.big.b, sizeof(float2) * st.big.elems));
+        st.big_ctl = st.big;                                    // the control stream transforms IRs beside the audio streams
+        HCV_TRY(hipMalloc(&st.big_ctl.a, sizeof(float2) * st.big.elems));
+        HCV_TRY(hipMalloc(&st.big_ctl.b, sizeof(float2) * st.big.elems));
     }
     st.tl_len = pow2ceil(2LL * mMaxBlock + st.M);       // two blocks deep (block k+1 adds while block k is emitted)
     HCV_TRY(hipMalloc(&st.timeline, sizeof(float) * mCfg.nout * st.tl_len));
@@ -337,7 +354,11 @@ void Engine::free_stage(Stage &st)
     st.bg_done = nullptr;
     if (st.big.a) (void) hipFree(st.big.a);
     if (st.big.b) (void) hipFree(st.big.b);
-    st.big.a = st.big.b = nullptr;
+    if (st.big_ctl.a) (void) hipFree(st.big_ctl.a);
+    if (st.big_ctl.b) (void) hipFree(st.big_ctl.b);
+    if (st.stage_spec) (void) hipFree(st.stage_spec);
+    st.stage_spec = nullptr;
+    st.big.a = st.big.b = st.big_ctl.a = st.big_ctl.b = nullptr;
     for (int k = 0; k < 2; k++)
         if (st.done[k]) (void) hipEventDestroy(st.done[k]);
     if (st.stream && st.stream != mStream) (void) hipStreamDestroy(st.stream);
@@ -351,7 +372,8 @@ void Engine::free_stage(Stage &st)
 
 Engine::~Engine()
 {
-    (void) hipSetDevice(mDevice);
+    DeviceGuard dg(mDevice);
+    if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);
     if (mInStream) (void) hipStreamSynchronize(mInStream);
     if (mTdStream) (void) hipStreamSynchronize(mTdStream);
     for (Stage *st : mStages)
@@ -396,6 +418,13 @@ Engine::~Engine()
     }
     if (mEvCtl) (void) hipEventDestroy(mEvCtl);
     if (mEvSerial) (void) hipEventDestroy(mEvSerial);
+    if (mEvSwapDone) (void) hipEventDestroy(mEvSwapDone);
+    if (mEvSnap) (void) hipEventDestroy(mEvSnap);
+    if (mEvHostDone) (void) hipEventDestroy(mEvHostDone);
+    if (mStageTaps) (void) hipFree(mStageTaps);
+    if (mStageHead) (void) hipFree(mStageHead);
+    if (mStageTailHead) (void) hipFree(mStageTailHead);
+    if (mCtlStream) (void) hipStreamDestroy(mCtlStream);
     if (mGhostHist) (void) hipFree(mGhostHist);
     if (mRetireTmp) (void) hipFree(mRetireTmp);
     if (mGhostPin) (void) hipHostFree(mGhostPin);
@@ -424,7 +453,7 @@ uint32_t Engine::td_taps(uint32_t in, uint32_t out) const
 
 void Engine::set_stage_window(size_t s, uint64_t offset, uint64_t length)
 {
-    std::lock_guard<std::mutex> g(mMutex);
+    std::lock_guard<std::mutex> g(mSetMutex);          // (the windows are read by set_ir only)
     if (s < mStages.size())
     {
         mStages[s]->cfg.offset = offset;
@@ -434,7 +463,7 @@ void Engine::set_stage_window(size_t s, uint64_t offset, uint64_t length)
 
 void Engine::set_td_window(uint64_t offset, uint64_t length)
 {
-    std::lock_guard<std::mutex> g(mMutex);
+    std::lock_guard<std::mutex> g(mSetMutex);
     mCfg.td_offset = offset;
     mCfg.td_length = length;
 }
@@ -458,16 +487,20 @@ bool Engine::fence_background(bool keep_plan)
 
 // Capacity growth of a stage (MonoConvolve::resize / set(..., requestResize) reallocate the tail partition,
 // MonoConvolve.cpp:101-110,123; here all pairs of a stage share one allocation, so growing re-strides it).
+//
+// The MemorySwap idea (MemorySwap.h:187-229) applied to the whole stage: the new buffers are allocated and filled on the
+// control stream while the audio thread keeps processing on the old ones; only the pointer swap — plus a catch-up copy of
+// the few ring slots written meanwhile — happens under the engine lock.
 bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
 {
-    std::lock_guard<std::mutex> g(mMutex);
+    std::lock_guard<std::mutex> gs(mSetMutex);
     if (s >= mStages.size()) return false;
-    (void) hipSetDevice(mDevice);
+    DeviceGuard dg(mDevice);
     Stage &st = *mStages[s];
     const uint32_t newP = (uint32_t) std::max<uint64_t>(1, (capacity + st.M - 1) / st.M);
     if (newP <= st.Pcap) return true;
-    if (!fence_background()) return false;
 
+    // ---- outside the engine lock: allocate, clear, re-stride what exists
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     const uint32_t newR = newP + 2 * st.Tmax;
     float2 *nHs = nullptr, *nX = nullptr;
@@ -484,41 +517,113 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
         (void) hipFree(nHs);
         return false;
     }
-    bool ok = hipMemsetAsync(nHs, 0, hs_bytes, mStream) == hipSuccess && hipMemsetAsync(nX, 0, x_bytes, mStream) == hipSuccess;
-    if (ok && st.P > 0)
+    long long h_snap = 0;
+    uint32_t live_P = 0;
     {
-        ok = launch_regrow_spectra(st.Hs, nHs, (long long) pairs, (int) st.Pcap, (int) newP, (int) st.M, mStream) == hipSuccess;
-        const long long h_done = mN / st.M;                // hops completed so far: indices 0 .. h_done-1
-        const int live = (int) std::min<long long>(st.P, h_done);
-        if (ok && live > 0)
-            ok = launch_regrow_ring(st.X, nX, (int) mCfg.nin, (int) st.R, (int) newR, (int) st.M, h_done - 1, live, mStream) == hipSuccess;
+        // a snapshot of the hop clock; everything the blocks so far have enqueued is ordered before the copies below
+        std::lock_guard<std::mutex> g(mMutex);
+        h_snap = mN / st.M;
+        live_P = st.P;
+        if (hipEventRecord(mEvSnap, mStream) != hipSuccess) { (void) hipGetLastError(); }
     }
-    ok = ok && hipStreamSynchronize(mStream) == hipSuccess;
+    bool ok = hipStreamWaitEvent(mCtlStream, mEvSnap, 0) == hipSuccess && hipStreamWaitEvent(mCtlStream, mEvSwapDone, 0) == hipSuccess;
+    ok = ok && hipMemsetAsync(nHs, 0, hs_bytes, mCtlStream) == hipSuccess && hipMemsetAsync(nX, 0, x_bytes, mCtlStream) == hipSuccess;
+    if (ok && live_P > 0)
+    {
+        // (the spectra are only ever written by control calls, which mSetMutex serialises with this one)
+        ok = launch_regrow_spectra(st.Hs, nHs, (long long) pairs, (int) st.Pcap, (int) newP, (int) st.M, mCtlStream) == hipSuccess;
+        const int live = (int) std::min<long long>(live_P, h_snap);
+        if (ok && live > 0)
+            ok = launch_regrow_ring(st.X, nX, (int) mCfg.nin, (int) st.R, (int) newR, (int) st.M, h_snap - 1, live, mCtlStream) == hipSuccess;
+    }
+    ok = ok && hipStreamSynchronize(mCtlStream) == hipSuccess;
     if (!ok)
     {
+        (void) hipGetLastError();
         (void) hipFree(nHs);
         (void) hipFree(nX);
         mErr = "stage regrow failed";
         return false;
     }
-    mCtlDirty = true;
-    (void) hipFree(st.Hs);
-    (void) hipFree(st.X);
-    st.Hs = nHs;
-    st.X = nX;
-    st.Pcap = newP;
-    st.R = newR;
+
+    // ---- under the engine lock: the hops that arrived since the snapshot, then the pointer swap (no allocation, no wait)
+    float2 *oHs = nullptr, *oX = nullptr;
+    {
+        std::lock_guard<std::mutex> g(mMutex);
+        if (!fence_background()) ok = false;
+        const long long h_now = mN / st.M;
+        if (ok && st.P > 0 && h_now < h_snap)
+        {
+            // a global reset restarted the hop clock meanwhile: the ring copy is stale, the new clock's hops are what counts
+            ok = hipMemsetAsync(nX, 0, x_bytes, mStream) == hipSuccess;
+            h_snap = 0;
+        }
+        if (ok && st.P > 0 && h_now > h_snap)
+        {
+            const int late = (int) std::min<long long>(h_now - h_snap, (long long) st.R);
+            ok = launch_regrow_ring(st.X, nX, (int) mCfg.nin, (int) st.R, (int) newR, (int) st.M, h_now - 1, late, mStream) == hipSuccess;
+        }
+        if (ok)
+        {
+            oHs = st.Hs;
+            oX = st.X;
+            st.Hs = nHs;
+            st.X = nX;
+            st.Pcap = newP;
+            st.R = newR;
+            mCtlDirty = true;
+            ok = hipEventRecord(mEvSnap, mStream) == hipSuccess;       // the old buffers' last readers are behind this
+        }
+    }
+    if (!ok)
+    {
+        (void) hipGetLastError();
+        (void) hipFree(nHs);
+        (void) hipFree(nX);
+        mErr = "stage regrow failed";
+        return false;
+    }
+    (void) hipEventSynchronize(mEvSnap);
+    (void) hipFree(oHs);
+    (void) hipFree(oX);
     return true;
 }
 
+// staging room of a stage for one pair's spectra (grown with the stage's capacity); control thread only
+bool Engine::ensure_staging(Stage &st, uint32_t parts)
+{
+    if (parts <= st.stage_parts) return true;
+    HCV_TRY(hipStreamSynchronize(mCtlStream));
+    HCV_TRY(hipEventSynchronize(mEvSwapDone));
+    if (st.stage_spec) (void) hipFree(st.stage_spec);
+    st.stage_spec = nullptr;
+    st.stage_parts = 0;
+    const uint32_t want = std::max<uint32_t>(parts, st.Pcap);
+    HCV_TRY(hipMalloc(&st.stage_spec, sizeof(float2) * (size_t) want * st.M));
+    st.stage_parts = want;
+    return true;
+}
+
+// Load / clear one pair's IR (Convolver::set -> ... -> PartitionedConvolve::set, PartitionedConvolve.cpp:173-225).
+//
+// Phase A, no engine lock: the IR is uploaded and transformed into STAGING buffers on the control stream — the pageable host
+// copy, the FFTs of every partition and the wait for them happen while the audio thread keeps processing with the pair's
+// previous spectra (the reference mutes the pair for those blocks instead, MonoConvolve.cpp:118-140,181-183).
+// Phase B, under the engine lock: the pair's pending output is retired, the staged spectra are copied into place on the main
+// stream (device-to-device, asynchronous) and the bookkeeping is swapped — a short, host-only section with no allocation, no
+// host copy and no device wait, which is all the audio thread can ever wait for.
 bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bool device_ptr)
 {
     if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return false;
     std::lock_guard<std::mutex> gs(mSetMutex);
-    HCV_TRY(hipSetDevice(mDevice));
+    DeviceGuard dg(mDevice);
     if (!ir) len = 0;
+    const size_t pair = pair_index(in, out);
 
+    // ---- phase A
     const float *dsrc = nullptr;
+    // the previous swap's copies read the staging buffers on the main stream: order this call's writes behind them
+    HCV_TRY(hipStreamWaitEvent(mCtlStream, mEvSwapDone, 0));
     if (len)
     {
         if (device_ptr)
@@ -527,7 +632,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
         {
             if (len > mIrCap)
             {
-                HCV_TRY(hipStreamSynchronize(mStream));
+                HCV_TRY(hipStreamSynchronize(mCtlStream));
                 if (mIrBuf) (void) hipFree(mIrBuf);
                 mIrBuf = nullptr;
                 mIrCap = 0;
@@ -535,70 +640,85 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
                 HCV_TRY(hipMalloc(&mIrBuf, sizeof(float) * want));
                 mIrCap = want;
             }
+            HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mCtlStream));
             dsrc = mIrBuf;
         }
     }
+    std::vector<uint32_t> newPs(mStages.size(), 0);
+    for (size_t si = 0; si < mStages.size(); si++)
+    {
+        Stage &st = *mStages[si];
+        uint64_t seg = len > st.cfg.offset ? len - st.cfg.offset : 0;          // PartitionedConvolve.cpp:192-193
+        if (st.cfg.length && st.cfg.length < seg) seg = st.cfg.length;
+        const uint64_t cap = (uint64_t) st.Pcap * st.M;
+        if (seg > cap) seg = cap;                                               // :195-199 (caller reports the error)
+        const uint32_t newP = (uint32_t) ((seg + st.M - 1) / st.M);
+        newPs[si] = newP;
+        if (!newP) continue;
+        if (!ensure_staging(st, newP)) return false;
+        HCV_TRY(launch_rfft_ir(st.log2n, dsrc + st.cfg.offset, (long long) seg, (int) newP, st.stage_spec, st.tw, &st.big_ctl, mCtlStream));
+    }
+    uint64_t taps = 0;
+    if (mCfg.has_td)
+    {
+        const uint64_t lim = mCfg.td_length ? mCfg.td_length : 2044;            // TimeDomainConvolve.cpp:77
+        taps = len > mCfg.td_offset ? std::min<uint64_t>(len - mCfg.td_offset, lim) : 0;
+        if (taps > 2044) taps = 2044;
+        if (taps) HCV_TRY(hipMemcpyAsync(mStageTaps, dsrc + mCfg.td_offset, sizeof(float) * taps, hipMemcpyDeviceToDevice, mCtlStream));
+        HCV_TRY(hipMemsetAsync(mStageTaps + taps, 0, sizeof(float) * (2048 - taps), mCtlStream));
+        if (mHeadFFT)
+        {
+            Stage &s0 = *mStages[0];
+            HCV_TRY(launch_rfft_ir(s0.log2n, taps ? dsrc + mCfg.td_offset : mHist, (long long) taps, 1, mStageHead, s0.tw, &s0.big_ctl, mCtlStream));
+        }
+    }
+    if (mTailHead)
+    {
+        Stage &tl = *mStages.back();
+        const uint64_t first = std::min<uint64_t>(len, tl.M);
+        HCV_TRY(launch_rfft_ir(tl.log2n, first ? dsrc : mHist, (long long) first, 1, mStageTailHead, tl.tw, &tl.big_ctl, mCtlStream));
+    }
+    HCV_TRY(hipStreamSynchronize(mCtlStream));          // the device has consumed `ir`; the staging buffers are complete
 
+    // ---- phase B
     {
         std::lock_guard<std::mutex> g(mMutex);
         if (!fence_background(exact_restart())) return false;
-        if (len && !device_ptr) HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mStream));
-        const size_t pair = pair_index(in, out);
         // what the pair still has to deliver belongs to the spectra about to be replaced: take it out of the timelines now
         if (mLoaded[pair] && !mRetired[pair] && !retire_pair(pair)) return false;
         mRetired[pair] = 1;                                                         // (an empty pair has nothing pending)
         bool any = false;
-        for (Stage *sp : mStages)
+        for (size_t si = 0; si < mStages.size(); si++)
         {
-            Stage &st = *sp;
-            uint64_t seg = len > st.cfg.offset ? len - st.cfg.offset : 0;          // PartitionedConvolve.cpp:192-193
-            if (st.cfg.length && st.cfg.length < seg) seg = st.cfg.length;
-            const uint64_t cap = (uint64_t) st.Pcap * st.M;
-            if (seg > cap) seg = cap;                                               // :195-199 (caller reports the error)
-            const uint32_t newP = (uint32_t) ((seg + st.M - 1) / st.M);
-            const uint32_t oldP = st.pact[pair];
-            const uint32_t wr = std::max(newP, oldP);
-            if (wr)
-            {
-                const float *src = seg ? dsrc + st.cfg.offset : mHist;              // never dereferenced when seg == 0
-                HCV_TRY(launch_rfft_ir(st.log2n, src, (long long) seg, (int) wr, st.Hs + pair * (size_t) st.Pcap * st.M, st.tw, &st.big, mStream));
-            }
+            Stage &st = *mStages[si];
+            const uint32_t newP = std::min(newPs[si], st.Pcap), oldP = st.pact[pair];
+            float2 *dst = st.Hs + pair * (size_t) st.Pcap * st.M;
+            if (newP) HCV_TRY(hipMemcpyAsync(dst, st.stage_spec, sizeof(float2) * (size_t) newP * st.M, hipMemcpyDeviceToDevice, mStream));
+            if (oldP > newP) HCV_TRY(hipMemsetAsync(dst + (size_t) newP * st.M, 0, sizeof(float2) * (size_t) (oldP - newP) * st.M, mStream));
             st.live_parts += newP;
-            st.live_parts -= st.pact[pair];
+            st.live_parts -= oldP;
             st.pact[pair] = newP;
             st.P = *std::max_element(st.pact.begin(), st.pact.end());
             any = any || newP;
         }
         if (mCfg.has_td)
         {
-            const uint64_t lim = mCfg.td_length ? mCfg.td_length : 2044;            // TimeDomainConvolve.cpp:77
-            uint64_t taps = len > mCfg.td_offset ? std::min<uint64_t>(len - mCfg.td_offset, lim) : 0;
-            if (taps > 2044) taps = 2044;
-            float *dst = mTaps + pair * 2048;
-            if (taps) HCV_TRY(hipMemcpyAsync(dst, dsrc + mCfg.td_offset, sizeof(float) * taps, hipMemcpyDeviceToDevice, mStream));
-            HCV_TRY(hipMemsetAsync(dst + taps, 0, sizeof(float) * (2048 - taps), mStream));
+            HCV_TRY(hipMemcpyAsync(mTaps + pair * 2048, mStageTaps, sizeof(float) * 2048, hipMemcpyDeviceToDevice, mStream));
             if (mHeadFFT)
-            {
-                Stage &s0 = *mStages[0];
-                const float *src = taps ? dsrc + mCfg.td_offset : mHist;
-                HCV_TRY(launch_rfft_ir(s0.log2n, src, (long long) taps, 1, mHeadSpec + pair * (size_t) s0.M, s0.tw, &s0.big, mStream));
-            }
+                HCV_TRY(hipMemcpyAsync(mHeadSpec + pair * (size_t) mStages[0]->M, mStageHead, sizeof(float2) * mStages[0]->M, hipMemcpyDeviceToDevice, mStream));
             mTdCount[pair] = (uint32_t) taps;
             uint32_t mx = *std::max_element(mTdCount.begin(), mTdCount.end());
             mTdLpad = ((mx + 15) / 16) * 16;
             any = any || taps;
         }
         if (mTailHead)
-        {
-            Stage &tl = *mStages.back();
-            const uint64_t first = std::min<uint64_t>(len, tl.M);
-            HCV_TRY(launch_rfft_ir(tl.log2n, first ? dsrc : mHist, (long long) first, 1, mTailHeadSpec + pair * (size_t) tl.M, tl.tw, &tl.big, mStream));
-        }
+            HCV_TRY(hipMemcpyAsync(mTailHeadSpec + pair * (size_t) mStages.back()->M, mStageTailHead, sizeof(float2) * mStages.back()->M,
+                                   hipMemcpyDeviceToDevice, mStream));
         mLoaded[pair] = any ? 1 : 0;
         mPending[pair] = 1;                                                         // set() always ends in reset()
         mCtlDirty = true;
+        HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
     }
-    HCV_TRY(hipStreamSynchronize(mStream));
     return true;
 }
 
@@ -639,7 +759,7 @@ bool Engine::global_reset()
 
 bool Engine::synchronize()
 {
-    HCV_TRY(hipSetDevice(mDevice));
+    DeviceGuard dg(mDevice);
     HCV_TRY(hipStreamSynchronize(mStream));
     if (mProfiling) collect_events();
     return true;

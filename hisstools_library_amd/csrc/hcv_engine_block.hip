@@ -3,6 +3,8 @@
 
 #include "hcv_engine_impl.h"
 
+#include <chrono>
+
 namespace hcv
 {
 
@@ -434,41 +436,114 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     return true;
 }
 
+// The audio thread takes the engine lock with try_lock (MemorySwap::attempt, MemorySwap.h:182-185).  Control calls hold it
+// only for host-only pointer-swap sections (set_ir phase B, the swap of ensure_stage_capacity, flag writes) — no upload, no
+// allocation, no device wait — so contention is polled out; past kAudioLockBudgetNs the block is given up as silence, the
+// whole-matrix form of the reference's muted pair (MonoConvolve.cpp:181-183).
+constexpr long long kAudioLockBudgetNs = 2000000;
+
+bool Engine::lock_for_audio(std::unique_lock<std::mutex> &lk)
+{
+    lk = std::unique_lock<std::mutex>(mMutex, std::try_to_lock);
+    if (lk.owns_lock()) return true;
+    mLockContended++;
+    const auto t0 = std::chrono::steady_clock::now();
+    long long waited = 0;
+    bool got = false;
+    while (waited < kAudioLockBudgetNs)
+    {
+        for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+        got = lk.try_lock();
+        waited = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (got) break;
+    }
+    uint64_t prev = mLockWaitNsMax.load();
+    while ((uint64_t) waited > prev && !mLockWaitNsMax.compare_exchange_weak(prev, (uint64_t) waited)) {}
+    if (!got) mBlocksMuted++;
+    return got;
+}
+
+// Host-pointer path, first half: stage the inputs, enqueue the block and the download of its result.  Small blocks (the
+// real-time sizes) skip both DMA copies: scatter_input reads the pinned staging buffer through its device mapping and emit
+// writes the pinned output buffer directly — two copy-engine round trips less per call.
+bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t nout_act, uint32_t B)
+{
+    DeviceGuard dg(mDevice);
+    nout_act = std::min(nout_act, mCfg.nout);
+    nin_act = std::min(nin_act, mCfg.nin);
+    mHostMuted = false;
+    if (!nout_act || !B) return true;
+    if (B > mMaxBlock) { mErr = "process_begin: block longer than max_block"; return false; }
+    const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+    for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i], sizeof(float) * B);
+    std::unique_lock<std::mutex> lk;
+    if (!lock_for_audio(lk))
+    {
+        mHostMuted = true;
+        return true;
+    }
+    if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+    static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
+    const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
+    if (zero_copy)
+    {
+        if (!enqueue_chunk(mPinInDev, B, mPinOutDev, B, nin_act, nout_act, B)) return false;
+    }
+    else
+    {
+        // the upload goes on the main stream and is handed to the block like control work: a serial block scatters on the
+        // main stream, a streamed one makes its input stream wait for it (enqueue_chunk, mCtlDirty)
+        if (rows_in)
+        {
+            HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
+            mCtlDirty = true;
+        }
+        if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
+        HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
+    }
+    HCV_TRY(hipEventRecord(mEvHostDone, mStream));
+    return true;
+}
+
+// second half: wait for THIS block's result (an event, not the stream) and deliver it
+bool Engine::process_end(float *const *outs, uint32_t nout_act, uint32_t B, bool accumulate)
+{
+    nout_act = std::min(nout_act, mCfg.nout);
+    if (!nout_act || !B) return true;
+    if (mHostMuted)
+    {
+        if (!accumulate)
+            for (uint32_t o = 0; o < nout_act; o++) std::memset(outs[o], 0, sizeof(float) * B);
+        return true;
+    }
+    DeviceGuard dg(mDevice);
+    HCV_TRY(hipEventSynchronize(mEvHostDone));
+    for (uint32_t o = 0; o < nout_act; o++)
+    {
+        float *dst = outs[o];
+        const float *src = mPinOut + (size_t) o * B;
+        if (accumulate)
+            for (uint32_t j = 0; j < B; j++) dst[j] += src[j];
+        else
+            std::memcpy(dst, src, sizeof(float) * B);
+    }
+    return true;
+}
+
 bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_act, uint32_t nout_act, uint64_t n, bool accumulate)
 {
-    HCV_TRY(hipSetDevice(mDevice));
     nout_act = std::min(nout_act, mCfg.nout);
     nin_act = std::min(nin_act, mCfg.nin);
     if (!nout_act || !n) return true;
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
-
+    std::vector<const float *> ip(std::max<uint32_t>(rows_in, 1));
+    std::vector<float *> op(nout_act);
     for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
     {
         const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
-        for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i] + pos, sizeof(float) * B);
-        {
-            std::lock_guard<std::mutex> g(mMutex);
-            if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
-            // the upload goes on the main stream and is handed to the block like control work: a serial block scatters on the
-            // main stream, a streamed one makes its input stream wait for it (enqueue_chunk, mCtlDirty)
-            if (rows_in)
-            {
-                HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
-                mCtlDirty = true;
-            }
-            if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
-            HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
-        }
-        HCV_TRY(hipStreamSynchronize(mStream));
-        for (uint32_t o = 0; o < nout_act; o++)
-        {
-            float *dst = outs[o] + pos;
-            const float *src = mPinOut + (size_t) o * B;
-            if (accumulate)
-                for (uint32_t j = 0; j < B; j++) dst[j] += src[j];
-            else
-                std::memcpy(dst, src, sizeof(float) * B);
-        }
+        for (uint32_t i = 0; i < rows_in; i++) ip[i] = ins[i] + pos;
+        for (uint32_t o = 0; o < nout_act; o++) op[o] = outs[o] + pos;
+        if (!process_begin(ip.data(), nin_act, nout_act, B) || !process_end(op.data(), nout_act, B, accumulate)) return false;
     }
     if (mProfiling) collect_events();
     return true;
@@ -477,12 +552,19 @@ bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_a
 bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
                          bool sync)
 {
-    HCV_TRY(hipSetDevice(mDevice));
+    DeviceGuard dg(mDevice);
     nout_act = std::min(nout_act, mCfg.nout);
     nin_act = std::min(nin_act, mCfg.nin);
     if (!nout_act || !n) return true;
     {
-        std::lock_guard<std::mutex> g(mMutex);
+        std::unique_lock<std::mutex> lk;
+        if (!lock_for_audio(lk))
+        {
+            // given up: silence for this call (see lock_for_audio); nothing of the engine's state is touched
+            HCV_TRY(hipMemset2DAsync(outs, sizeof(float) * (size_t) out_stride, 0, sizeof(float) * n, nout_act, mStream));
+            if (sync) HCV_TRY(hipStreamSynchronize(mStream));
+            return true;
+        }
         if (!update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
         for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
         {

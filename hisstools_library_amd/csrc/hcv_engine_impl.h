@@ -26,6 +26,25 @@ inline long long pow2ceil(long long v)
     return p;
 }
 
+// the calling thread's current HIP device is put back when an entry point returns (the engine may live on another GPU than
+// the one the caller — PyTorch, say — is working on)
+struct DeviceGuard
+{
+    int prev = -1;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void) hipSetDevice(device);
+        else prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void) hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 constexpr int kBgSlices = 16;
 constexpr int kTailHeadSplit = 8;
 
@@ -62,6 +81,9 @@ struct Engine::Stage
     float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
+    BigFFTWork big_ctl;                 // the same for IR transforms on the control stream
+    float2 *stage_spec = nullptr;       // staging for one pair's spectra (set_ir phase A), stage_parts partitions
+    uint32_t stage_parts = 0;
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream (the MAC stream)
     hipEvent_t mac_done[2] = { nullptr, nullptr };     // the stage's spectral_mac of a block has finished (tail gate)
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity

@@ -99,6 +99,14 @@ namespace hcv
     };
     hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, const float *td, long long td_stride, float *out,
                            long long out_stride, hipStream_t st);
+    // ---- sharded matrices: the sum of the input groups' partial output blocks ----
+    constexpr int kMaxParts = 16;
+    struct PartSources
+    {
+        const float *part[kMaxParts];
+        int count;
+    };
+    hipError_t launch_sum_parts(const PartSources &src, long long part_stride, int B, int nout, float *out, long long out_stride, hipStream_t st);
     // ---- one-shot spectral convolution / correlation ----
     hipError_t launch_spectral_pointwise(float2 *a, const float2 *b, int M, float scale, int correlate, hipStream_t st);
     hipError_t launch_segment_op(float *out, const float *t, long long o_off, long long off, long long n, int op, hipStream_t st);

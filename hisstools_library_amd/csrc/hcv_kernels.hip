@@ -484,6 +484,21 @@ __global__ void emit_kernel(EmitSources src, long long n0, int B, const float *_
     }
 }
 
+// the final per-output sum over the input groups of a sharded matrix (NToMonoConvolve.cpp:39-42 across devices):
+// out[o][j] = sum_c part_c[o][j]; the partial blocks may live on peer devices (read over xGMI)
+__global__ void sum_parts_kernel(PartSources src, long long part_stride, int B, float *__restrict__ out, long long out_stride)
+{
+    const int o = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B; j += gridDim.x * blockDim.x)
+    {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxParts; c++)
+            if (c < src.count) v += src.part[c][(long long) o * part_stride + j];
+        out[(long long) o * out_stride + j] = v;
+    }
+}
+
 __global__ void fill_i64_kernel(long long *p, long long n, long long v)
 {
     for (long long j = blockIdx.x * (long long) blockDim.x + threadIdx.x; j < n; j += (long long) gridDim.x * blockDim.x) p[j] = v;
@@ -729,6 +744,14 @@ hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, co
     if (B <= 0 || nout <= 0) return hipSuccess;
     dim3 grid(std::min((B + 255) / 256, 64), nout);
     hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, src, n0, B, td, td_stride, out, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_parts(const PartSources &src, long long part_stride, int B, int nout, float *out, long long out_stride, hipStream_t st)
+{
+    if (B <= 0 || nout <= 0 || src.count <= 0) return hipSuccess;
+    dim3 grid(std::min((B + 255) / 256, 64), nout);
+    hipLaunchKernelGGL(sum_parts_kernel, grid, dim3(256), 0, st, src, part_stride, B, out, out_stride);
     return hipGetLastError();
 }
 

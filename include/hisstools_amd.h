@@ -150,6 +150,41 @@ HCV_API int hcv_convolver_process_f32_dev(hcv_convolver *h, const float *ins_dev
 HCV_API int hcv_convolver_synchronize(hcv_convolver *h);
 HCV_API int hcv_convolver_device(hcv_convolver *h);
 
+/* Multi-GPU, one host object (Convolver.h:23-50 stays the interface): `numDevices` engines, one per listed device
+ * (an index may repeat: several shards on one GPU).  Output rows are split over the devices first — no exchange, each device
+ * delivers final samples for its rows.  With fewer output rows than devices the inputs are split as well and the partial blocks
+ * of a row group are summed on the group's first device: the per-output sum of NToMonoConvolve.cpp:39-42 taken across GPUs
+ * (peer reads over xGMI).  Every hcv_convolver_* call works on the result: set / resize / clear / reset go to the shard that
+ * owns the pair, process splits the channel pointers (host path: all shards are begun before the first is waited for; device
+ * path: buffers on devices[0], read and written in place by every device).  Parameters as hcv_convolver_create_custom.
+ * HCV_DEVICES="0,1,..." in the environment makes hcv_convolver_create / _create_parallel (and so HISSTools::Convolver) build
+ * such an object, so that a caller that recompiles unchanged uses every GPU listed. */
+HCV_API hcv_convolver *hcv_convolver_create_sharded(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency,
+                                                    uint32_t A, uint32_t B, uint32_t C, uint32_t D, const int *devices, int numDevices,
+                                                    uint32_t maxBlock);
+HCV_API int hcv_convolver_num_shards(hcv_convolver *h);
+
+/* One process per GPU (torch.distributed, MPI): each rank owns a single-device object holding its share of the inputs of a row
+ * group, and the group's partial output blocks are summed with ONE ncclAllReduce(ncclFloat, ncclSum) per call, enqueued on the
+ * object's own stream behind the block (RCCL over xGMI; librccl is bound at run time, the copy the process already holds is
+ * used).  hcv_rccl_unique_id fills 128 bytes (ncclUniqueId) on one rank; the caller distributes them (its launcher's store);
+ * every rank of the group then calls hcv_convolver_comm_init with its rank in the group.  _allreduce = process_f32_dev + the
+ * in-place all-reduce of outs_dev (numOuts rows of numSamples).  0 ok, -1 failure. */
+HCV_API int hcv_rccl_unique_id(void *out128);
+HCV_API int hcv_convolver_comm_init(hcv_convolver *h, const void *unique_id128, int rank, int nranks);
+HCV_API int hcv_convolver_process_f32_dev_allreduce(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride,
+                                                    size_t numIns, size_t numOuts, size_t numSamples, int sync);
+
+/* The audio-thread contract (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:181-183): process never waits for a
+ * control call's upload, allocation or device work, at most for the short host-only section in which a control call swaps its
+ * staged result in.  Counters since the last hcv_convolver_clear_stats: process calls that found the engine lock taken, the
+ * longest such wait in nanoseconds, and blocks given up as silence after 2 ms (the whole-matrix form of the muted pair). */
+typedef struct hcv_rt_stats
+{
+    uint64_t lock_contended, lock_wait_ns_max, blocks_muted;
+} hcv_rt_stats;
+HCV_API int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out);
+
 /* per-stage measurements of the spectral multiply-accumulate kernel (HIP events on the launch stream) */
 typedef struct hcv_stage_stats
 {

@@ -1,0 +1,134 @@
+"""The audio-thread contract of the reference (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:118-140,181-183):
+`process` never waits for a control thread's `set` / `resize` — not for the IR upload, not for an allocation, not for the
+device.  The reference mutes the pair being replaced for the blocks processed meanwhile; here the pair keeps playing its
+previous IR until the staged spectra are swapped in (engine.h: set_ir phases A / B), and what the audio thread can wait for is
+one short host-only section.
+
+A control thread loops set(resize=True) with GROWING 10 s-class IRs on a 16x16 zero-latency engine — every growth re-strides the
+tail stage's whole spectrum store — while the audio thread issues paced 128-sample calls.  Asserted: no call exceeds the
+2.67 ms real-time budget of 128 samples at 48 kHz; no block was given up; the outputs whose pairs are NOT being replaced equal
+the CPU oracle's sample for sample (tolerance 1e-5) right through the swaps and regrows; the replaced pairs stay finite; and
+after the control thread has finished, a known IR set + reset gives the oracle's stream again.
+"""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hisstools_library_amd as H
+    assert H.load().hcv_device_count() > 0, "no GPU visible: the HIP path cannot run (and there is no fallback)"
+    return H
+
+
+def _paced(call, ncalls, period):
+    ts = np.zeros(ncalls)
+    t_start = time.perf_counter()
+    for k in range(ncalls):
+        while time.perf_counter() < t_start + k * period:
+            pass
+        t0 = time.perf_counter()
+        call(k)
+        ts[k] = time.perf_counter() - t0
+    return ts * 1e3
+
+
+@pytest.mark.parametrize("entry", ["host_pointers", "device_pointers"])
+def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    nin = nout = 16
+    fs, RB = 48000, 128
+    steady = [0, 1]                                    # output rows checked against the oracle (their pairs are never replaced)
+    L_fix = 60000
+    ncalls = 1400                                      # 3.7 s of audio
+    S = ncalls * RB
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    c = H.Convolver(nin, nout, 0, maxBlock=8192)
+    ref = oracle.Convolver(nin, len(steady), 0)
+    ref.setResetOffset(0)
+    for o in range(nout):
+        for i in range(nin):
+            h = oracle.synth_ir(i, o, L_fix)
+            assert c.set(i, o, h, True) == 0
+            if o in steady:
+                assert ref.set(i, steady.index(o), h, True) == 0
+    # growing IRs for the control thread: 1.25 s .. 10 s, host memory (pageable: the upload is part of what must not block)
+    grow = [oracle.synth_ir(3, 9, n) for n in range(60000, 480001, 60000)]
+
+    ys = np.zeros((nout, S), np.float32)
+    if entry == "device_pointers":
+        xd, yd = torch.from_numpy(xs).to(dev), torch.zeros((nout, S), device=dev)
+        torch.cuda.synchronize()
+
+        def call(k):
+            c.process_dev(xd.data_ptr() + 4 * k * RB, S, yd.data_ptr() + 4 * k * RB, S, nin, nout, RB, sync=True)
+    else:
+        def call(k):
+            c.process(xs[:, k * RB:(k + 1) * RB], ys[:, k * RB:(k + 1) * RB])
+
+    for k in range(40):                                # settle clocks and allocator pools before the control thread starts
+        call(k)
+    c.reset()
+    c.clear_stats()
+    stop = threading.Event()
+    sets = {"n": 0, "worst_ms": 0.0, "errors": []}
+
+    def control():
+        k = 0
+        while not stop.is_set():
+            h = grow[k % len(grow)]
+            o = 8 + (k % 8)                            # rows 8..15 only: the checked rows keep their IRs
+            t0 = time.perf_counter()
+            rc = c.set((5 * k) % nin, o, h, True)
+            sets["worst_ms"] = max(sets["worst_ms"], 1e3 * (time.perf_counter() - t0))
+            if rc != 0:
+                sets["errors"].append(rc)
+            sets["n"] += 1
+            k += 1
+            time.sleep(0.002)
+
+    th = threading.Thread(target=control)
+    th.start()
+    try:
+        ts = _paced(call, ncalls, RB / fs)
+    finally:
+        stop.set()
+        th.join()
+    if entry == "device_pointers":
+        ys = yd.cpu().numpy()
+    rt = c.rt_stats()
+    budget = 1e3 * RB / fs
+    print(f"[{entry}] {sets['n']} set(resize) calls (worst {sets['worst_ms']:.1f} ms each) beside {ncalls} paced calls: p50 {np.percentile(ts, 50):.3f} "
+          f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); lock contended {rt['lock_contended']}x, longest wait "
+          f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}")
+    assert not sets["errors"] and sets["n"] >= 8                         # every length was loaded at least once: the stage regrew
+    assert rt["blocks_muted"] == 0
+    assert rt["lock_wait_ns_max"] < 1.0e6                                  # host-only swap sections: far below a millisecond
+    assert ts.max() < budget, f"a process call took {ts.max():.3f} ms beside set(): over the {budget:.2f} ms budget"
+    assert np.isfinite(ys).all()
+    y_ref = ref.run(xs, len(steady), 2048)
+    for k, o in enumerate(steady):
+        assert rel_err(ys[o], y_ref[k]) < 1e-5, (o, rel_err(ys[o], y_ref[k]))
+    # afterwards: known IRs everywhere + reset -> the oracle's stream again (nothing stale survived the swaps and regrows)
+    rows = [0, 9, 15]
+    ref2 = oracle.Convolver(nin, len(rows), 0)
+    ref2.setResetOffset(0)
+    for o in range(8, nout):
+        for i in range(nin):
+            assert c.set(i, o, oracle.synth_ir(i, o, 30000), True) == 0
+    for k, o in enumerate(rows):
+        for i in range(nin):
+            assert ref2.set(i, k, oracle.synth_ir(i, o, L_fix if o < 8 else 30000), True) == 0
+    c.reset()
+    y2 = c.run(xs[:, :40000], nout, [128, 4096, 1000])
+    y2_ref = ref2.run(xs[:, :40000], len(rows), 2048)
+    for k, o in enumerate(rows):
+        assert rel_err(y2[o], y2_ref[k]) < 1e-5

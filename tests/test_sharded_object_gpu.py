@@ -1,0 +1,199 @@
+"""Multi-GPU as a property of the C ABI: ONE Convolver object driving several engines
+(hcv_convolver_create_sharded; Convolver.h:23-50 stays the interface, the per-output sum of NToMonoConvolve.cpp:39-42 is what
+crosses devices).  On the one-GPU test box the device list names the same GPU twice or more: two or four HIP engines behind one
+object, the same code path as distinct devices minus the peer mapping.
+
+Bars: a sharded run matches the unsharded HIP output to <= 1e-6 (row split: identical arithmetic per row) and
+<= 1e-5 (input split: the sum order changes), and both match the CPU oracle within the stated tolerance.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hisstools_library_amd as H
+    assert H.load().hcv_device_count() > 0, "no GPU visible: the HIP path cannot run (and there is no fallback)"
+    return H
+
+
+def _load(c, irs):
+    for (i, o), h in irs.items():
+        assert c.set(i, o, h, True) == 0
+
+
+@pytest.mark.parametrize("nin,nout,ndev,tol", [(4, 4, 2, 1e-6), (5, 3, 2, 1e-6), (8, 1, 2, 1e-5), (8, 1, 4, 1e-5), (6, 2, 4, 1e-5)])
+def test_sharded_object_matches_unsharded_and_oracle(H, oracle, nin, nout, ndev, tol):
+    L, S = 30000, 60000
+    irs = {(i, o): oracle.synth_ir(i, o, L - 700 * i - 90 * o) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    one = H.Convolver(nin, nout, 0)
+    many = H.Convolver(nin, nout, 0, devices=[0] * ndev)
+    assert many.num_shards() == ndev and one.num_shards() == 1
+    ref = oracle.Convolver(nin, nout, 0)
+    ref.setResetOffset(0)
+    for c in (one, many, ref):
+        _load(c, irs)
+    blocks = [512, 8192, 100, 3000, 16384]
+    y1, yn, yr = one.run(xs, nout, blocks), many.run(xs, nout, blocks), ref.run(xs, nout, 2048)
+    for o in range(nout):
+        assert rel_err(yn[o], y1[o]) < tol, (o, rel_err(yn[o], y1[o]))
+        assert rel_err(yn[o], yr[o]) < 1e-5
+    # a live IR swap and a reset of single pairs go to the shard that owns them
+    new_ir = oracle.synth_ir(9, 9, L)
+    for c in (one, many):
+        assert c.set(nin - 1, nout - 1, new_ir, True) == 0
+        assert c.reset(0, 0) == 0
+    y1b, ynb = one.run(xs[:, :20000], nout, 1000), many.run(xs[:, :20000], nout, 1000)
+    for o in range(nout):
+        assert rel_err(ynb[o], y1b[o]) < max(tol, 2e-6)
+    # channel-range errors are those of the unsharded object (Convolver.cpp:88-134)
+    assert many.set(nin, 0, new_ir, True) == one.set(nin, 0, new_ir, True) == 1
+    assert many.set(0, nout, new_ir, True) == one.set(0, nout, new_ir, True) == 2
+    assert many.resize(0, nout, 100) == one.resize(0, nout, 100) == 1
+    assert many.reset(nin + 3, 0) == one.reset(nin + 3, 0) == 1
+
+
+def test_sharded_object_fewer_active_channels(H, oracle):
+    """process with fewer inputs / outputs than constructed (Convolver.cpp:148-153): the active ranges are split per shard."""
+    nin, nout, L, S = 6, 4, 9000, 20000
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    one, many = H.Convolver(nin, nout, 0), H.Convolver(nin, nout, 0, devices=[0, 0])
+    for c in (one, many):
+        _load(c, irs)
+    for (ai, ao) in ((6, 4), (3, 3), (5, 1)):
+        for c in (one, many):
+            c.reset()
+        ya, yb = np.zeros((nout, S), np.float32), np.zeros((nout, S), np.float32)
+        one.process(xs, ya, ai, ao)
+        many.process(xs, yb, ai, ao)
+        for o in range(ao):
+            assert rel_err(yb[o], ya[o]) < 2e-6, (ai, ao, o)
+        assert not yb[ao:].any()
+
+
+def test_sharded_object_parallel_mode_and_double_api(H, oracle):
+    n, L, S = 5, 7000, 30000
+    irs = [oracle.synth_ir(o, o, L - 100 * o) for o in range(n)]
+    xs = np.stack([oracle.synth_audio(o, S) for o in range(n)])
+    one, many = H.Convolver(n, None, 1), H.Convolver(n, None, 1, devices=[0, 0, 0])
+    for c in (one, many):
+        for o in range(n):
+            assert c.set(o, o, irs[o], True) == 0
+        assert c.set(0, 1, irs[0], True) == 1                     # parallel mode: only in == out (Convolver.cpp:92,106,118)
+    y1, yn = one.run(xs, n, 4096), many.run(xs, n, 4096)
+    for o in range(n):
+        assert rel_err(yn[o], y1[o]) < 1e-6
+    for c in (one, many):
+        c.reset()
+    d1, dn = one.run(xs.astype(np.float64), n, 777), many.run(xs.astype(np.float64), n, 777)
+    for o in range(n):
+        assert rel_err(dn[o], d1[o]) < 1e-6
+
+
+@pytest.mark.parametrize("nin,nout,ndev", [(4, 4, 2), (8, 1, 4), (8, 2, 4)])
+def test_sharded_object_device_pointers(H, oracle, nin, nout, ndev):
+    """HBM-resident audio: every shard reads / writes the caller's buffers in place; the input-split layouts sum the row
+    group's partial blocks with one kernel on the group's root stream (events across the shards' streams)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    L, S, B = 40000, 10 * 8192, 8192
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    xs_h = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    xs = torch.from_numpy(xs_h).to(dev)
+    one = H.Convolver(nin, nout, 0, maxBlock=B)
+    many = H.Convolver(nin, nout, 0, maxBlock=B, devices=[0] * ndev)
+    for c in (one, many):
+        _load(c, irs)
+    ys = [torch.zeros((nout, S), device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for c, y in zip((one, many), ys):
+        for pos in range(0, S, B):                                     # asynchronous calls back to back, then one wait
+            c.process_dev(xs.data_ptr() + 4 * pos, S, y.data_ptr() + 4 * pos, S, nin, nout, B)
+        c.synchronize()
+    a, b = ys[0].cpu().numpy(), ys[1].cpu().numpy()
+    for o in range(nout):
+        assert rel_err(b[o], a[o]) < (1e-6 if nout >= ndev else 1e-5), (o, rel_err(b[o], a[o]))
+    # ragged and small calls (the deferred tail) through the sharded object, against the oracle
+    ref = oracle.Convolver(nin, nout, 0)
+    ref.setResetOffset(0)
+    _load(ref, irs)
+    yr = ref.run(xs_h[:, :30000], nout, 2048)
+    many.reset()
+    y2 = torch.zeros((nout, 30000), device=dev)
+    pos = 0
+    for n in [128] * 100 + [1000, 333, 8192, 5000, 2675]:
+        many.process_dev(xs.data_ptr() + 4 * pos, S, y2.data_ptr() + 4 * pos, 30000, nin, nout, n, sync=True)
+        pos += n
+    assert pos == 30000
+    for o in range(nout):
+        assert rel_err(y2[o].cpu().numpy(), yr[o]) < 1e-5
+
+
+def test_env_devices_shards_the_reference_shaped_constructor(H):
+    """HCV_DEVICES makes hcv_convolver_create (what HISSTools::Convolver calls) build the sharded object."""
+    code = ("import hisstools_library_amd as H, numpy as np\n"
+            "c = H.Convolver(3, 4, 0)\n"
+            "assert c.set(2, 3, np.ones(100, np.float32), True) == 0\n"
+            "y = c.run(np.ones((3, 600), np.float32), 4, 256)\n"
+            "print(c.num_shards(), float(y[3, -1]), float(y[0, -1]))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, HCV_DEVICES="0,0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    shards, last, silent = out.stdout.split()[-3:]
+    assert int(shards) == 2 and abs(float(last) - 100.0) < 1e-3 and float(silent) == 0.0
+
+
+def test_rccl_allreduce_entry_point_world_of_one(H, oracle):
+    """hcv_convolver_comm_init + process_f32_dev_allreduce with a one-rank communicator: RCCL is found and bound at run time, the
+    collective is enqueued on the engine's stream behind the block, and (one rank) leaves the block as process_dev wrote it."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    nin, nout, L, S, B = 3, 2, 20000, 4 * 8192, 8192
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    xs = torch.from_numpy(np.stack([oracle.synth_audio(i, S) for i in range(nin)])).to(dev)
+    a, b = H.Convolver(nin, nout, 0, maxBlock=B), H.Convolver(nin, nout, 0, maxBlock=B)
+    for c in (a, b):
+        _load(c, irs)
+    b.comm_init(H.rccl_unique_id(), 0, 1)
+    ya, yb = torch.zeros((nout, S), device=dev), torch.zeros((nout, S), device=dev)
+    torch.cuda.synchronize()
+    for pos in range(0, S, B):
+        a.process_dev(xs.data_ptr() + 4 * pos, S, ya.data_ptr() + 4 * pos, S, nin, nout, B)
+        b.process_dev_allreduce(xs.data_ptr() + 4 * pos, S, yb.data_ptr() + 4 * pos, S, nin, nout, B)      # strided rows: grouped calls
+    a.synchronize()
+    b.synchronize()
+    assert torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize("workload,flags", [("c3", ["--scaling", "strong"]), ("m16", ["--scaling", "strong"]), ("m16", ["--sharding", "grid"])])
+def test_bench_two_ranks_share_the_gpu(workload, flags):
+    """bench.py --gpus 2 with two ranks on the one GPU (gloo for the rendezvous and, on the reduce path, for the all-reduce):
+    strong scaling splits the workload's own matrix — c3 (8 -> 1) by inputs with one all-reduce per step, m16 by output rows."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "4", "--warmup", "1", "--batched-block", "0",
+           "--extended-ratio", "0", "--realtime-block", "0", "--no-cpu-baseline"] + flags
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["finite_output"]
+    if "strong" in flags:
+        assert d["scaling"] == "strong"
+        nin, nout = {"c3": (8, 1), "m16": (16, 16)}[workload]
+        assert f"({nin}x{nout} over 2 GPU)" in d["config"]["workload"]

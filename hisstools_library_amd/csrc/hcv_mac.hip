@@ -27,9 +27,11 @@
 
 #include "hcv_kernels.h"
 #include "hcv_fft_device.h"
+#include "hcv_mac_params.h"
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef HCV_MAC_UNROLL
 #define HCV_MAC_UNROLL 1
@@ -37,22 +39,6 @@
 
 namespace hcv
 {
-
-struct MacParams
-{
-    const float4 *X;        // [nin][R][M/2] float4
-    const float4 *H;        // [nout][nin_alloc][Pcap][M/2] float4
-    float4 *Y;              // [ksplit][T][nout][M/2] float4
-    const long long *hv;    // [nout][nin_alloc]
-    long long h_first;
-    int M2;                 // float4 per spectrum = M/2
-    int R, P, Pcap, T;
-    int nin, nin_alloc, nout;
-    int diag;               // parallel mode: output o reads input o only (nin == 1 logically)
-    int ksplit, kper;       // k-slices over blockIdx.x and their length
-    int binblocks;
-    long long ks_stride4;   // float4 stride between k-slices of Y
-};
 
 __device__ __forceinline__ void cmac2(float4 &acc, const float4 &x, const float4 &h)
 {
@@ -251,7 +237,10 @@ void mac_plan(const MacShape &s, MacPlan &pl)
 
     const long long K = (long long) (s.diag ? 1 : s.nin) * s.P;
     const long long base = (long long) pl.binblocks * pl.outtiles * pl.tz;
-    const long long tgt = s.target_blocks > 0 ? s.target_blocks : target_blocks;
+    // workgroups to aim for = what is resident at once: 3 per CU for the single-hop tile (132 registers), 2 per CU for the
+    // large hop tiles (4 x 4 and 4 x 8 need 176 - 233): a third, half-empty round of workgroups cost the 4 x 8 tile 8 %
+    static const bool blocks_forced = std::getenv("HCV_MAC_BLOCKS") != nullptr;
+    const long long tgt = s.target_blocks > 0 ? s.target_blocks : (!blocks_forced && pl.ot == 4 && pl.tt >= 4) ? 512 : target_blocks;
     long long want = std::max<long long>(1, tgt / base);
     long long maxsplit = K / 8;                                 // keep every k-slice at least 8 long
     if (maxsplit < 1) maxsplit = 1;
@@ -271,6 +260,10 @@ static hipError_t launch_mac_tile(const MacParams &a, const MacPlan &pl, bool ch
 {
     dim3 grid(pl.binblocks * pl.ksplit, pl.outtiles, pl.tz);
     dim3 block(pl.bx, pl.by);
+    // HCV_MAC_PREFETCH (default 1): steady-state launches of the hop-tiled shapes take the software-pipelined kernel
+    // (hcv_mac_tiled.hip, its own translation unit: it is compiled without the SLP vectoriser)
+    static const bool prefetch = !(std::getenv("HCV_MAC_PREFETCH") && std::atoi(std::getenv("HCV_MAC_PREFETCH")) == 0);
+    if (TT > 1 && !check && prefetch) return launch_mac_tiled(OT, TT, pl.nt != 0, grid, block, a, st);
     if (check)
         hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, true, false>), grid, block, 0, st, a);
     else if (pl.nt)

@@ -179,6 +179,7 @@ namespace hcv
         std::atomic<uint64_t> mLockContended { 0 }, mLockWaitNsMax { 0 }, mBlocksMuted { 0 };
         hipEvent_t mEvSerial = nullptr;     // end of a run of serial blocks (see enqueue_chunk)
         bool mPrevSerial = false;           // the previous block ran serially on the main stream
+        bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         uint64_t mBlockCount = 0;
 

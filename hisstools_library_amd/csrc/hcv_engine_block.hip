@@ -134,9 +134,18 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     hipStream_t sM = sS, sF = sS, sI = sS;
     st.Y = st.Yq[q];
 
-    HCV_TRY(wt(sF, mEvInput[q]));
-    if (blk.gate && tail_gate >= 2) HCV_TRY(wt(sF, blk.gate));
-    HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
+    if (direct_in)
+    {
+        // the transforms read the caller's block themselves and file it in the history ring: no scatter, no wait for one
+        HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, sF));
+        HCV_TRY(rec(mEvInput[q], sF));          // "the block's input is in the ring"
+    }
+    else
+    {
+        HCV_TRY(wt(sF, mEvInput[q]));
+        if (blk.gate && tail_gate >= 2) HCV_TRY(wt(sF, blk.gate));
+        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
+    }
     if (blk.gate && tail_gate == 1) HCV_TRY(wt(sM, blk.gate));
     if (head_here)
     {
@@ -264,9 +273,14 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         }
         else
         {
-            HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, sI));
-            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
-                                             &st.big, sI));
+            // the split-K partial sums are added up by the inverse transform's loads when that is cheaper than a launch of its
+            // own: few slices, many transforms (each workgroup then reads ksplit spectra instead of one — c4: 6 x 64 KB per
+            // output, 14 us less per step; c5's 24 slices over 16 outputs keep the reduction kernel, which uses the whole chip)
+            static const int fold_max = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
+            const bool fold = pl.ksplit > 1 && pl.ksplit <= fold_max && !is_big_fft(st.log2n) && (long long) T * nout_act >= 16;
+            if (!fold) HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, sI));
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold ? pl.ksplit : 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1,
+                                             st.tw, &st.big, sI));
         }
     }
     HCV_TRY(rec(st.done[q], sI));
@@ -372,12 +386,31 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     }
     // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
     static const bool pipeline = !(std::getenv("HCV_PIPELINE") && std::atoi(std::getenv("HCV_PIPELINE")) == 0);
-    if (!pipeline) HCV_TRY(wt(sIn, mEvEmit[q ^ 1]));
-    // the block two back read the history this scatter may overwrite
-    for (Stage *st : mStages) HCV_TRY(wt(sIn, st->done[q]));
-    HCV_TRY(wt(sIn, mEvTd[q]));
-    HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
-    HCV_TRY(rec(mEvInput[q], sIn));
+    // Direct input (HCV_DIRECT_IN, default on): when exactly one FFT stage runs this block and the block is made of whole,
+    // aligned hops of it — whole-hop mode, or a single-stage engine — that stage's forward transforms read the caller's block
+    // in their first pass and file it in the history ring themselves (launch_rfft_frames_direct).  The scatter launch goes,
+    // and with it the cross-stream hand-over in front of the stage's first kernel: on a 64x64 engine with 2 s IRs the next
+    // block's scatter used to sit in a hardware queue behind the tail MAC (there are fewer queues than streams), 25-40 us of
+    // every 0.58 ms step.  Needs 8-byte aligned input rows (the first pass loads sample pairs).
+    static const bool allow_direct = !(std::getenv("HCV_DIRECT_IN") && std::atoi(std::getenv("HCV_DIRECT_IN")) == 0);
+    const bool one_stage_aligned = mStages.size() == 1 && !td_any && mStages[0]->P > 0 && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
+    const bool direct_in = allow_direct && rows_in > 0 && (whole_hops ? mStages[last]->P + 1 > 0 : one_stage_aligned) && !mStages.empty() &&
+                           !is_big_fft(mStages[last]->log2n) && ((uintptr_t) din % 8) == 0 && (in_stride % 2) == 0 && !leaving && !entering;
+    blk.direct_in = direct_in;
+    if (!direct_in)
+    {
+        if (!pipeline) HCV_TRY(wt(sIn, mEvEmit[q ^ 1]));
+        // the block two back read the history this scatter may overwrite
+        for (Stage *st : mStages) HCV_TRY(wt(sIn, st->done[q]));
+        HCV_TRY(wt(sIn, mEvTd[q]));
+        // after direct-input blocks the ring was last written on the last stage's stream: later hops must land behind those
+        if (mPrevDirect && !serial) HCV_TRY(wt(sIn, mStages[last]->done[q ^ 1]));
+        HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
+        HCV_TRY(rec(mEvInput[q], sIn));
+    }
+    else if (!pipeline)
+        HCV_TRY(wt(serial ? mStream : mStages[last]->stream, mEvEmit[q ^ 1]));
+    mPrevDirect = direct_in;
 
     if (td)
     {

@@ -134,6 +134,7 @@ struct Engine::Block
     size_t last = 0;                    // index of the last stage
     bool td_any = false, td_check = false, whole_hops = false, entering = false, leaving = false, head_fft = false, td = false;
     bool serial = false, full_matrix = false;
+    bool direct_in = false;             // the (only) running stage's forward FFTs read the caller's block themselves: no scatter launch
     int tail_gate = 0;
     hipEvent_t gate = nullptr;          // the tail's spectral_mac of this block has finished (tail gate)
     hipStream_t main = nullptr, sIn = nullptr, sTd = nullptr;
@@ -155,9 +156,10 @@ struct Engine::Block
                full_matrix = (b).full_matrix;                                                                                                      \
     const int tail_gate = (b).tail_gate;                                                                                                           \
     const hipStream_t sTd = (b).sTd;                                                                                                               \
+    const bool direct_in = (b).direct_in;                                                                                                          \
     auto rec = [&](hipEvent_t e_, hipStream_t s_) { return (b).rec(e_, s_); };                                                                     \
     auto wt = [&](hipStream_t s_, hipEvent_t e_) { return (b).wt(s_, e_); };                                                                       \
     (void) n0; (void) hmask; (void) nin_act; (void) nout_act; (void) rows_in; (void) B; (void) q; (void) last; (void) whole_hops; (void) entering; \
-    (void) leaving; (void) head_fft; (void) serial; (void) full_matrix; (void) tail_gate; (void) sTd; (void) rec; (void) wt
+    (void) leaving; (void) head_fft; (void) serial; (void) full_matrix; (void) tail_gate; (void) sTd; (void) rec; (void) wt; (void) direct_in
 
 } // namespace hcv

@@ -22,6 +22,10 @@ namespace hcv
 
     hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin,
                                   float2 *X, int R, const float2 *tw, const BigFFTWork *big, hipStream_t st);
+    // hop-aligned block: the new hops come straight from the caller's block `in` (first sample = position n0) and are filed in
+    // the history ring by the transform itself (no scatter launch); LDS sizes only
+    hipError_t launch_rfft_frames_direct(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride,
+                                         long long n0, long long h_first, int T, int nin, float2 *X, int R, const float2 *tw, hipStream_t st);
     hipError_t launch_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork *big, hipStream_t st);
     hipError_t launch_rfft_rows(int log2n, const float *src, long long src_stride, long long in_len, int batch, float2 *dst, const float2 *tw,
                                 const BigFFTWork *big, hipStream_t st);

@@ -82,6 +82,56 @@ struct FrameLoad
     }
 };
 
+// The same frame with its NEW hop taken straight from the caller's block (the framing copy of PartitionedConvolve.cpp:304-307
+// fused into the transform's first-pass loads): positions >= n0 are read from in[pos - n0], older ones from the history ring.
+// The transform of hop h also files hop h's samples (the second half of its frame) in the ring, for the next block's first
+// frame and for every reader of the history — so a hop-aligned block needs no separate scatter launch, and the stage's stream
+// no cross-stream wait before its first kernel.
+struct DirectFrameLoad
+{
+    static constexpr bool is_lds = false;
+    float *hist_row;
+    const float *in_row;
+    long long base, mask, n0, own;      // own = first position of the frame's own (second) half
+    bool live;
+    __device__ __forceinline__ float2 operator()(int k) const
+    {
+        if (!live) return make_float2(0.f, 0.f);
+        const long long pos = base + 2LL * k;
+        if (pos < n0) return *reinterpret_cast<const float2 *>(hist_row + (pos & mask));
+        const float2 v = *reinterpret_cast<const float2 *>(in_row + (pos - n0));
+        if (pos >= own) *reinterpret_cast<float2 *>(hist_row + (pos & mask)) = v;
+        return v;
+    }
+};
+
+template <int LOG2M>
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rfft_frames_direct_kernel(float *__restrict__ hist, long long hist_stride, long long hist_mask,
+                                                                 const float *__restrict__ in, long long in_stride, long long n0,
+                                                                 long long h_first, int T, int nin, float2 *__restrict__ X, int R,
+                                                                 const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
+    const int q = blockIdx.x * G + g;
+    const bool live = q < T * nin;
+    const int t = live ? q / nin : 0, i = live ? q % nin : 0;
+    const long long h = h_first + t;
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
+
+    const DirectFrameLoad ld = { hist + (long long) i * hist_stride, in + (long long) i * in_stride, (h - 1) * (long long) M, hist_mask, n0,
+                                 h * (long long) M, live };
+    LdsFFT<LOG2M, TG>::run(ld, LdsIO<float2>{ s }, s, tid, tw);
+    if (live)
+    {
+        int slot = (int) (h % R);
+        real_post_store<LOG2M, TG>(s, tid, tw, X + ((long long) i * R + slot) * M);
+    }
+}
+
 template <int LOG2M>
 __global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rfft_frames_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
                                                           long long h_first, int T, int nin, float2 *__restrict__ X, int R,
@@ -618,6 +668,23 @@ hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_strid
         if (e != hipSuccess) return e;
         int grid = (T * nin + Gm::G - 1) / Gm::G;
         hipLaunchKernelGGL(rfft_frames_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, hist, hist_stride, hist_mask, h_first, T, nin, X, R, tw);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_rfft_frames_direct(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0,
+                                     long long h_first, int T, int nin, float2 *X, int R, const float2 *tw, hipStream_t st)
+{
+    if (T <= 0 || nin <= 0) return hipSuccess;
+    if (is_big_fft(log2n)) return hipErrorInvalidValue;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rfft_frames_direct_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (T * nin + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rfft_frames_direct_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, hist, hist_stride, hist_mask, in, in_stride, n0, h_first, T,
+                           nin, X, R, tw);
     });
     return hipGetLastError();
 }

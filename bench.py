@@ -564,12 +564,15 @@ def main():
         Hh = tail["fft_size"] // 2
         launches = max(1, tail["mac_launches"])
         hops_per_launch = tail["mac_hops"] / launches
-        alg_bytes = algorithmic_bytes_per_hop(Hh, tail["partitions"], nin, nout) * hops_per_launch
+        # (a whole-hop launch reduces over the stage's own partitions plus the one holding the IR in front of its segment —
+        #  the work of every shorter stage and the head, SURVEY 8d's sum over stages — : launch_partitions)
+        parts = max(tail["partitions"], tail.get("launch_partitions", 0))
+        alg_bytes = algorithmic_bytes_per_hop(Hh, parts, nin, nout) * hops_per_launch
         avg_ms = tail["mac_ms"] / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # a working set that fits the 256 MiB Infinity Cache is not an HBM test (SURVEY §8d on c2): the step is bound by its
         # launches, and the "achieved" rate is cache bandwidth
-        live_bytes = 8 * Hh * tail["partitions"] * nin * nout
+        live_bytes = 8 * Hh * parts * nin * nout
         bound = "hbm" if live_bytes > (256 << 20) else "launch"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
@@ -586,9 +589,10 @@ def main():
             ot = max(1, bst["out_tile"])
             # one launch covers `bh` hops: H is read once per hop tile (ceil(bh / hop_tile) times), X once per output tile
             tiles = -(-int(round(bh)) // max(1, bst["hop_tile"]))
-            b_bytes = (8 * Hh * bst["partitions"] * nin * nout * tiles + 8 * Hh * (bst["partitions"] + bh) * nin * (-(-nout // ot))
+            bp = max(bst["partitions"], bst.get("launch_partitions", 0))
+            b_bytes = (8 * Hh * bp * nin * nout * tiles + 8 * Hh * (bp + bh) * nin * (-(-nout // ot))
                        + 8 * Hh * nout * bh * max(1, bst["ksplit"]))
-            b_flops = 8.0 * Hh * bst["partitions"] * nin * nout * bh
+            b_flops = 8.0 * Hh * bp * nin * nout * bh
             b_ms = bst["mac_ms"] / bl
             roofline_batched = {
                 "kernel": f"spectral_mac (tail stage, hop tile {bst['hop_tile']}, out tile {ot}, ksplit {bst['ksplit']}), {batched['block']}-sample calls",
@@ -636,7 +640,7 @@ def main():
             },
             "roofline": {
                 "bound": bound,
-                "kernel": f"spectral_mac (tail stage, FFT {tail['fft_size']}, P={tail['partitions']}, ksplit={tail['ksplit']}, out_tile={tail['out_tile']})",
+                "kernel": f"spectral_mac (tail stage, FFT {tail['fft_size']}, P={parts}, ksplit={tail['ksplit']}, out_tile={tail['out_tile']})",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1192,7 +1192,7 @@ extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_
     out->out_tile = s.out_tile;
     out->mac_steady_launches = s.mac_steady_launches;
     out->hop_tile = s.hop_tile;
-    out->reserved = 0;
+    out->launch_partitions = s.launch_partitions;
     return 0;
 }
 

@@ -60,7 +60,7 @@ namespace hcv
         double mac_ms;              // summed HIP-event time of this stage's spectral_mac launches (profiling on)
         uint32_t ksplit, out_tile;
         uint64_t mac_steady_launches;   // of mac_launches: the unchecked instantiation with nontemporal IR loads
-        uint32_t hop_tile;
+        uint32_t hop_tile, launch_partitions;
     };
 
     class Engine
@@ -140,7 +140,7 @@ namespace hcv
         bool enqueue_stage(Block &blk, size_t si, size_t sj);
         static MacShape mac_shape(const Stage &st, int P, int Pcap, int nin, int nin_alloc, int nout, int diag, int T, int max_ksplit);
         bool advance_background(const Block &blk, Stage &st, bool boundary);
-        bool catch_up_stage(const Block &blk, Stage &st, long long h_first);
+        bool catch_up_stage(const Block &blk, Stage &st, long long h_first, bool rebuild_spectra);
         size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }
         void collect_events();
         // exact per-pair restart (hcv_ghost.hip): ghost spectra of the input before the restart, the pair's pending output retired
@@ -197,8 +197,7 @@ namespace hcv
         bool mHeadFFT = false;              // the head may take the FFT path (taps fit one hop of the first stage)
         // Whole-hop mode: for calls made of whole, aligned hops of the LAST stage everything in front of that stage's segment
         // (head + shorter stages) is one extra zero-latency partition of it
-        float2 *mTailHeadSpec = nullptr;    // [nout][nin_alloc][Mlast] spectrum of IR[0 : Mlast)
-        float2 *mTailHeadYq[2] = { nullptr, nullptr };   // [TmaxLast][nout][Mlast], by block parity
+        // (the spectrum of IR[0 : Mlast) lives in the lead slot of the last stage's spectra, Stage::lead)
         bool mTailHead = false;             // the layout allows it (contiguous zero-latency ladder)
         bool mTailHeadPrev = false;         // the previous block ran in whole-hop mode
         float *mTaps = nullptr;

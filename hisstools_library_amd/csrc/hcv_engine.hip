@@ -212,10 +212,35 @@ bool Engine::init(const EngineCfg &cfg)
     mRetired.assign(pairs, 0);
     mGhostOf.assign(pairs, nullptr);
 
+    // Whole-hop mode (see enqueue_chunk): needs the zero-latency ladder — head at [0, a), every shorter stage continuing
+    // where the previous coverage ends, the last stage starting exactly one of its hops in.  The last stage then keeps the
+    // spectrum of IR[0 : its hop) in a lead slot in front of every pair's partitions (Stage::lead).
+    if (mCfg.stages.size() >= 2 || (mCfg.has_td && !mCfg.stages.empty()))
+    {
+        static const bool allow = !(std::getenv("HCV_TAIL_HEAD") && std::atoi(std::getenv("HCV_TAIL_HEAD")) == 0);
+        uint64_t end = 0;
+        bool ok = allow;
+        if (mCfg.has_td)
+        {
+            ok = ok && mCfg.td_offset == 0 && mCfg.td_length > 0;
+            end = mCfg.td_length;
+        }
+        for (size_t k = 0; ok && k + 1 < mCfg.stages.size(); k++)
+        {
+            const StageCfg &sc = mCfg.stages[k];
+            ok = sc.offset == end && sc.length > 0;
+            end = sc.offset + sc.length;
+        }
+        const StageCfg &tl = mCfg.stages.back();
+        ok = ok && tl.offset == end && tl.offset == tl.fft_size / 2 && !is_big_fft(ilog2(tl.fft_size));
+        mTailHead = ok;
+    }
+
     for (const StageCfg &sc : mCfg.stages)
     {
         Stage *st = new Stage();
         st->cfg = sc;
+        st->lead = (mTailHead && &sc == &mCfg.stages.back()) ? 1 : 0;
         st->log2n = ilog2(sc.fft_size);
         st->N = sc.fft_size;
         st->M = sc.fft_size / 2;
@@ -225,6 +250,7 @@ bool Engine::init(const EngineCfg &cfg)
         if (!st->tw) return false;
         if (!alloc_stage(*st)) return false;
     }
+    if (mTailHead) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages.back()->M));
     // Head through the FFT: the head's taps (<= one hop of the first FFT stage, MonoConvolve.cpp:235-240) form one extra,
     // zero-latency partition of that stage, whose input spectra exist anyway.  Used for hop-aligned blocks of larger
     // matrices, where the direct-form FIR would cost more than all FFT-stage MACs together; ragged blocks and small
@@ -243,36 +269,6 @@ bool Engine::init(const EngineCfg &cfg)
             HCV_TRY(hipMalloc(&mStageHead, sizeof(float2) * s0.M));
         }
     }
-    // Whole-hop mode (see enqueue_chunk): needs the zero-latency ladder — head at [0, a), every shorter stage continuing
-    // where the previous coverage ends, the last stage starting exactly one of its hops in
-    if (mStages.size() >= 2 || (mCfg.has_td && !mStages.empty()))
-    {
-        static const bool allow = !(std::getenv("HCV_TAIL_HEAD") && std::atoi(std::getenv("HCV_TAIL_HEAD")) == 0);
-        uint64_t end = 0;
-        bool ok = allow;
-        if (mCfg.has_td)
-        {
-            ok = ok && mCfg.td_offset == 0 && mCfg.td_length > 0;
-            end = mCfg.td_length;
-        }
-        for (size_t k = 0; ok && k + 1 < mStages.size(); k++)
-        {
-            const StageCfg &sc = mStages[k]->cfg;
-            ok = sc.offset == end && sc.length > 0;
-            end = sc.offset + sc.length;
-        }
-        const Stage &tl = *mStages.back();
-        ok = ok && tl.cfg.offset == end && tl.cfg.offset == tl.M && !is_big_fft(tl.log2n);
-        if (ok)
-        {
-            mTailHead = true;
-            HCV_TRY(hipMalloc(&mTailHeadSpec, sizeof(float2) * pairs * tl.M));
-            HCV_TRY(hipMemset(mTailHeadSpec, 0, sizeof(float2) * pairs * tl.M));
-            HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * tl.M));
-            // (room for kTailHeadSplit k-slices: with one partition the MAC has only the input axis to split)
-            for (int k = 0; k < 2; k++) HCV_TRY(hipMalloc(&mTailHeadYq[k], sizeof(float2) * (size_t) tl.Tmax * kTailHeadSplit * mCfg.nout * tl.M));
-        }
-    }
     HCV_TRY(hipDeviceSynchronize());
     return true;
 }
@@ -284,7 +280,7 @@ bool Engine::alloc_stage(Stage &st)
     st.Pcap = (uint32_t) std::max<uint64_t>(1, (cap + st.M - 1) / st.M);
     st.Tmax = mMaxBlock / st.M + 1;
     st.R = st.Pcap + 2 * st.Tmax;      // FFT of block k+1 may write while the MAC of block k still reads
-    const size_t hs_elems = pairs * st.Pcap * st.M;
+    const size_t hs_elems = pairs * st.hstride();
     const size_t x_elems = (size_t) mCfg.nin * st.R * st.M;
     // room for split-K partials: up to 64 slices for short spectra, fewer as the bin axis alone fills the chip
     const uint32_t split_cap = std::max<uint32_t>(1, std::min<uint32_t>(64, 2048u / std::max<uint32_t>(1, st.M / 512)));
@@ -404,9 +400,6 @@ Engine::~Engine()
     if (mIrBuf) (void) hipFree(mIrBuf);
     if (mTaps) (void) hipFree(mTaps);
     if (mHeadSpec) (void) hipFree(mHeadSpec);
-    if (mTailHeadSpec) (void) hipFree(mTailHeadSpec);
-    for (int k = 0; k < 2; k++)
-        if (mTailHeadYq[k]) (void) hipFree(mTailHeadYq[k]);
     for (int k = 0; k < 2; k++)
         if (mHeadYq[k]) (void) hipFree(mHeadYq[k]);
     if (mTdValid) (void) hipFree(mTdValid);
@@ -504,7 +497,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     const uint32_t newR = newP + 2 * st.Tmax;
     float2 *nHs = nullptr, *nX = nullptr;
-    const size_t hs_bytes = sizeof(float2) * pairs * newP * st.M;
+    const size_t hs_bytes = sizeof(float2) * pairs * (newP + st.lead) * st.M;
     const size_t x_bytes = sizeof(float2) * (size_t) mCfg.nin * newR * st.M;
     if (hipMalloc(&nHs, hs_bytes) != hipSuccess)
     {
@@ -528,10 +521,10 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     }
     bool ok = hipStreamWaitEvent(mCtlStream, mEvSnap, 0) == hipSuccess && hipStreamWaitEvent(mCtlStream, mEvSwapDone, 0) == hipSuccess;
     ok = ok && hipMemsetAsync(nHs, 0, hs_bytes, mCtlStream) == hipSuccess && hipMemsetAsync(nX, 0, x_bytes, mCtlStream) == hipSuccess;
-    if (ok && live_P > 0)
+    if (ok && (live_P > 0 || st.lead))
     {
         // (the spectra are only ever written by control calls, which mSetMutex serialises with this one)
-        ok = launch_regrow_spectra(st.Hs, nHs, (long long) pairs, (int) st.Pcap, (int) newP, (int) st.M, mCtlStream) == hipSuccess;
+        ok = launch_regrow_spectra(st.Hs, nHs, (long long) pairs, st.hparts(), (int) (newP + st.lead), (int) st.M, mCtlStream) == hipSuccess;
         const int live = (int) std::min<long long>(live_P, h_snap);
         if (ok && live > 0)
             ok = launch_regrow_ring(st.X, nX, (int) mCfg.nin, (int) st.R, (int) newR, (int) st.M, h_snap - 1, live, mCtlStream) == hipSuccess;
@@ -692,7 +685,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
         {
             Stage &st = *mStages[si];
             const uint32_t newP = std::min(newPs[si], st.Pcap), oldP = st.pact[pair];
-            float2 *dst = st.Hs + pair * (size_t) st.Pcap * st.M;
+            float2 *dst = st.Ht() + pair * st.hstride();
             if (newP) HCV_TRY(hipMemcpyAsync(dst, st.stage_spec, sizeof(float2) * (size_t) newP * st.M, hipMemcpyDeviceToDevice, mStream));
             if (oldP > newP) HCV_TRY(hipMemsetAsync(dst + (size_t) newP * st.M, 0, sizeof(float2) * (size_t) (oldP - newP) * st.M, mStream));
             st.live_parts += newP;
@@ -712,7 +705,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             any = any || taps;
         }
         if (mTailHead)
-            HCV_TRY(hipMemcpyAsync(mTailHeadSpec + pair * (size_t) mStages.back()->M, mStageTailHead, sizeof(float2) * mStages.back()->M,
+            HCV_TRY(hipMemcpyAsync(mStages.back()->Hs + pair * mStages.back()->hstride(), mStageTailHead, sizeof(float2) * mStages.back()->M,
                                    hipMemcpyDeviceToDevice, mStream));
         mLoaded[pair] = any ? 1 : 0;
         mPending[pair] = 1;                                                         // set() always ends in reset()
@@ -805,6 +798,7 @@ bool Engine::stage_stats(size_t s, StageStats *out)
     out->out_tile = st.last_ot;
     out->mac_steady_launches = st.steady_launches;
     out->hop_tile = st.last_tt;
+    out->launch_partitions = st.last_parts;
     return true;
 }
 

@@ -29,7 +29,7 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
             HCV_TRY(hipMemsetAsync(slot, 0, sizeof(float2) * slot_elems, sS));
             continue;
         }
-        const MacShape sb = mac_shape(st, /* P */ b - a, /* Pcap */ (int) st.Pcap,
+        const MacShape sb = mac_shape(st, /* P */ b - a, /* Pcap */ st.hparts(),
                                       /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) mCfg.nout, /* diag */ mCfg.diag ? 1 : 0,
                                       /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) mCfg.nout * st.M)));       // (full matrix only)
         MacPlan pb;
@@ -37,7 +37,7 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
         const long long hop = st.pre_hop - 1 - a;
         const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
         float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
-        if (!mac(st, sb, pb, st.Hs + (size_t) (1 + a) * st.M, scratch, hop, bcheck, sS)) return false;
+        if (!mac(st, sb, pb, st.Ht() + (size_t) (1 + a) * st.M, scratch, hop, bcheck, sS)) return false;
         HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS));
         HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, sS));
         HCV_TRY(hipEventRecord(st.bg_done, sS));
@@ -46,25 +46,28 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
     return true;
 }
 
-// Back from whole-hop mode: this stage was not run for a while.  Rebuild the input spectra its partitions reach back to from the
-// history ring, and compute the hop just before this block — its result is emitted during the first hop of the block (every
-// stage has one hop of latency).
-bool Engine::catch_up_stage(const Block &blk, Stage &st, long long h_first)
+// Back from whole-hop mode: this stage's own machinery was not run for a while.  Rebuild the input spectra its partitions reach
+// back to from the history ring (not for the last stage: it kept its ring up to date), and compute the hop just before this
+// block — its result is emitted during the first hop of the block (every stage has one hop of latency).
+bool Engine::catch_up_stage(const Block &blk, Stage &st, long long h_first, bool rebuild_spectra)
 {
     HCV_BLOCK_LOCALS(blk);
     const hipStream_t sS = blk.stage_stream(st.stream);
     HCV_TRY(wt(sS, mEvInput[q]));
     st.Y = st.Yq[q];
-    const long long h_lo = std::max<long long>(0, h_first - (long long) st.P);
-    HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_lo, (int) (h_first - h_lo), (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sS));
-    const MacShape sc = mac_shape(st, /* P */ (int) std::min<long long>(st.P, h_first), /* Pcap */ (int) st.Pcap,
+    if (rebuild_spectra)
+    {
+        const long long h_lo = std::max<long long>(0, h_first - (long long) st.P);
+        HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_lo, (int) (h_first - h_lo), (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sS));
+    }
+    const MacShape sc = mac_shape(st, /* P */ (int) std::min<long long>(st.P, h_first), /* Pcap */ st.hparts(),
                                   /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
                                   /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M)));
     MacPlan pc;
     mac_plan(sc, pc);
     const bool ccheck = (h_first - 1 - st.max_hv) < (long long) st.P - 1;
     const long long c_elems = (long long) nout_act * st.M;
-    if (!mac(st, sc, pc, st.Hs, st.Y, h_first - 1, ccheck, sS)) return false;
+    if (!mac(st, sc, pc, st.Ht(), st.Y, h_first - 1, ccheck, sS)) return false;
     HCV_TRY(launch_reduce_partials(st.Y, pc.ksplit, c_elems, c_elems, sS));
     HCV_TRY(wt(sS, mEvEmit[q]));        // emit(k-2) has cleared the timeline span reused now
     HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, c_elems, h_first - 1, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
@@ -82,34 +85,31 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     HCV_BLOCK_LOCALS(blk);
     Stage &st = *mStages[si];
     const hipStream_t sS = serial ? mStream : st.stream;
-    if (whole_hops && si != last)
+    if (whole_hops && entering)
     {
-        if (entering)
-        {
-            // this stage's pending results duplicate what the last stage now computes: drop them (after the emit that
-            // may still be reading them) together with any plan of a deferred accumulation
-            HCV_TRY(wt(sS, mEvEmit[q ^ 1]));
-            HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, sS));
-            HCV_TRY(rec(st.done[q], sS));
-            HCV_TRY(wt(mStream, st.done[q]));
-            st.pre_hop = -1;
-        }
-        return true;
+        // what this stage has pending duplicates what the last stage's whole-hop convolution now computes (for the last stage
+        // itself: its own partitions' result for the block's first hop): drop it — after the emit that may still be reading
+        // it — together with any plan of a deferred accumulation
+        HCV_TRY(wt(sS, mEvEmit[q ^ 1]));
+        HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, sS));
+        HCV_TRY(rec(st.done[q], sS));
+        HCV_TRY(wt(mStream, st.done[q]));
+        st.pre_hop = -1;
     }
+    if (whole_hops && si != last) return true;
     blk.src.timeline[blk.src.count] = st.timeline;              // the ring may still hold hops of earlier calls
     blk.src.stride[blk.src.count] = st.tl_len;
     blk.src.mask[blk.src.count] = st.tl_len - 1;
     blk.src.count++;
     const bool tail_head_here = whole_hops && si == last;
     int head_ksplit = 1;
-    bool head_on_side = false;
-    const bool head_here = (head_fft && si == 0) || tail_head_here;
-    const float2 *head_spec = tail_head_here ? mTailHeadSpec : mHeadSpec;
-    float2 *head_y = tail_head_here ? mTailHeadYq[q] : mHeadYq[q];
-    if (!st.P && !head_here) return true;
+    const bool head_here = head_fft && si == 0;
+    const float2 *head_spec = mHeadSpec;
+    float2 *head_y = mHeadYq[q];
+    if (!st.P && !head_here && !tail_head_here) return true;
     const long long h_first = n0 / st.M;
     const int T = (int) ((n0 + B) / st.M - h_first);
-    if (leaving && si != last && st.P && h_first >= 1 && !catch_up_stage(blk, st, h_first)) return false;
+    if (leaving && st.P && h_first >= 1 && !catch_up_stage(blk, st, h_first, /* rebuild_spectra */ si != last)) return false;
     // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
     static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
     static const int slices_env = std::getenv("HCV_BG_SLICES") ? std::atoi(std::getenv("HCV_BG_SLICES")) : kBgSlices;
@@ -147,50 +147,6 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         HCV_TRY(launch_rfft_frames(st.log2n, mHist, mHistLen, hmask, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, &st.big, sF));
     }
     if (blk.gate && tail_gate == 1) HCV_TRY(wt(sM, blk.gate));
-    if (head_here)
-    {
-        // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
-        const MacShape hs = mac_shape(st, /* P */ 1, /* Pcap */ 1,
-                                      /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
-                                      /* T */ T, /* max_ksplit */ tail_head_here ? kTailHeadSplit : 1);
-        MacPlan hp;
-        mac_plan(hs, hp);
-        static const bool head_side = !(std::getenv("HCV_HEAD_STREAM") && std::atoi(std::getenv("HCV_HEAD_STREAM")) == 0);
-        if (tail_head_here && head_side && !serial)
-        {
-            // whole-hop mode: the head partition's MAC, reduction and inverse run on the otherwise idle head stream, beside
-            // the tail MAC, so the last stage's own stream carries only FFT -> MAC -> reduce -> inverse (c4 853 -> 917,
-            // c5 66.4 -> 68.2, c3 72 -> 84 Msamples/s).  Both inverses add into the same timeline; the adds are atomic.
-            HCV_TRY(rec(st.mac_done[q], sM));                       // = "forward FFTs of this block are done"
-            HCV_TRY(wt(sTd, st.mac_done[q]));
-            HCV_TRY(wt(sTd, mEvEmit[q]));
-            const long long he = (long long) T * nout_act * st.M;
-            if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sTd)) return false;
-            HCV_TRY(launch_reduce_partials(head_y, hp.ksplit, he, he, sTd));
-            HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
-                                             &st.big, sTd));
-            HCV_TRY(rec(mEvTd[q], sTd));
-            head_on_side = true;
-        }
-        else
-        {
-            if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sM)) return false;
-            head_ksplit = hp.ksplit;
-        }
-    }
-
-    // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
-    // reference, PartitionedConvolve.cpp:285,322,373): right after a reset the reduction is short
-    const long long p_live = std::min<long long>(st.P, h_first + T);
-    MacShape sh = mac_shape(st, /* P */ (int) p_live, /* Pcap */ (int) st.Pcap,
-                            /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
-                            /* T */ T, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M)));
-    const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
-    const long long y_elems = (long long) T * nout_act * st.M;
-
-    const bool defer = allow_defer && st.P > 0 && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && nout_act == mCfg.nout &&
-                       nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
-    const bool have_pre = defer && st.pre_hop == h_first;
 
     EventPair *ev = nullptr;
     auto begin_event = [&]() -> bool
@@ -211,6 +167,69 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         return true;
     };
 
+    if (tail_head_here)
+    {
+        // Whole-hop mode: ONE zero-latency uniform convolution over the lead slot (IR[0 : M)) and the stage's own partitions,
+        //     Y(h) = sum_{p' = 0 .. P} X[h - p'] H'[p'],
+        // one spectral_mac launch, one inverse, emitted in the hop's own slot.  Nothing is parked for the next block (the
+        // stage's own partitions, which normally run one hop ahead of their emission, are simply computed in the block that
+        // emits them), so the head chain, its stream hand-overs and the second inverse of the earlier scheme are gone.
+        const int Pw = (int) st.P + 1;
+        const long long p_live = std::min<long long>(Pw, h_first + T);
+        MacShape sw = mac_shape(st, /* P */ (int) p_live, /* Pcap */ st.hparts(),
+                                /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
+                                /* T */ T, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M)));
+        const bool wcheck = (h_first - st.max_hv) < (long long) Pw - 1;
+        MacPlan pw;
+        mac_plan(sw, pw);
+        if (!begin_event()) return false;
+        if (!mac(st, sw, pw, st.Hs, st.Y, h_first, wcheck, sM)) return false;
+        if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
+        st.launches++;
+        st.hops += (uint64_t) T;
+        st.last_ksplit = (uint32_t) pw.ksplit;
+        st.last_ot = (uint32_t) pw.ot;
+        st.last_tt = (uint32_t) pw.tt;
+        st.last_parts = (uint32_t) p_live;
+        if (!wcheck && pw.nt) st.steady_launches++;
+        const long long w_elems = (long long) T * nout_act * st.M;
+        static const int fold_max_w = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
+        const bool fold_w = pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial);
+        if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sI));
+        HCV_TRY(wt(sI, mEvEmit[q]));             // emit(k-2) has cleared the timeline span reused now
+        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold_w ? pw.ksplit : 1, w_elems, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len,
+                                         st.tl_len - 1, st.tw, &st.big, sI));       // h_first - 1: emitted with NO latency (hop h at h*M)
+        HCV_TRY(rec(st.done[q], sI));
+        HCV_TRY(wt(mStream, st.done[q]));
+        st.pre_hop = -1;
+        return true;
+    }
+
+    if (head_here)
+    {
+        // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
+        const MacShape hs = mac_shape(st, /* P */ 1, /* Pcap */ 1,
+                                      /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
+                                      /* T */ T, /* max_ksplit */ 1);
+        MacPlan hp;
+        mac_plan(hs, hp);
+        if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sM)) return false;
+        head_ksplit = hp.ksplit;
+    }
+
+    // hops since the last global reset bound how many partitions can have input yet (mValidPartitions in the
+    // reference, PartitionedConvolve.cpp:285,322,373): right after a reset the reduction is short
+    const long long p_live = std::min<long long>(st.P, h_first + T);
+    MacShape sh = mac_shape(st, /* P */ (int) p_live, /* Pcap */ st.hparts(),
+                            /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
+                            /* T */ T, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M)));
+    const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
+    const long long y_elems = (long long) T * nout_act * st.M;
+
+    const bool defer = allow_defer && st.P > 0 && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && nout_act == mCfg.nout &&
+                       nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+    const bool have_pre = defer && st.pre_hop == h_first;
+
     // ---- MAC phase (stream sM)
     MacPlan pl;
     pl.ksplit = 1;
@@ -226,19 +245,20 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             s0.P = 1;
             s0.max_ksplit = 1;
             mac_plan(s0, pl);
-            if (!mac(st, s0, pl, st.Hs, st.Y, h_first, check, sM)) return false;
+            if (!mac(st, s0, pl, st.Ht(), st.Y, h_first, check, sM)) return false;
         }
         else
         {
             mac_plan(sh, pl);
             if (!begin_event()) return false;
-            if (!mac(st, sh, pl, st.Hs, st.Y, h_first, check, sM)) return false;
+            if (!mac(st, sh, pl, st.Ht(), st.Y, h_first, check, sM)) return false;
             if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
             st.launches++;
             st.hops += (uint64_t) T;
             st.last_ksplit = (uint32_t) pl.ksplit;
             st.last_ot = (uint32_t) pl.ot;
             st.last_tt = (uint32_t) pl.tt;
+            st.last_parts = (uint32_t) p_live;
             if (!check && pl.nt) st.steady_launches++;
         }
     }
@@ -250,7 +270,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
 
     // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
     HCV_TRY(wt(sI, mEvEmit[q]));             // emit(k-2) has cleared the timeline span reused now
-    if (head_here && !head_on_side)
+    if (head_here)
     {
         HCV_TRY(launch_reduce_partials(head_y, head_ksplit, (long long) T * nout_act * st.M, (long long) T * nout_act * st.M, sI));
         HCV_TRY(launch_rifft_overlap_add(st.log2n, head_y, 1, 0, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1, st.tw,
@@ -458,7 +478,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     for (size_t sj = 0; sj < mStages.size(); sj++)
         if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj)) return false;
 
-    if (td || whole_hops) HCV_TRY(wt(mStream, mEvTd[q]));
+    if (td) HCV_TRY(wt(mStream, mEvTd[q]));
     HCV_TRY(wt(mStream, mEvInput[q]));           // a block with no live stage still orders after its scatter
     HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
     HCV_TRY(rec(mEvEmit[q], mStream));

@@ -46,7 +46,6 @@ struct DeviceGuard
 };
 
 constexpr int kBgSlices = 16;
-constexpr int kTailHeadSplit = 8;
 
 // HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
 // per stage and its pending output is not withdrawn) — for A/B comparison only
@@ -63,7 +62,15 @@ struct Engine::Stage
     int log2n = 0;
     uint32_t N = 0, M = 0;
     uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
+    // Hs = [pairs][lead + Pcap][M].  lead = 1 on the last stage of a whole-hop capable layout: slot 0 of every pair then holds
+    // the spectrum of IR[0 : M) — everything in front of the stage's own segment — so that in whole-hop mode the stage runs ONE
+    // zero-latency uniform convolution over lead + P partitions (Y(h) = sum_p' X[h - p'] H'[p']); the stage's own partitions
+    // follow at Ht()
+    uint32_t lead = 0;
     float2 *Hs = nullptr, *X = nullptr;
+    size_t hstride() const { return (size_t) (Pcap + lead) * M; }       // float2 between two pairs' spectra
+    int hparts() const { return (int) (Pcap + lead); }                  // the same in partitions (MacShape::Pcap is this stride)
+    float2 *Ht() const { return Hs + (size_t) lead * M; }               // the stage's own partitions of pair 0
     float2 *Y = nullptr;                // scratch of the current block = Yq[block parity]
     float2 *Yq[2] = { nullptr, nullptr };   // split-K partials, double-buffered so MAC(k+1) can run while block k is inverted
     size_t y_elems = 0;
@@ -102,7 +109,7 @@ struct Engine::Stage
     // stats
     uint64_t launches = 0, hops = 0;
     double ms = 0.0;
-    uint32_t last_ksplit = 0, last_ot = 0, last_tt = 0;
+    uint32_t last_ksplit = 0, last_ot = 0, last_tt = 0, last_parts = 0;
     uint64_t steady_launches = 0;
 };
 

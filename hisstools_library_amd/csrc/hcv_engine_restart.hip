@@ -221,20 +221,20 @@ bool Engine::retire_pair(size_t pair)
         const long long h_r = mN / st.M;
         const long long P = std::min<long long>(st.pact[pair], h_r);
         if (P <= 0) continue;
-        if (mTailHeadPrev && si + 1 != mStages.size()) continue;       // whole-hop mode: the shorter stages have nothing pending
+        if (mTailHeadPrev) continue;        // whole-hop mode: every block delivers all it computes, no stage has anything pending
         if (!mRetireTmp)
         {
             uint32_t nmax = 0;
             for (Stage *sp : mStages) nmax = std::max(nmax, sp->N);
             HCV_TRY(hipMalloc(&mRetireTmp, sizeof(float) * nmax));
         }
-        MacShape sh = mac_shape(st, /* P */ (int) P, /* Pcap */ (int) st.Pcap,
+        MacShape sh = mac_shape(st, /* P */ (int) P, /* Pcap */ st.hparts(),
                                 /* nin */ 1, /* nin_alloc */ 1, /* nout */ 1, /* diag */ 0,
                                 /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / st.M));
         MacPlan pl;
         mac_plan(sh, pl);
         float2 *Y = st.Yq[0];
-        const float2 *H = st.Hs + pair * (size_t) st.Pcap * st.M;
+        const float2 *H = st.Ht() + pair * st.hstride();
         HCV_TRY(launch_spectral_mac(sh, pl, st.X + (size_t) row * st.R * st.M, H, Y, st.hv + pair, h_r - 1, true, mStream));
         for (int e = 0; e < st.gh_count; e++)
             if (st.gh_pair[e] == pair)
@@ -258,13 +258,13 @@ bool Engine::retire_pair(size_t pair)
         const int per = (st.bg_parts + st.bg_slices - 1) / st.bg_slices;
         const long long covered = std::min<long long>(std::min(st.bg_parts, st.bg_launched * per), (long long) st.pact[pair] - 1);
         if (covered <= 0) continue;
-        MacShape sh = mac_shape(st, /* P */ (int) covered, /* Pcap */ (int) st.Pcap,
+        MacShape sh = mac_shape(st, /* P */ (int) covered, /* Pcap */ st.hparts(),
                                 /* nin */ 1, /* nin_alloc */ 1, /* nout */ 1, /* diag */ 0,
                                 /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / st.M));
         MacPlan pl;
         mac_plan(sh, pl);
         float2 *Y = st.Yq[0];
-        const float2 *H = st.Hs + pair * (size_t) st.Pcap * st.M + st.M;          // partitions 1 .. covered at hop pre_hop - 1
+        const float2 *H = st.Ht() + pair * st.hstride() + st.M;                  // partitions 1 .. covered at hop pre_hop - 1
         HCV_TRY(launch_spectral_mac(sh, pl, st.X + (size_t) row * st.R * st.M, H, Y, st.hv + pair, st.pre_hop - 1, true, mStream));
         for (int e = 0; e < st.gh_count; e++)
             if (st.gh_pair[e] == pair)

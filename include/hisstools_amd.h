@@ -193,9 +193,10 @@ typedef struct hcv_stage_stats
     double mac_ms;
     uint32_t ksplit, out_tile;
     /* launches of the steady-state instantiation (every partition of every pair live: no per-pair bounds, IR spectra
-     * streamed with nontemporal loads) among mac_launches, and the hop tile of the last launch */
+     * streamed with nontemporal loads) among mac_launches; the hop tile of the last launch; the partitions it reduced over
+     * (whole-hop blocks: the stage's own + the one holding the IR in front of its segment) */
     uint64_t mac_steady_launches;
-    uint32_t hop_tile, reserved;
+    uint32_t hop_tile, launch_partitions;
 } hcv_stage_stats;
 HCV_API void hcv_convolver_set_profiling(hcv_convolver *h, int on);
 HCV_API int hcv_convolver_num_stages(hcv_convolver *h);

@@ -198,7 +198,8 @@ namespace hcv
         // Whole-hop mode: for calls made of whole, aligned hops of the LAST stage everything in front of that stage's segment
         // (head + shorter stages) is one extra zero-latency partition of it
         // (the spectrum of IR[0 : Mlast) lives in the lead slot of the last stage's spectra, Stage::lead)
-        bool mTailHead = false;             // the layout allows it (contiguous zero-latency ladder)
+        bool mTailHead = false;             // the layout allows whole-hop blocks (contiguous zero-latency ladder, or a lone FFT stage)
+        bool mLeadSlot = false;             // ... of the first kind: the last stage carries the lead slot (Stage::lead)
         bool mTailHeadPrev = false;         // the previous block ran in whole-hop mode
         float *mTaps = nullptr;
         long long *mTdValid = nullptr;

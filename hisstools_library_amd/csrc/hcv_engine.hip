@@ -233,14 +233,21 @@ bool Engine::init(const EngineCfg &cfg)
         }
         const StageCfg &tl = mCfg.stages.back();
         ok = ok && tl.offset == end && tl.offset == tl.fft_size / 2 && !is_big_fft(ilog2(tl.fft_size));
-        mTailHead = ok;
+        mTailHead = mLeadSlot = ok;
+    }
+    else if (mCfg.stages.size() == 1 && !mCfg.has_td && !is_big_fft(ilog2(mCfg.stages[0].fft_size)))
+    {
+        // a lone FFT stage (a PartitionedConvolve): the same block structure without a lead slot — hop-aligned blocks compute
+        // exactly the hops they emit (the partitions' one hop of latency is taken by evaluating hop h - 1 in block h)
+        static const bool allow = !(std::getenv("HCV_TAIL_HEAD") && std::atoi(std::getenv("HCV_TAIL_HEAD")) == 0);
+        mTailHead = allow;
     }
 
     for (const StageCfg &sc : mCfg.stages)
     {
         Stage *st = new Stage();
         st->cfg = sc;
-        st->lead = (mTailHead && &sc == &mCfg.stages.back()) ? 1 : 0;
+        st->lead = (mLeadSlot && &sc == &mCfg.stages.back()) ? 1 : 0;
         st->log2n = ilog2(sc.fft_size);
         st->N = sc.fft_size;
         st->M = sc.fft_size / 2;
@@ -250,7 +257,7 @@ bool Engine::init(const EngineCfg &cfg)
         if (!st->tw) return false;
         if (!alloc_stage(*st)) return false;
     }
-    if (mTailHead) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages.back()->M));
+    if (mLeadSlot) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages.back()->M));
     // Head through the FFT: the head's taps (<= one hop of the first FFT stage, MonoConvolve.cpp:235-240) form one extra,
     // zero-latency partition of that stage, whose input spectra exist anyway.  Used for hop-aligned blocks of larger
     // matrices, where the direct-form FIR would cost more than all FFT-stage MACs together; ragged blocks and small
@@ -665,7 +672,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             HCV_TRY(launch_rfft_ir(s0.log2n, taps ? dsrc + mCfg.td_offset : mHist, (long long) taps, 1, mStageHead, s0.tw, &s0.big_ctl, mCtlStream));
         }
     }
-    if (mTailHead)
+    if (mLeadSlot)
     {
         Stage &tl = *mStages.back();
         const uint64_t first = std::min<uint64_t>(len, tl.M);
@@ -704,7 +711,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             mTdLpad = ((mx + 15) / 16) * 16;
             any = any || taps;
         }
-        if (mTailHead)
+        if (mLeadSlot)
             HCV_TRY(hipMemcpyAsync(mStages.back()->Hs + pair * mStages.back()->hstride(), mStageTailHead, sizeof(float2) * mStages.back()->M,
                                    hipMemcpyDeviceToDevice, mStream));
         mLoaded[pair] = any ? 1 : 0;

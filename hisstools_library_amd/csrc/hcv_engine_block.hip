@@ -174,16 +174,23 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         // one spectral_mac launch, one inverse, emitted in the hop's own slot.  Nothing is parked for the next block (the
         // stage's own partitions, which normally run one hop ahead of their emission, are simply computed in the block that
         // emits them), so the head chain, its stream hand-overs and the second inverse of the earlier scheme are gone.
-        const int Pw = (int) st.P + 1;
-        const long long p_live = std::min<long long>(Pw, h_first + T);
+        // (a lone stage has no lead slot: its partitions' one hop of latency is taken by evaluating hops h - 1 .. in block h)
+        const int Pw = (int) (st.P + st.lead);
+        const long long h_mac = h_first - (long long) (1 - st.lead);
+        const long long p_live = std::max<long long>(0, std::min<long long>(Pw, h_mac + T));
+        // (HCV_SERIAL_KSPLIT = n caps a small, serial engine at n slices, which the inverse then adds up itself — one launch
+        // less; measured on the 8 -> 1 workload it loses: the MAC wants its 30 slices, 10.6 -> 20 us at 8.  Off by default.)
+        static const int serial_ksplit = std::getenv("HCV_SERIAL_KSPLIT") ? std::atoi(std::getenv("HCV_SERIAL_KSPLIT")) : 0;
+        size_t ks_cap = std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M));
+        if (serial && serial_ksplit > 0) ks_cap = std::min<size_t>(ks_cap, (size_t) serial_ksplit);
         MacShape sw = mac_shape(st, /* P */ (int) p_live, /* Pcap */ st.hparts(),
                                 /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
-                                /* T */ T, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M)));
-        const bool wcheck = (h_first - st.max_hv) < (long long) Pw - 1;
+                                /* T */ T, /* max_ksplit */ (int) ks_cap);
+        const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
         MacPlan pw;
         mac_plan(sw, pw);
         if (!begin_event()) return false;
-        if (!mac(st, sw, pw, st.Hs, st.Y, h_first, wcheck, sM)) return false;
+        if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM)) return false;
         if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
         st.launches++;
         st.hops += (uint64_t) T;
@@ -196,9 +203,18 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         static const int fold_max_w = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
         const bool fold_w = pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial);
         if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sI));
-        HCV_TRY(wt(sI, mEvEmit[q]));             // emit(k-2) has cleared the timeline span reused now
-        HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold_w ? pw.ksplit : 1, w_elems, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len,
-                                         st.tl_len - 1, st.tw, &st.big, sI));       // h_first - 1: emitted with NO latency (hop h at h*M)
+        if (blk.direct_out)
+        {
+            // the inverse delivers the block itself; "emit" of this block = the end of this launch
+            HCV_TRY(launch_rifft_emit(st.log2n, st.Y, fold_w ? pw.ksplit : 1, w_elems, T, (int) nout_act, blk.dout, blk.out_stride, st.tw, sI));
+            HCV_TRY(rec(mEvEmit[q], sI));
+        }
+        else
+        {
+            HCV_TRY(wt(sI, mEvEmit[q]));         // emit(k-2) has cleared the timeline span reused now
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold_w ? pw.ksplit : 1, w_elems, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len,
+                                             st.tl_len - 1, st.tw, &st.big, sI));   // h_first - 1: emitted with NO latency (hop h at h*M)
+        }
         HCV_TRY(rec(st.done[q], sI));
         HCV_TRY(wt(mStream, st.done[q]));
         st.pre_hop = -1;
@@ -413,10 +429,14 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // block's scatter used to sit in a hardware queue behind the tail MAC (there are fewer queues than streams), 25-40 us of
     // every 0.58 ms step.  Needs 8-byte aligned input rows (the first pass loads sample pairs).
     static const bool allow_direct = !(std::getenv("HCV_DIRECT_IN") && std::atoi(std::getenv("HCV_DIRECT_IN")) == 0);
-    const bool one_stage_aligned = mStages.size() == 1 && !td_any && mStages[0]->P > 0 && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
-    const bool direct_in = allow_direct && rows_in > 0 && (whole_hops ? mStages[last]->P + 1 > 0 : one_stage_aligned) && !mStages.empty() &&
-                           !is_big_fft(mStages[last]->log2n) && ((uintptr_t) din % 8) == 0 && (in_stride % 2) == 0 && !leaving && !entering;
+    const bool direct_in = allow_direct && rows_in > 0 && whole_hops && !is_big_fft(mStages[last]->log2n) && ((uintptr_t) din % 8) == 0 &&
+                           (in_stride % 2) == 0 && !entering;
     blk.direct_in = direct_in;
+    // Direct output (HCV_DIRECT_OUT, default on): a whole-hop block past the mode's first has empty timelines and one
+    // zero-latency transform per output and hop, so the inverse's last pass writes the caller's block (launch_rifft_emit) and the
+    // emit launch — with its wait for the stage's stream — goes too.  Needs 8-byte aligned output rows.
+    static const bool allow_direct_out = !(std::getenv("HCV_DIRECT_OUT") && std::atoi(std::getenv("HCV_DIRECT_OUT")) == 0);
+    blk.direct_out = allow_direct_out && whole_hops && !entering && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
     if (!direct_in)
     {
         if (!pipeline) HCV_TRY(wt(sIn, mEvEmit[q ^ 1]));
@@ -478,10 +498,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     for (size_t sj = 0; sj < mStages.size(); sj++)
         if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj)) return false;
 
-    if (td) HCV_TRY(wt(mStream, mEvTd[q]));
-    HCV_TRY(wt(mStream, mEvInput[q]));           // a block with no live stage still orders after its scatter
-    HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
-    HCV_TRY(rec(mEvEmit[q], mStream));
+    if (!blk.direct_out)
+    {
+        if (td) HCV_TRY(wt(mStream, mEvTd[q]));
+        HCV_TRY(wt(mStream, mEvInput[q]));       // a block with no live stage still orders after its scatter
+        HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
+        HCV_TRY(rec(mEvEmit[q], mStream));
+    }
     mN += B;
     mBlockCount++;
     mLastNin = rows_in;

@@ -34,6 +34,11 @@ namespace hcv
                                         float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, const BigFFTWork *big,
                                         hipStream_t st);
 
+    // the inverse of a whole-hop block: the valid half of every transform goes straight to the caller's block (row o, hop t at
+    // out[o * out_stride + t * M]); no timeline, no emit.  LDS sizes only; rows 8-byte aligned.
+    hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
+                                 const float2 *tw, hipStream_t st);
+
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,
                                int R, const float2 *tw, const BigFFTWork &w, hipStream_t st);
     hipError_t big_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork &w, hipStream_t st);

@@ -335,6 +335,43 @@ __global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_overlap_add_
     LdsFFT<LOG2M, TG>::run(PreLoad<LOG2M>{ s, tw }, st, s, tid, tw);
 }
 
+// The same inverse delivering its valid half straight into the caller's output block (scaleStore + the framing copy of
+// PartitionedConvolve.cpp:232-241,359-360 in the transform's last pass): for blocks whose samples come from ONE zero-latency
+// transform per output and hop — whole-hop mode — so that neither a timeline ring nor an emit launch stands between the
+// inverse and the caller.
+struct EmitStore
+{
+    static constexpr bool is_lds = false;
+    float *row;             // out[o] + t * M - M: sample e of the frame lands at row[e]
+    float scale;
+    int first;
+    bool live;
+    __device__ __forceinline__ void operator()(int k, float2 v) const
+    {
+        if (!live || k < first) return;
+        *reinterpret_cast<float2 *>(row + 2LL * k) = make_float2(v.y * scale, v.x * scale);
+    }
+};
+
+template <int LOG2M>
+__global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_emit_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, int T, int nout,
+                                                         float *__restrict__ out, long long out_stride, const float2 *__restrict__ tw)
+{
+    using Gm = FFTGeom<LOG2M>;
+    constexpr int M = Gm::M, TG = Gm::TG, G = Gm::G;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+    const int g = wave_uniform_group<TG>(), tid = threadIdx.x % TG;
+    const int q = blockIdx.x * G + g;
+    const bool live = q < T * nout;
+    const int t = live ? q / nout : 0, o = live ? q % nout : 0;
+    LdsBuf<float2> s = { lds + g * lds_padded(M) };
+
+    stage_spectrum<LOG2M, TG>(s, tid, Y + ((long long) t * nout + o) * M, ksplit, ks_stride, live);
+    const EmitStore st = { out + (long long) o * out_stride + (long long) t * M - M, 1.f / (float) (8 * M), M / 2, live };
+    LdsFFT<LOG2M, TG>::run(PreLoad<LOG2M>{ s, tw }, st, s, tid, tw);
+}
+
 struct SwapStore
 {
     static constexpr bool is_lds = false;
@@ -749,6 +786,22 @@ hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long
         int grid = (T * nout + Gm::G - 1) / Gm::G;
         hipLaunchKernelGGL(rifft_overlap_add_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, Y, ksplit, ks_stride, h_first, T, nout, timeline,
                            tl_stride, tl_mask, tw);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
+                             const float2 *tw, hipStream_t st)
+{
+    if (T <= 0 || nout <= 0) return hipSuccess;
+    if (is_big_fft(log2n)) return hipErrorInvalidValue;
+    HCV_FFT_DISPATCH(log2n - 1, {
+        using Gm = FFTGeom<L>;
+        size_t lds = fft_lds_bytes<L>();
+        hipError_t e = allow_lds(rifft_emit_kernel<L>, lds);
+        if (e != hipSuccess) return e;
+        int grid = (T * nout + Gm::G - 1) / Gm::G;
+        hipLaunchKernelGGL(rifft_emit_kernel<L>, dim3(grid), dim3(Gm::THREADS), lds, st, Y, ksplit, ks_stride, T, nout, out, out_stride, tw);
     });
     return hipGetLastError();
 }

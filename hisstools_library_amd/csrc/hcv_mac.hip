@@ -247,7 +247,7 @@ void mac_plan(const MacShape &s, MacPlan &pl)
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;
     if (s.max_ksplit > 0 && want > s.max_ksplit) want = s.max_ksplit;
-    pl.kper = (int) ((K + want - 1) / want);
+    pl.kper = (int) std::max<long long>(1, (K + want - 1) / want);      // (K = 0: no live input, the launch writes zeros)
     pl.ksplit = (int) ((K + pl.kper - 1) / pl.kper);
     if (pl.ksplit < 1) pl.ksplit = 1;
     // every H element is read exactly once per launch when a single hop tile covers the call: stream it

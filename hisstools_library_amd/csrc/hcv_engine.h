@@ -179,6 +179,11 @@ namespace hcv
         std::atomic<uint64_t> mLockContended { 0 }, mLockWaitNsMax { 0 }, mBlocksMuted { 0 };
         hipEvent_t mEvSerial = nullptr;     // end of a run of serial blocks (see enqueue_chunk)
         bool mPrevSerial = false;           // the previous block ran serially on the main stream
+        // small engines, whole-hop blocks: the forward transforms of block k+1 run on a second stream beside block k's
+        // multiply-accumulate and inverse (the block's time is a chain of latency-bound launches; asynchronous callers overlap them)
+        hipStream_t mPipeStream = nullptr;
+        hipEvent_t mEvPipe[2] = { nullptr, nullptr };
+        bool mPrevPipe2 = false;
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         uint64_t mBlockCount = 0;

@@ -180,6 +180,8 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipEventCreateWithFlags(&mEvSwapDone, hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvSnap, hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvHostDone, hipEventDisableTiming));
+    HCV_TRY(hipStreamCreateWithFlags(&mPipeStream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipe[k], hipEventDisableTiming));
     HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
 
     // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
@@ -377,6 +379,7 @@ Engine::~Engine()
 {
     DeviceGuard dg(mDevice);
     if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);
+    if (mPipeStream) (void) hipStreamSynchronize(mPipeStream);
     if (mInStream) (void) hipStreamSynchronize(mInStream);
     if (mTdStream) (void) hipStreamSynchronize(mTdStream);
     for (Stage *st : mStages)
@@ -425,6 +428,9 @@ Engine::~Engine()
     if (mStageHead) (void) hipFree(mStageHead);
     if (mStageTailHead) (void) hipFree(mStageTailHead);
     if (mCtlStream) (void) hipStreamDestroy(mCtlStream);
+    if (mPipeStream) (void) hipStreamDestroy(mPipeStream);
+    for (int k = 0; k < 2; k++)
+        if (mEvPipe[k]) (void) hipEventDestroy(mEvPipe[k]);
     if (mGhostHist) (void) hipFree(mGhostHist);
     if (mRetireTmp) (void) hipFree(mRetireTmp);
     if (mGhostPin) (void) hipHostFree(mGhostPin);

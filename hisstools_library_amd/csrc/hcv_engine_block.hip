@@ -134,7 +134,18 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     hipStream_t sM = sS, sF = sS, sI = sS;
     st.Y = st.Yq[q];
 
-    if (direct_in)
+    if (direct_in && blk.pipe2)
+    {
+        // two-stream pipeline of a small engine: this block's transforms run on the pipe stream, beside the previous block's
+        // multiply-accumulate and inverse on the main stream.  The ring slots they write are read by the MAC of the block two
+        // back at the latest (R = Pcap + 2 Tmax), hence the wait for that block's end; the MAC of this block waits for them.
+        HCV_TRY(hipStreamWaitEvent(mPipeStream, st.done[q], 0));
+        HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw,
+                                          mPipeStream));
+        HCV_TRY(hipEventRecord(mEvPipe[q], mPipeStream));
+        HCV_TRY(hipStreamWaitEvent(sM, mEvPipe[q], 0));
+    }
+    else if (direct_in)
     {
         // the transforms read the caller's block themselves and file it in the history ring: no scatter, no wait for one
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, sF));
@@ -215,6 +226,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold_w ? pw.ksplit : 1, w_elems, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len,
                                              st.tl_len - 1, st.tw, &st.big, sI));   // h_first - 1: emitted with NO latency (hop h at h*M)
         }
+        if (blk.pipe2) HCV_TRY(hipEventRecord(st.done[q], sI));    // (serial blocks record no events otherwise)
         HCV_TRY(rec(st.done[q], sI));
         HCV_TRY(wt(mStream, st.done[q]));
         st.pre_hop = -1;
@@ -412,6 +424,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     mPrevSerial = serial;
     if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
     // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
+    const bool ctl_was_dirty = mCtlDirty;
     if (mCtlDirty)
     {
         HCV_TRY(rec(mEvCtl, mStream));
@@ -451,6 +464,23 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     else if (!pipeline)
         HCV_TRY(wt(serial ? mStream : mStages[last]->stream, mEvEmit[q ^ 1]));
     mPrevDirect = direct_in;
+    // HCV_PIPE2 (default OFF — measured slower): serial whole-hop blocks of small engines put their forward transforms on a second
+    // stream (see enqueue_stage).  c3's block is rfft 15.5 us -> MAC 7.3 -> reduce 5.2 -> inverse 11.3 in a row, so with the next
+    // block's transforms under the current block's MAC and inverse an asynchronous caller should pay max(15.5, 24) per block;
+    // in fact the two cross-stream hand-overs per block cost more than the overlap gives: c3 0.0459 -> 0.0497 ms per block,
+    // c2 0.0329 -> 0.0400.  Kept for the record and for a runtime with cheaper cross-queue dependencies.
+    static const bool allow_pipe2 = std::getenv("HCV_PIPE2") && std::atoi(std::getenv("HCV_PIPE2")) != 0;
+    blk.pipe2 = allow_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr;
+    if (blk.pipe2)
+    {
+        if (!mPrevPipe2 || ctl_was_dirty)
+        {
+            // the pipe stream starts behind everything the main stream holds so far (earlier blocks, control work)
+            HCV_TRY(hipEventRecord(mEvSerial, mStream));
+            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvSerial, 0));
+        }
+    }
+    mPrevPipe2 = blk.pipe2;
 
     if (td)
     {

@@ -12,6 +12,7 @@ import sys
 
 w = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/pmc_{w}"
+batched = len(sys.argv) > 3 and sys.argv[3] == "batched"       # the hop-tiled launch of 65536-sample calls instead of the single-hop one
 GiB = 1 << 30
 
 
@@ -34,7 +35,7 @@ tail = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     run = load(f"{src}/{c}/run_counter_collection.csv")
     # the steady-state tail launch: the unpredicated single-hop spectral_mac (<OT, 1, false, NT>) moving the most bytes
-    cand = {k: v for k, v in run.items() if "spectral_mac_kernel" in k[0] and ", 1, false," in k[0]}
+    cand = {k: v for k, v in run.items() if ("spectral_mac_tiled_kernel" in k[0] if batched else ("spectral_mac_kernel" in k[0] and ", 1, false," in k[0]))}
     # the head partition's MAC of whole-hop mode can share the tail's template variant and grid: the tail launches are the
     # ones near the largest value of the (name, grid) group that holds it
     key = max(cand, key=lambda k: max(cand[k]))
@@ -47,5 +48,5 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 out["hbm_read_bytes_per_launch"] = int(tail["FETCH_SIZE"] * 1024 * factors["FETCH_SIZE"])
 out["hbm_write_bytes_per_launch"] = int(tail["WRITE_SIZE"] * 1024 * factors["WRITE_SIZE"])
 out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
-json.dump(out, open(f"profiles/traffic_{w}.json", "w"), indent=1)
+json.dump(out, open(f"profiles/traffic_{w}{'_batched' if batched else ''}.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -138,6 +138,29 @@ struct LdsFFT
     __device__ static __forceinline__ void pass16(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
     {
         C u[BPT16][16];
+        // the pass twiddles come from the table in global memory (L1 / L2 hits, hundreds of cycles): issue those loads FIRST,
+        // in front of the LDS reads and the barrier, so that they are in flight while the data is fetched — behind the barrier
+        // their latency stood in line with the arithmetic in every pass of a single-transform workgroup
+        C tw6[BPT16][6];
+        if (!FIRST)
+        {
+#pragma unroll
+            for (int b = 0; b < BPT16; b++)
+            {
+                const int i = tid + b * TG;
+                if (NB16 % TG == 0 || i < NB16)
+                {
+                    const int k = i & (p - 1);
+                    const int step = k * ((2 * M) / (16 * p));
+                    tw6[b][0] = root<LOG2M>(tw, step);
+                    tw6[b][1] = root<LOG2M>(tw, 2 * step);
+                    tw6[b][2] = root<LOG2M>(tw, 3 * step);
+                    tw6[b][3] = root<LOG2M>(tw, 4 * step);
+                    tw6[b][4] = root<LOG2M>(tw, 8 * step);
+                    tw6[b][5] = root<LOG2M>(tw, 12 * step);
+                }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < BPT16; b++)
         {
@@ -162,8 +185,7 @@ struct LdsFFT
                 else
                 {
                     // pass twiddle w^r, w = exp(-2 pi i k / (16 p)) = root(k * 2M / (16 p)); r = 4a + b: w^(4a) here, w^b inside
-                    const int step = k * ((2 * M) / (16 * p));
-                    const C w4 = root<LOG2M>(tw, 4 * step), w8 = root<LOG2M>(tw, 8 * step), w12 = root<LOG2M>(tw, 12 * step);
+                    const C w4 = tw6[b][3], w8 = tw6[b][4], w12 = tw6[b][5];
 #pragma unroll
                     for (int c = 0; c < 4; c++)
                     {
@@ -171,7 +193,7 @@ struct LdsFFT
                         u[b][8 + c] = cmul(u[b][8 + c], w8);
                         u[b][12 + c] = cmul(u[b][12 + c], w12);
                     }
-                    dft16<false>(u[b], root<LOG2M>(tw, step), root<LOG2M>(tw, 2 * step), root<LOG2M>(tw, 3 * step));
+                    dft16<false>(u[b], tw6[b][0], tw6[b][1], tw6[b][2]);
                 }
 #pragma unroll
                 for (int q2 = 0; q2 < 4; q2++)
@@ -186,6 +208,19 @@ struct LdsFFT
     __device__ static __forceinline__ void pass4(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
     {
         C u[BPT4][4];
+        C tw3[BPT4][3];                                     // (table loads in front of the LDS reads and the barrier, as in pass16)
+#pragma unroll
+        for (int b = 0; b < BPT4; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB4 % TG == 0 || i < NB4)
+            {
+                const int step = (i & (p - 1)) * ((2 * M) / (4 * p));
+                tw3[b][0] = root<LOG2M>(tw, step);
+                tw3[b][1] = root<LOG2M>(tw, 2 * step);
+                tw3[b][2] = root<LOG2M>(tw, 3 * step);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < BPT4; b++)
         {
@@ -206,10 +241,9 @@ struct LdsFFT
                 const int k = i & (p - 1);
                 const int j = ((i - k) << 2) + k;
                 // twiddle exp(-2 pi i k r / (4p)) = root(k * r * (2M / 4p))
-                const int step = k * ((2 * M) / (4 * p));
-                u[b][1] = cmul(u[b][1], root<LOG2M>(tw, step));
-                u[b][2] = cmul(u[b][2], root<LOG2M>(tw, 2 * step));
-                u[b][3] = cmul(u[b][3], root<LOG2M>(tw, 3 * step));
+                u[b][1] = cmul(u[b][1], tw3[b][0]);
+                u[b][2] = cmul(u[b][2], tw3[b][1]);
+                u[b][3] = cmul(u[b][3], tw3[b][2]);
                 radix4(u[b][0], u[b][1], u[b][2], u[b][3]);
 #pragma unroll
                 for (int r = 0; r < 4; r++) dst(j + r * p, u[b][r]);
@@ -222,6 +256,13 @@ struct LdsFFT
     __device__ static __forceinline__ void pass2(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
     {
         C u[BPT2][2];
+        C tw1[BPT2];
+#pragma unroll
+        for (int b = 0; b < BPT2; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB2 % TG == 0 || i < NB2) tw1[b] = root<LOG2M>(tw, (i & (p - 1)) * ((2 * M) / (2 * p)));
+        }
 #pragma unroll
         for (int b = 0; b < BPT2; b++)
         {
@@ -242,7 +283,7 @@ struct LdsFFT
                 const int k = i & (p - 1);
                 const int j = ((i - k) << 1) + k;
                 const C u0 = u[b][0];
-                const C u1 = cmul(u[b][1], root<LOG2M>(tw, k * ((2 * M) / (2 * p))));
+                const C u1 = cmul(u[b][1], tw1[b]);
                 dst(j, C(u0.x + u1.x, u0.y + u1.y));
                 dst(j + p, C(u0.x - u1.x, u0.y - u1.y));
             }

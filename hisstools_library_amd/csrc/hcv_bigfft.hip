@@ -96,8 +96,11 @@ __global__ __launch_bounds__((FourStepTile<(1 << L1), 8>::THREADS)) void big_col
     {
         const int c = e % BIG_COLS, k1 = e / BIG_COLS;
         const int n2 = col0 + c;
-        const float2 w = root_rt(twN, 2 * n2 * k1, M);             // W_M^(n2 k1) = (N-th root)^(2 n2 k1)
-        tout[(long long) k1 * M2 + n2] = cmul(LdsBuf<float2>{ lds + c * lds_padded(M1) }[k1], w);
+        // W_M^(n2 k1) = (N-th root)^(2 n2 k1), computed rather than gathered from the N/2-entry table (one scattered 8-byte
+        // load per element of the tile bound this pass; sincospi of the exactly reduced fraction is within 2 ulp)
+        float sn, cs;
+        sincospif(-(float) ((2 * n2 * k1) & (2 * M - 1)) / (float) M, &sn, &cs);
+        tout[(long long) k1 * M2 + n2] = cmul(LdsBuf<float2>{ lds + c * lds_padded(M1) }[k1], make_float2(cs, sn));
     }
 }
 

@@ -302,6 +302,36 @@ namespace
         return (idx & M) ? C(-w.x, -w.y) : w;
     }
 
+    // The four-step twiddle W_M^(n2 k1) = exp(-2 pi i idx / 2M), idx = 2 n2 k1 (an index into the 2M-th roots).  Every element of
+    // a column tile needs its own, and as a table look-up that is one scattered 8-byte load per element from a table far larger
+    // than the L1 (512 KiB at 2^16 points): the column pass was bound by those gathers.  In float the value is computed instead
+    // (sincospi of the exactly reduced fraction: <= 2 ulp, inside the table's own rounding for the stated tolerance); double keeps
+    // the table (a double-precision sincospi costs more than the load).
+    __device__ __forceinline__ float2 fx_twiddle(const float2 *__restrict__, int idx, int M)
+    {
+        float sn, cs;
+        sincospif(-(float) (idx & (2 * M - 1)) / (float) M, &sn, &cs);      // idx / 2M turns = idx / M half-turns; both powers of two: exact
+        return make_float2(cs, sn);
+    }
+    __device__ __forceinline__ double2 fx_twiddle(const double2 *__restrict__, int idx, int M)
+    {
+        double sn, cs;
+        sincospi(-(double) (idx & (2 * M - 1)) / (double) M, &sn, &cs);
+        return make_double2(cs, sn);
+    }
+
+    // 16-byte vectors of the split arrays: 4 floats / 2 doubles of adjacent columns (or bins) per lane.  The tiles' rows are runs
+    // of 128 bytes per split array, so one-element-per-lane access issued four (two) times the memory instructions for the same
+    // bytes; the four-step passes are bound by exactly that issue rate, not by HBM (their scratch stays in the Infinity Cache).
+    template <class T> struct FxVec;
+    template <> struct FxVec<float> { typedef float4 type; static constexpr int V = 4; };
+    template <> struct FxVec<double> { typedef double2 type; static constexpr int V = 2; };
+    __device__ __forceinline__ float fx_get(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+    __device__ __forceinline__ double fx_get(const double2 &v, int j) { return j == 0 ? v.x : v.y; }
+    __device__ __forceinline__ void fx_put(float4 &v, int j, float x) { if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x; }
+    __device__ __forceinline__ void fx_put(double2 &v, int j, double x) { if (j == 0) v.x = x; else v.y = x; }
+    template <class T> __device__ __forceinline__ bool fx_aligned16(const T *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
     // M = M1 * M2, n = M2*n1 + n2, k = k1 + M1*k2.   cols: for every n2 an M1-point transform over n1, times W_M^(n2 k1)
     template <class T, int L1>
     __global__ __launch_bounds__((FxTile<(1 << L1), (int) sizeof(typename Cx<T>::type)>::THREADS)) void fx_cols_kernel(FxK<T> a0, typename Cx<T>::type *__restrict__ work, int M2, int M, long long q0,
@@ -316,20 +346,43 @@ namespace
 
         const int col0 = blockIdx.x * COLS;
         const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
-        for (int e = threadIdx.x; e < COLS * M1; e += NT)
+        typedef typename FxVec<T>::type VT;
+        constexpr int V = FxVec<T>::V;
+        if (a.load == L_SPLIT && COLS % V == 0 && fx_aligned16(static_cast<const T *>(a.sa)) && fx_aligned16(a.sb))      // (wave-uniform)
         {
-            const int c = e % COLS, n1 = e / COLS;
-            LdsBuf<C>{ lds + c * lds_padded(M1) }[n1] = fx_load<T, C>(a, 0, n1 * M2 + col0 + c, M, twN);
+            const T *re = static_cast<const T *>(a.sa), *im = a.sb;
+            for (int e = threadIdx.x; e < (COLS / V) * M1; e += NT)
+            {
+                const int cv = (e % (COLS / V)) * V, n1 = e / (COLS / V);
+                const long long idx = (long long) n1 * M2 + col0 + cv;
+                const VT vr = *reinterpret_cast<const VT *>(re + idx), vi = *reinterpret_cast<const VT *>(im + idx);
+#pragma unroll
+                for (int j = 0; j < V; j++) LdsBuf<C>{ lds + (cv + j) * lds_padded(M1) }[n1] = C(fx_get(vr, j), fx_get(vi, j));
+            }
+        }
+        else
+        {
+            for (int e = threadIdx.x; e < COLS * M1; e += NT)
+            {
+                const int c = e % COLS, n1 = e / COLS;
+                LdsBuf<C>{ lds + c * lds_padded(M1) }[n1] = fx_load<T, C>(a, 0, n1 * M2 + col0 + c, M, twN);
+            }
         }
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
         for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(LdsBuf<C>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
         C *out = work + (long long) blockIdx.y * M;
-        for (int e = threadIdx.x; e < COLS * M1; e += NT)
+        constexpr int CV = 16 / (int) sizeof(C) > 0 ? 16 / (int) sizeof(C) : 1;       // complex values per 16-byte store: 2 (float), 1 (double)
+        for (int e = threadIdx.x; e < (COLS / CV) * M1; e += NT)
         {
-            const int c = e % COLS, k1 = e / COLS;
+            const int c = (e % (COLS / CV)) * CV, k1 = e / (COLS / CV);
             const int n2 = col0 + c;
-            out[(long long) k1 * M2 + n2] = cmul(LdsBuf<C>{ lds + c * lds_padded(M1) }[k1], fx_root_rt(twN, 2 * n2 * k1, M));
+            C v[CV];
+#pragma unroll
+            for (int j = 0; j < CV; j++) v[j] = cmul(LdsBuf<C>{ lds + (c + j) * lds_padded(M1) }[k1], fx_twiddle(twN, 2 * (n2 + j) * k1, M));
+            C *d = out + (long long) k1 * M2 + n2;
+            if (CV == 2) *reinterpret_cast<float4 *>(d) = make_float4((float) v[0].x, (float) v[0].y, (float) v[CV - 1].x, (float) v[CV - 1].y);
+            else d[0] = v[0];
         }
     }
 
@@ -347,18 +400,55 @@ namespace
 
         const int row0 = blockIdx.x * ROWS;
         const C *in = work + (long long) blockIdx.y * M + (long long) row0 * M2;
-        for (int e = threadIdx.x; e < ROWS * M2; e += NT) LdsBuf<C>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = in[e];
+        constexpr int CV = 16 / (int) sizeof(C) > 0 ? 16 / (int) sizeof(C) : 1;
+        if (CV == 2)
+        {
+            // (the tile's rows are contiguous in the scratch: two complex values per 16-byte load)
+            for (int e = threadIdx.x; e < ROWS * M2 / 2; e += NT)
+            {
+                const float4 v = reinterpret_cast<const float4 *>(in)[e];
+                const int row = (2 * e) / M2, n2 = (2 * e) % M2;
+                LdsBuf<C> b = { lds + row * lds_padded(M2) };
+                b[n2] = C(v.x, v.y);
+                b[n2 + 1] = C(v.z, v.w);
+            }
+        }
+        else
+            for (int e = threadIdx.x; e < ROWS * M2; e += NT) LdsBuf<C>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = in[e];
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
         for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(LdsBuf<C>{ lds + (r0 + g) * lds_padded(M2) }, t, tw2);
         const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
-        for (int e = threadIdx.x; e < ROWS * M2; e += NT)
+        typedef typename FxVec<T>::type VT;
+        constexpr int V = FxVec<T>::V;
+        if (a0.store == S_SPLIT && ROWS % V == 0 && fx_aligned16(a.da) && fx_aligned16(a.db))                              // (wave-uniform)
         {
-            const int r = e % ROWS, k2 = e / ROWS;
-            const int k = row0 + r + M1 * k2;
-            const C v = LdsBuf<C>{ lds + r * lds_padded(M2) }[k2];
-            if (a0.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
-            else fx_store<T, C>(a, 0, k, v);
+            for (int e = threadIdx.x; e < (ROWS / V) * M2; e += NT)
+            {
+                const int r = (e % (ROWS / V)) * V, k2 = e / (ROWS / V);
+                const long long k = row0 + r + (long long) M1 * k2;
+                VT vr, vi;
+#pragma unroll
+                for (int j = 0; j < V; j++)
+                {
+                    const C v = LdsBuf<C>{ lds + (r + j) * lds_padded(M2) }[k2];
+                    fx_put(vr, j, a.swap_out ? v.y : v.x);
+                    fx_put(vi, j, a.swap_out ? v.x : v.y);
+                }
+                *reinterpret_cast<VT *>(a.da + k) = vr;
+                *reinterpret_cast<VT *>(a.db + k) = vi;
+            }
+        }
+        else
+        {
+            for (int e = threadIdx.x; e < ROWS * M2; e += NT)
+            {
+                const int r = e % ROWS, k2 = e / ROWS;
+                const int k = row0 + r + M1 * k2;
+                const C v = LdsBuf<C>{ lds + r * lds_padded(M2) }[k2];
+                if (a0.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
+                else fx_store<T, C>(a, 0, k, v);
+            }
         }
     }
 

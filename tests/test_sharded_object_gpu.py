@@ -176,7 +176,7 @@ def test_rccl_allreduce_entry_point_world_of_one(H, oracle):
     assert torch.equal(ya, yb)
 
 
-@pytest.mark.parametrize("workload,flags", [("c3", ["--scaling", "strong"]), ("m16", ["--scaling", "strong"]), ("m16", ["--sharding", "grid"])])
+@pytest.mark.parametrize("workload,flags", [("c3", ["--scaling", "strong"]), ("m16", ["--scaling", "strong"]), ("m16", ["--sharding", "grid"]), ("m16", [])])
 def test_bench_two_ranks_share_the_gpu(workload, flags):
     """bench.py --gpus 2 with two ranks on the one GPU (gloo for the rendezvous and, on the reduce path, for the all-reduce):
     strong scaling splits the workload's own matrix — c3 (8 -> 1) by inputs with one all-reduce per step, m16 by output rows."""
@@ -193,6 +193,8 @@ def test_bench_two_ranks_share_the_gpu(workload, flags):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["finite_output"]
+    if not flags:
+        assert d["scaling"] == "weak" and "(16x32 over 2 GPU)" in d["config"]["workload"]          # every rank brings its own 16 rows
     if "strong" in flags:
         assert d["scaling"] == "strong"
         nin, nout = {"c3": (8, 1), "m16": (16, 16)}[workload]

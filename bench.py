@@ -13,6 +13,7 @@ Workloads (BASELINE.json configs; default c5 = the config the metric's HBM claus
     c4    Convolver 64x64, 2 s @ 48 kHz IRs  (L = 96,000),    zero latency
     c3    NToMono-shaped 8 -> 1, 5 s IRs     (L = 240,000),   zero latency
     c2    PartitionedConvolve-shaped 1x1, 10 s IR, one 4096-point stage (cache resident, launch bound)
+    c1    MonoConvolve-shaped 1x1, 1 s IR, one 16384-point stage (the reference's own CPU-runnable case; launch bound)
     ns64  64x64, 10 s @ 48 kHz IRs (north-star target shape),  zero latency     15.7 GB of spectra
 
 Inputs are SURVEY.md §8(d)'s generator: raw mt19937 draws, u = (r >> 8) * 2^-24; IR(in, out): seed 1000*in + out + 1,
@@ -54,6 +55,7 @@ WORKLOADS = {
     "c5":   (16, 16, 5760000, 96000, (True, 256, 1024, 4096, 16384)),
     "c4":   (64, 64, 96000,   48000, (True, 256, 1024, 4096, 16384)),
     "c3":   (8,  1,  240000,  48000, (True, 256, 1024, 4096, 16384)),
+    "c1":   (1,  1,  48000,   48000, (False, 16384, 0, 0, 0)),           # BASELINE config 1: MonoConvolve(48000, false, 16384), 1 s IR (P = 6)
     "c2":   (1,  1,  480000,  48000, (False, 4096, 0, 0, 0)),
     "ns64": (64, 64, 480000,  48000, (True, 256, 1024, 4096, 16384)),
     "m16":  (16, 16, 96000,   48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 2 s IRs (not a BASELINE config)
@@ -168,9 +170,9 @@ def cpu_baseline(workload, hops=64):
     block = 512
     xs = np.stack([O.synth_audio(i, warm + S) for i in range(sub_in)])
     t_set = time.perf_counter()
-    if workload == "c2":
+    if workload in ("c2", "c1"):
         block = 2048
-        p = O.PartitionedConvolve(4096, L, 0, 0, backend=backend)
+        p = O.PartitionedConvolve(layout[1], L, 0, 0, backend=backend)
         p.setResetOffset(0)
         p.set(O.synth_ir(0, 0, L))
         t_set = time.perf_counter() - t_set

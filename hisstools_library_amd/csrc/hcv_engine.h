@@ -8,7 +8,8 @@
 // inputs and partitions in the frequency domain.
 //
 // HBM layout per FFT stage s (N = fft size, M = N/2 bins, float2 = interleaved complex bin):
-//     Hs [nout][nin_alloc][Pcap][M] float2      IR partition spectra, bin-contiguous (streamed by spectral_mac)
+//     Hs [nout][nin_alloc][lead + Pcap][M] float2   IR partition spectra, bin-contiguous (streamed by spectral_mac); lead = 1 on
+//                                              the last stage of a zero-latency ladder: slot 0 = spectrum of IR[0 : M), whole-hop mode
 //     X  [nin][R][M]               float2      ring of the last R input spectra per input (R >= Pcap + Tmax)
 //     Y  [ksplit][T][nout][M]      float2      split-K partial sums of one process call
 //     hv [nout][nin_alloc]         int64       first hop each pair may see (per-pair reset)
@@ -18,6 +19,9 @@
 //                                              emission time, emit() sums the stages' rings and clears the block
 //     taps     [nout][nin_alloc][2048] float   time-domain head taps, zero padded
 //     ghost spectra, pooled                    per restart of single pairs and stage: [inputs restarted][2][M] float2 (hcv_ghost.hip)
+//
+// Control calls stage their work outside the engine lock (set_ir: upload + FFTs into staging buffers on a control stream, then
+// a pointer-swap section; ensure_stage_capacity: new buffers filled beside the running audio thread), process() try-locks.
 //
 // Source files: hcv_engine.hip (set-up, IR loading, capacity growth), hcv_engine_block.hip (the per-block scheduler:
 // enqueue_chunk -> enqueue_stage, streams, serial blocks, deferred slices), hcv_engine_restart.hip (exact per-pair restart:

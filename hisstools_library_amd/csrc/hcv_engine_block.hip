@@ -356,6 +356,10 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
 //   head stream:  wait in[q], emit[q]                       ─ fir_head → tdout[q]                                   ─ record td[q]
 //   main stream:  wait done_s[q] for all s, td[q] ─ emit(tdout[q]) ─ record emit[q]
 //
+// Whole-hop blocks (made of whole, aligned hops of the last stage) run ONE stage on one stream instead:
+//   last stage:   rfft_frames_direct -> spectral_mac over lead + P partitions -> [reduce_partials] -> rifft_emit
+// (see enqueue_stage: no scatter, no head chain, no timeline, no emit).
+//
 // The stages only meet in emit(), so the latency-bound short stages and the FIR head hide under the HBM-bound tail;
 // and because block k+1's scatter and FFTs do not wait for block k's emit, consecutive asynchronous calls overlap.
 // Ring depths make that safe: the history ring holds three blocks + a frame (a block's readers must be done before

@@ -92,15 +92,18 @@ struct DirectFrameLoad
     static constexpr bool is_lds = false;
     float *hist_row;
     const float *in_row;
-    long long base, mask, n0, own;      // own = first position of the frame's own (second) half
+    long long base, mask, n0;
+    int half;                           // float2 index of the frame's own (second) half: k >= half <=> position >= h * M
     bool live;
     __device__ __forceinline__ float2 operator()(int k) const
     {
         if (!live) return make_float2(0.f, 0.f);
         const long long pos = base + 2LL * k;
-        if (pos < n0) return *reinterpret_cast<const float2 *>(hist_row + (pos & mask));
-        const float2 v = *reinterpret_cast<const float2 *>(in_row + (pos - n0));
-        if (pos >= own) *reinterpret_cast<float2 *>(hist_row + (pos & mask)) = v;
+        // ONE load through a selected pointer (a branch per element would make the compiler wait for each load in turn
+        // instead of keeping a thread's sixteen in flight); the store is uniform per call: k >= half for a whole butterfly row
+        const float *src = pos < n0 ? hist_row + (pos & mask) : in_row + (pos - n0);
+        const float2 v = *reinterpret_cast<const float2 *>(src);
+        if (k >= half) *reinterpret_cast<float2 *>(hist_row + (pos & mask)) = v;
         return v;
     }
 };
@@ -122,8 +125,7 @@ __global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rfft_frames_direct
     const long long h = h_first + t;
     LdsBuf<float2> s = { lds + g * lds_padded(M) };
 
-    const DirectFrameLoad ld = { hist + (long long) i * hist_stride, in + (long long) i * in_stride, (h - 1) * (long long) M, hist_mask, n0,
-                                 h * (long long) M, live };
+    const DirectFrameLoad ld = { hist + (long long) i * hist_stride, in + (long long) i * in_stride, (h - 1) * (long long) M, hist_mask, n0, M / 2, live };
     LdsFFT<LOG2M, TG>::run(ld, LdsIO<float2>{ s }, s, tid, tw);
     if (live)
     {

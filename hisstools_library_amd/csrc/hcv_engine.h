@@ -136,6 +136,11 @@ namespace hcv
         bool global_reset();
         bool fence_background(bool keep_plan = false);
         bool ensure_staging(Stage &st, uint32_t parts);
+        // control-path device memory: stream-ordered allocation on the control stream (hipMallocAsync / hipFreeAsync).  The
+        // synchronous calls take runtime-wide locks and, for hipFree, wait for the whole device: an audio thread's launches
+        // stood behind them for up to 19 ms while a control thread regrew a stage.  (ctl_alloc'ed memory: ctl_free only.)
+        hipError_t ctl_alloc(void **p, size_t bytes);
+        void ctl_free(void *p);
         bool lock_for_audio(std::unique_lock<std::mutex> &lk);
         bool apply_pending_resets();
         bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
@@ -188,6 +193,7 @@ namespace hcv
         hipStream_t mPipeStream = nullptr;
         hipEvent_t mEvPipe[2] = { nullptr, nullptr };
         bool mPrevPipe2 = false;
+        std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         uint64_t mBlockCount = 0;

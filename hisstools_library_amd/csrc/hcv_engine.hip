@@ -387,6 +387,7 @@ Engine::~Engine()
         if (st->stream) (void) hipStreamSynchronize(st->stream);
     }
     if (mStream) (void) hipStreamSynchronize(mStream);
+    for (void *p : mParked) (void) hipFree(p);
     drop_ghosts();
     for (auto &blk : mGhostPool) (void) hipFree(blk.second);
     for (Stage *st : mStages)
@@ -512,15 +513,10 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     float2 *nHs = nullptr, *nX = nullptr;
     const size_t hs_bytes = sizeof(float2) * pairs * (newP + st.lead) * st.M;
     const size_t x_bytes = sizeof(float2) * (size_t) mCfg.nin * newR * st.M;
-    if (hipMalloc(&nHs, hs_bytes) != hipSuccess)
+    if (ctl_alloc((void **) &nHs, hs_bytes) != hipSuccess) return false;
+    if (ctl_alloc((void **) &nX, x_bytes) != hipSuccess)
     {
-        (void) hipGetLastError();
-        return false;
-    }
-    if (hipMalloc(&nX, x_bytes) != hipSuccess)
-    {
-        (void) hipGetLastError();
-        (void) hipFree(nHs);
+        ctl_free(nHs);
         return false;
     }
     long long h_snap = 0;
@@ -546,14 +542,15 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     if (!ok)
     {
         (void) hipGetLastError();
-        (void) hipFree(nHs);
-        (void) hipFree(nX);
+        ctl_free(nHs);
+        ctl_free(nX);
         mErr = "stage regrow failed";
         return false;
     }
 
     // ---- under the engine lock: the hops that arrived since the snapshot, then the pointer swap (no allocation, no wait)
     float2 *oHs = nullptr, *oX = nullptr;
+    const bool old_ctl = st.hs_ctl;
     {
         std::lock_guard<std::mutex> g(mMutex);
         if (!fence_background()) ok = false;
@@ -584,15 +581,61 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     if (!ok)
     {
         (void) hipGetLastError();
-        (void) hipFree(nHs);
-        (void) hipFree(nX);
+        ctl_free(nHs);
+        ctl_free(nX);
         mErr = "stage regrow failed";
         return false;
     }
-    (void) hipEventSynchronize(mEvSnap);
-    (void) hipFree(oHs);
-    (void) hipFree(oX);
+    // the old buffers' last readers are behind mEvSnap: the frees are ordered after it on the control stream (the first
+    // buffers of a stage came from hipMalloc in init and are parked until the engine goes: hipFree would stall the device)
+    (void) hipStreamWaitEvent(mCtlStream, mEvSnap, 0);
+    static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
+    if (old_ctl || !async)
+    {
+        if (!async) (void) hipEventSynchronize(mEvSnap);
+        ctl_free(oHs);
+        ctl_free(oX);
+    }
+    else
+    {
+        mParked.push_back(oHs);
+        mParked.push_back(oX);
+    }
+    st.hs_ctl = async;
     return true;
+}
+
+hipError_t Engine::ctl_alloc(void **p, size_t bytes)
+{
+    static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
+    if (async)
+    {
+        static std::once_flag once;
+        std::call_once(once, [&]()
+        {
+            // keep freed blocks in the pool instead of returning them to the driver at the next synchronisation
+            hipMemPool_t pool = nullptr;
+            if (hipDeviceGetDefaultMemPool(&pool, mDevice) == hipSuccess && pool)
+            {
+                uint64_t keep = ~uint64_t(0);
+                (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+            (void) hipGetLastError();
+        });
+        const hipError_t e = hipMallocAsync(p, bytes, mCtlStream);
+        if (e == hipSuccess) return e;
+        (void) hipGetLastError();
+        return e;
+    }
+    return hipMalloc(p, bytes);
+}
+
+void Engine::ctl_free(void *p)
+{
+    static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
+    if (!p) return;
+    if (async) (void) hipFreeAsync(p, mCtlStream);
+    else (void) hipFree(p);
 }
 
 // staging room of a stage for one pair's spectra (grown with the stage's capacity); control thread only
@@ -601,11 +644,11 @@ bool Engine::ensure_staging(Stage &st, uint32_t parts)
     if (parts <= st.stage_parts) return true;
     HCV_TRY(hipStreamSynchronize(mCtlStream));
     HCV_TRY(hipEventSynchronize(mEvSwapDone));
-    if (st.stage_spec) (void) hipFree(st.stage_spec);
+    if (st.stage_spec) ctl_free(st.stage_spec);
     st.stage_spec = nullptr;
     st.stage_parts = 0;
     const uint32_t want = std::max<uint32_t>(parts, st.Pcap);
-    HCV_TRY(hipMalloc(&st.stage_spec, sizeof(float2) * (size_t) want * st.M));
+    HCV_TRY(ctl_alloc((void **) &st.stage_spec, sizeof(float2) * (size_t) want * st.M));
     st.stage_parts = want;
     return true;
 }
@@ -639,11 +682,11 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             if (len > mIrCap)
             {
                 HCV_TRY(hipStreamSynchronize(mCtlStream));
-                if (mIrBuf) (void) hipFree(mIrBuf);
+                if (mIrBuf) ctl_free(mIrBuf);
                 mIrBuf = nullptr;
                 mIrCap = 0;
-                uint64_t want = std::max<uint64_t>(len, 65536);
-                HCV_TRY(hipMalloc(&mIrBuf, sizeof(float) * want));
+                uint64_t want = std::max<uint64_t>(len + len / 2, 65536);       // (headroom: growing IRs do not reallocate every time)
+                HCV_TRY(ctl_alloc((void **) &mIrBuf, sizeof(float) * want));
                 mIrCap = want;
             }
             HCV_TRY(hipMemcpyAsync(mIrBuf, ir, sizeof(float) * len, hipMemcpyHostToDevice, mCtlStream));

@@ -89,6 +89,7 @@ struct Engine::Stage
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
     BigFFTWork big_ctl;                 // the same for IR transforms on the control stream
+    bool hs_ctl = false;                // Hs / X came from ctl_alloc (a regrow) rather than from init's hipMalloc
     float2 *stage_spec = nullptr;       // staging for one pair's spectra (set_ir phase A), stage_parts partitions
     uint32_t stage_parts = 0;
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream (the MAC stream)

@@ -338,8 +338,17 @@ bool Engine::alloc_stage(Stage &st)
 
 void Engine::free_stage(Stage &st)
 {
-    if (st.Hs) (void) hipFree(st.Hs);
-    if (st.X) (void) hipFree(st.X);
+    // (what the control path allocated goes back the way it came: stream-ordered memory is not mixed with hipFree)
+    if (st.hs_ctl)
+    {
+        ctl_free(st.Hs);
+        ctl_free(st.X);
+    }
+    else
+    {
+        if (st.Hs) (void) hipFree(st.Hs);
+        if (st.X) (void) hipFree(st.X);
+    }
     for (int k = 0; k < 2; k++)
     {
         if (st.Yq[k]) (void) hipFree(st.Yq[k]);
@@ -361,7 +370,7 @@ void Engine::free_stage(Stage &st)
     if (st.big.b) (void) hipFree(st.big.b);
     if (st.big_ctl.a) (void) hipFree(st.big_ctl.a);
     if (st.big_ctl.b) (void) hipFree(st.big_ctl.b);
-    if (st.stage_spec) (void) hipFree(st.stage_spec);
+    if (st.stage_spec) ctl_free(st.stage_spec);
     st.stage_spec = nullptr;
     st.big.a = st.big.b = st.big_ctl.a = st.big_ctl.b = nullptr;
     for (int k = 0; k < 2; k++)
@@ -408,7 +417,8 @@ Engine::~Engine()
     if (mDevOut) (void) hipFree(mDevOut);
     if (mPinIn) (void) hipHostFree(mPinIn);
     if (mPinOut) (void) hipHostFree(mPinOut);
-    if (mIrBuf) (void) hipFree(mIrBuf);
+    if (mIrBuf) ctl_free(mIrBuf);
+    if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);        // the stream-ordered frees above have run
     if (mTaps) (void) hipFree(mTaps);
     if (mHeadSpec) (void) hipFree(mHeadSpec);
     for (int k = 0; k < 2; k++)

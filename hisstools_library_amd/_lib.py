@@ -113,6 +113,8 @@ SIGNATURES = {
     "hcv_convolver_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "hcv_convolver_process_f32_dev_allreduce": (C.c_int, [vp, vp, usz, vp, usz, usz, usz, usz, C.c_int]),
     "hcv_convolver_rt_stats": (C.c_int, [vp, C.POINTER(RtStats)]),
+    "hcv_host_register": (C.c_int, [vp, usz]),
+    "hcv_host_unregister": (C.c_int, [vp]),
     "hcv_convolver_set_profiling": (None, [vp, C.c_int]),
     "hcv_convolver_num_stages": (C.c_int, [vp]),
     "hcv_convolver_stage_stats": (C.c_int, [vp, C.c_int, C.POINTER(StageStats)]),

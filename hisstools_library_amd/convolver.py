@@ -198,6 +198,16 @@ class spectral_processor:
         return out
 
 
+def host_register(a: np.ndarray):
+    """Pin and map a numpy array (hcv_host_register): process() calls on [channels][n] views of it skip the staging copies.
+    Keep the array alive and call host_unregister(a) before dropping it."""
+    _check(_lib.load().hcv_host_register(a.ctypes.data, a.nbytes), "host_register")
+
+
+def host_unregister(a: np.ndarray):
+    _check(_lib.load().hcv_host_unregister(a.ctypes.data), "host_unregister")
+
+
 def rccl_unique_id() -> bytes:
     """128 bytes (ncclUniqueId) for hcv_convolver_comm_init, made on ONE rank of a row group and handed to the others."""
     buf = C.create_string_buffer(128)

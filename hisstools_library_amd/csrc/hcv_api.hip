@@ -10,6 +10,7 @@
 #include "hcv_rccl.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -935,12 +936,102 @@ static int sharded_process_host(hcv_convolver *h, const float *const *ins, float
     return 0;
 }
 
+// ---- registered host memory: callers that keep their channel buffers for a while (plug-in hosts) can pin and map them once;
+// process() calls whose rows all lie in registered memory, evenly spaced, then run on the caller's memory in place — the
+// kernels read the inputs and write the outputs over PCIe — instead of going through the staging copies (two host memcpys of
+// the whole block and two DMA transfers per call: 0.55 of the 1.1 ms a 64x64 engine's 8192-sample host call takes).
+
+namespace
+{
+    struct HostRegion { const char *base; size_t bytes; char *dev; };
+    std::mutex gRegMutex;
+    std::vector<HostRegion> gRegions;
+    std::atomic<int> gRegionCount { 0 };
+
+    // the device address of a [rows][n] block given as row pointers, if it is one evenly spaced block inside a registered region
+    bool mapped_block(const float *const *rows, size_t nrows, size_t n, const float **dev, int64_t *stride)
+    {
+        if (!nrows || !n || !rows[0]) return false;
+        const ptrdiff_t st = nrows > 1 ? rows[1] - rows[0] : (ptrdiff_t) n;
+        if (st < (ptrdiff_t) n) return false;                           // rows overlap or run backwards: not a plain block
+        for (size_t r = 2; r < nrows; r++)
+            if (rows[r] - rows[r - 1] != st) return false;
+        const char *lo = reinterpret_cast<const char *>(rows[0]);
+        const char *hi = reinterpret_cast<const char *>(rows[nrows - 1] + n);
+        std::lock_guard<std::mutex> g(gRegMutex);
+        for (const HostRegion &r : gRegions)
+            if (lo >= r.base && hi <= r.base + r.bytes)
+            {
+                *dev = reinterpret_cast<const float *>(r.dev + (lo - r.base));
+                *stride = (int64_t) st;
+                return true;
+            }
+        return false;
+    }
+}
+
+extern "C" int hcv_host_register(void *ptr, size_t bytes)
+{
+    if (!ptr || !bytes) return -1;
+    if (gDefaultDevice >= 0) (void) hipSetDevice(gDefaultDevice);
+    if (hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess)
+    {
+        set_error(std::string("hipHostRegister: ") + hipGetErrorString(hipGetLastError()));
+        return -1;
+    }
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess || !dev)
+    {
+        (void) hipGetLastError();
+        (void) hipHostUnregister(ptr);
+        set_error("hipHostGetDevicePointer failed for the registered block");
+        return -1;
+    }
+    std::lock_guard<std::mutex> g(gRegMutex);
+    gRegions.push_back({ static_cast<const char *>(ptr), bytes, static_cast<char *>(dev) });
+    gRegionCount = (int) gRegions.size();
+    return 0;
+}
+
+extern "C" int hcv_host_unregister(void *ptr)
+{
+    {
+        std::lock_guard<std::mutex> g(gRegMutex);
+        auto it = std::find_if(gRegions.begin(), gRegions.end(), [&](const HostRegion &r) { return r.base == ptr; });
+        if (it == gRegions.end()) return -1;
+        gRegions.erase(it);
+        gRegionCount = (int) gRegions.size();
+    }
+    if (hipHostUnregister(ptr) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        return -1;
+    }
+    return 0;
+}
+
 extern "C" int hcv_convolver_process_f32(hcv_convolver *h, const float *const *ins, float **outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
     if (h->sh) return sharded_process_host(h, ins, outs, numIns, numOuts, numSamples);
     Matrix &m = *h->m;
     const uint32_t no = (uint32_t) std::min<size_t>(numOuts, m.nout);
     const uint32_t ni = m.diag ? no : (uint32_t) std::min<size_t>(numIns, m.nin);
+    if (gRegionCount.load(std::memory_order_relaxed) > 0 && no && numSamples)
+    {
+        const float *din = nullptr, *dout = nullptr;
+        int64_t is = 0, os = 0;
+        const uint32_t rows_in = m.diag ? no : ni;
+        if ((rows_in == 0 || mapped_block(ins, rows_in, numSamples, &din, &is)) && mapped_block(outs, no, numSamples, &dout, &os))
+        {
+            if (!m.engine->process_pinned(rows_in ? ins[0] : nullptr, din, rows_in ? is : (int64_t) numSamples, outs[0], const_cast<float *>(dout), os, ni, no,
+                                          numSamples))
+            {
+                set_error(m.engine->last_error());
+                return -1;
+            }
+            return 0;
+        }
+    }
     if (!m.engine->process(ins, outs, ni, no, numSamples, false))
     {
         set_error(m.engine->last_error());

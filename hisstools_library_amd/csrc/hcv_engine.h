@@ -104,6 +104,11 @@ namespace hcv
         // device-resident call: ins/outs are [rows][stride] float on this GPU.  Asynchronous unless sync=true.
         bool process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
                          bool sync);
+        // synchronous call on PINNED host memory the caller registered (hcv_host_register): [rows][stride] blocks given by their
+        // host address and their device mapping.  Small blocks run on the mapping in place; larger ones are moved by the copy
+        // engines straight from / to the caller's memory (no staging memcpy on the host).
+        bool process_pinned(const float *ins_host, const float *ins_map, int64_t in_stride, float *outs_host, float *outs_map, int64_t out_stride,
+                            uint32_t nin_act, uint32_t nout_act, uint64_t n);
         bool synchronize();
         // for the layers that combine several engines (shards, collectives): the stream every block's emit — the only writer of
         // the caller's output buffer — runs on

@@ -659,6 +659,50 @@ bool Engine::process(const float *const *ins, float *const *outs, uint32_t nin_a
     return true;
 }
 
+bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t in_stride, float *outs_host, float *outs_map, int64_t out_stride,
+                            uint32_t nin_act, uint32_t nout_act, uint64_t n)
+{
+    static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
+    if (n <= (uint64_t) zc_limit) return process_dev(ins_map, in_stride, outs_map, out_stride, nin_act, nout_act, n, true);
+    DeviceGuard dg(mDevice);
+    nout_act = std::min(nout_act, mCfg.nout);
+    nin_act = std::min(nin_act, mCfg.nin);
+    if (!nout_act || !n) return true;
+    const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
+    for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
+    {
+        const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
+        std::unique_lock<std::mutex> lk;
+        if (!lock_for_audio(lk))
+        {
+            for (uint32_t o = 0; o < nout_act; o++) std::memset(outs_host + (size_t) o * out_stride + pos, 0, sizeof(float) * B);
+            continue;
+        }
+        if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+        if (rows_in)
+        {
+            // (a packed block is ONE transfer; a pitched one is moved row by row by the copy engine, a few microseconds per row)
+            if (in_stride == (int64_t) B)
+                HCV_TRY(hipMemcpyAsync(mDevIn, ins_host + pos, sizeof(float) * (size_t) B * rows_in, hipMemcpyHostToDevice, mStream));
+            else
+                HCV_TRY(hipMemcpy2DAsync(mDevIn, sizeof(float) * B, ins_host + pos, sizeof(float) * (size_t) in_stride, sizeof(float) * B, rows_in,
+                                         hipMemcpyHostToDevice, mStream));
+            mCtlDirty = true;
+        }
+        if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
+        if (out_stride == (int64_t) B)
+            HCV_TRY(hipMemcpyAsync(outs_host + pos, mDevOut, sizeof(float) * (size_t) B * nout_act, hipMemcpyDeviceToHost, mStream));
+        else
+            HCV_TRY(hipMemcpy2DAsync(outs_host + pos, sizeof(float) * (size_t) out_stride, mDevOut, sizeof(float) * B, sizeof(float) * B, nout_act,
+                                     hipMemcpyDeviceToHost, mStream));
+        HCV_TRY(hipEventRecord(mEvHostDone, mStream));
+        lk.unlock();
+        HCV_TRY(hipEventSynchronize(mEvHostDone));
+    }
+    if (mProfiling) collect_events();
+    return true;
+}
+
 bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
                          bool sync)
 {

@@ -175,6 +175,15 @@ HCV_API int hcv_convolver_comm_init(hcv_convolver *h, const void *unique_id128, 
 HCV_API int hcv_convolver_process_f32_dev_allreduce(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride,
                                                     size_t numIns, size_t numOuts, size_t numSamples, int sync);
 
+/* Registered host memory (optional).  The reference's process() takes host channel pointers (Convolver.cpp:138-154); by default
+ * every call here stages them through pinned buffers (two host copies of the block, PCIe both ways).  A caller that keeps its
+ * channel buffers for a while — a plug-in host — can pin and map them ONCE: hcv_convolver_process_f32 calls whose input rows and
+ * output rows each form one evenly spaced block inside registered memory then run on the caller's memory in place (the kernels
+ * read and write it over PCIe), with no staging copy.  Anything else takes the staging path as before.  Unregister before the
+ * memory is freed.  0 ok, -1 failure (hcv_last_error). */
+HCV_API int hcv_host_register(void *ptr, size_t bytes);
+HCV_API int hcv_host_unregister(void *ptr);
+
 /* The audio-thread contract (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:181-183): process never waits for a
  * control call's upload, allocation or device work, at most for the short host-only section in which a control call swaps its
  * staged result in.  Counters since the last hcv_convolver_clear_stats: process calls that found the engine lock taken, the

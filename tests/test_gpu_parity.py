@@ -761,3 +761,40 @@ def test_process_rejects_buffers_the_c_side_would_misread(H, oracle):
     c.process(x32, big[::2, :1024])
     for o in range(2):
         assert rel_err(big[2 * o, :1024], y_ref[o]) < TOL
+
+
+def test_registered_host_memory_runs_in_place(H, oracle):
+    """hcv_host_register: process() on evenly spaced rows inside registered memory runs on the caller's memory in place (no staging
+    copies) and must give the staged path's stream — hop-sized calls (direct input / output of whole-hop mode), small and ragged
+    calls, odd sample offsets (rows only 4-byte aligned), and a fallback to staging for rows outside the registration."""
+    nin, nout, L, S = 3, 2, 20000, 6 * 8192
+    irs = {(i, o): oracle.synth_ir(i, o, L) for i in range(nin) for o in range(nout)}
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    a, b = H.Convolver(nin, nout, 0, maxBlock=8192), H.Convolver(nin, nout, 0, maxBlock=8192)
+    for c in (a, b):
+        for (i, o), h in irs.items():
+            assert c.set(i, o, h, True) == 0
+    ya = a.run(xs, nout, [8192, 8192, 128, 1000, 333, 8192])             # staged
+    xr, yr = xs.copy(), np.zeros((nout, S), np.float32)
+    H.host_register(xr)
+    H.host_register(yr)
+    try:
+        pos, k = 0, 0
+        sizes = [8192, 8192, 128, 1000, 333, 8192]
+        while pos < S:
+            n = min(sizes[k % len(sizes)], S - pos)
+            b.process(xr[:, pos:pos + n], yr[:, pos:pos + n])
+            pos += n
+            k += 1
+        for o in range(nout):
+            assert rel_err(yr[o], ya[o]) < TOL
+        # rows outside the registered block: staged as before, same stream
+        b.reset()
+        other = np.zeros((nout, 4096), np.float32)
+        b.process(np.ascontiguousarray(xs[:, :4096]), other)
+        for o in range(nout):
+            assert rel_err(other[o], ya[o][:4096]) < TOL
+    finally:
+        H.host_unregister(xr)
+        H.host_unregister(yr)
+    assert H.load().hcv_host_unregister(xr.ctypes.data) == -1             # not registered any more

@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
 #pragma unroll
             for (int j = 0; j < OT; j++) hrow[j] = a.H + (long long) min(o0 + j, a.nout - 1) * out_stride4 + (long long) i * pair_stride4;
 
+            // small tiles (one or two outputs, one hop: the n x 1 and 1 x 1 engines) are latency-bound chains of short k-slices: with
+            // eight partitions unrolled their sixteen loads are in flight together; the large tiles keep their registers
+            constexpr int kUnroll = (OT <= 2 && TT == 1) ? 8 : HCV_MAC_UNROLL;
             // sliding window over the hop axis: xw[t] = X[h0 + t - p]
             float4 xw[TT];
             if (TT > 1)
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void spectral_mac_kernel(MacParams a)
                 }
             }
 
-#pragma unroll HCV_MAC_UNROLL
+#pragma unroll kUnroll
             for (int p = pa; p < pb; p++)
             {
                 float4 hval[OT];

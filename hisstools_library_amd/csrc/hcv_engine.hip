@@ -514,8 +514,11 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     if (s >= mStages.size()) return false;
     DeviceGuard dg(mDevice);
     Stage &st = *mStages[s];
-    const uint32_t newP = (uint32_t) std::max<uint64_t>(1, (capacity + st.M - 1) / st.M);
+    uint32_t newP = (uint32_t) std::max<uint64_t>(1, (capacity + st.M - 1) / st.M);
     if (newP <= st.Pcap) return true;
+    // grow by at least half: obtaining NEW device memory from the driver stalls every HIP call of the process while it maps
+    // (one 19 ms `process` call observed beside a regrow to 0.5 GB) — the pool keeps what it has, so make such growth rare
+    newP = std::max<uint32_t>(newP, st.Pcap + st.Pcap / 2);
 
     // ---- outside the engine lock: allocate, clear, re-stride what exists
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;

@@ -41,7 +41,7 @@ def _paced(call, ncalls, period):
     return ts * 1e3
 
 
-@pytest.mark.parametrize("entry", ["host_pointers", "device_pointers"])
+@pytest.mark.parametrize("entry", ["host_pointers", "device_pointers", "sharded_host_pointers"])
 def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
@@ -52,7 +52,9 @@ def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
     ncalls = 1400                                      # 3.7 s of audio
     S = ncalls * RB
     xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
-    c = H.Convolver(nin, nout, 0, maxBlock=8192)
+    # ("sharded": the same through ONE object driving two engines on the GPU — rows 0..7 on the first, 8..15, the ones being
+    #  replaced, on the second: control calls and process calls meet per shard)
+    c = H.Convolver(nin, nout, 0, maxBlock=8192, devices=[0, 0]) if entry.startswith("sharded") else H.Convolver(nin, nout, 0, maxBlock=8192)
     ref = oracle.Convolver(nin, len(steady), 0)
     ref.setResetOffset(0)
     for o in range(nout):

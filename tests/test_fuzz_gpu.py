@@ -3,7 +3,8 @@ mid-stream control calls (IR swaps, clears and restarts of single pairs, full re
 been run for 105000+ cases (65000 with the mid-stream control calls; worst relative error 6.5e-6 against the 1.5e-5 bound);
 the suite runs a fixed slice of the same seeds so that a regression shows up with a seed to reproduce it.
 Round 2 (whole-hop mode as one uniform convolution, direct input / output, staged IR loads): 20 661 more cases, also under
-HCV_SERIAL=1 and HCV_MAX_BLOCK=8192, worst 6.5e-6 (profiles/r02_fuzz.txt)."""
+HCV_SERIAL=1 and HCV_MAX_BLOCK=8192, worst 6.5e-6; 6 292 cases with every Convolver sharded over two or three engines (HCV_DEVICES=0,0[,0]), worst 2.0e-6
+(profiles/r02_fuzz.txt)."""
 import os
 import sys
 

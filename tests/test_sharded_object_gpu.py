@@ -199,3 +199,17 @@ def test_bench_two_ranks_share_the_gpu(workload, flags):
         assert d["scaling"] == "strong"
         nin, nout = {"c3": (8, 1), "m16": (16, 16)}[workload]
         assert f"({nin}x{nout} over 2 GPU)" in d["config"]["workload"]
+
+
+def test_random_cases_through_sharded_objects(monkeypatch):
+    """The randomised differential test (tests/perf/fuzz_parity.py: random matrices, latencies, call sizes, live IR swaps, clears and
+    resets) with HCV_DEVICES set, so that every Convolver it builds is ONE object over two engines."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    import fuzz_parity
+    monkeypatch.setenv("HCV_DEVICES", "0,0")
+    ran = 0
+    for seed in range(7001, 7061):
+        kind, desc, err = fuzz_parity.one_case(seed)
+        assert err <= fuzz_parity.TOL, (seed, kind, desc, err)
+        ran += kind in ("convolver", "parallel")
+    assert ran >= 20

@@ -87,20 +87,39 @@ __global__ __launch_bounds__((FourStepTile<(1 << L1), 8>::THREADS)) void big_col
     for (int e = threadIdx.x; e < BIG_COLS * M1; e += NT)
     {
         const int c = e % BIG_COLS, n1 = e / BIG_COLS;
-        LdsBuf<float2>{ lds + c * lds_padded(M1) }[n1] = zin[(long long) n1 * M2 + col0 + c];
+        LdsBuf<float2>{ lds + c * fourstep_pitch(M1) }[n1] = zin[(long long) n1 * M2 + col0 + c];
     }
     __syncthreads();
     const int g = threadIdx.x / TG, t = threadIdx.x % TG;
-    for (int c0 = 0; c0 < BIG_COLS; c0 += G) LdsFFT<L1, TG>::run(LdsBuf<float2>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
-    for (int e = threadIdx.x; e < BIG_COLS * M1; e += NT)
+    for (int c0 = 0; c0 < BIG_COLS; c0 += G) LdsFFT<L1, TG>::run(LdsBuf<float2>{ lds + (c0 + g) * fourstep_pitch(M1) }, t, tw1);
+    // W_M^(n2 k1) = (N-th root)^(2 n2 k1), computed rather than gathered from the N/2-entry table (one scattered 8-byte load
+    // per element of the tile bound this pass).  A thread's elements are its column at k1 = k10 + i DK: W^(n2 k10) and
+    // S, S^2, S^4, S^8 (S = W^(n2 DK)) each from sincospi of an exactly reduced fraction (within 2 ulp), the sixteen twiddles
+    // as products of at most four of them — five calls instead of sixteen (as fx_cols_kernel, hcv_fftx.hip).
+    constexpr int NI = BIG_COLS * M1 / NT, DK = NT / BIG_COLS;
+    static_assert((BIG_COLS * M1) % NT == 0 && NT % BIG_COLS == 0 && (NI & (NI - 1)) == 0 && NI <= 16, "tile geometry");
+    auto root = [&](int idx)
     {
-        const int c = e % BIG_COLS, k1 = e / BIG_COLS;
-        const int n2 = col0 + c;
-        // W_M^(n2 k1) = (N-th root)^(2 n2 k1), computed rather than gathered from the N/2-entry table (one scattered 8-byte
-        // load per element of the tile bound this pass; sincospi of the exactly reduced fraction is within 2 ulp)
         float sn, cs;
-        sincospif(-(float) ((2 * n2 * k1) & (2 * M - 1)) / (float) M, &sn, &cs);
-        tout[(long long) k1 * M2 + n2] = cmul(LdsBuf<float2>{ lds + c * lds_padded(M1) }[k1], make_float2(cs, sn));
+        sincospif(-(float) (idx & (2 * M - 1)) / (float) M, &sn, &cs);
+        return make_float2(cs, sn);
+    };
+    const int c = (int) threadIdx.x % BIG_COLS, k10 = (int) threadIdx.x / BIG_COLS;
+    const int n2 = col0 + c;
+    float2 w[NI];
+    w[0] = root(2 * n2 * k10);
+#pragma unroll
+    for (int bit = 1; bit < NI; bit *= 2)
+    {
+        const float2 sb = root(2 * n2 * DK * bit);                  // (not S squared: that would double S's error every time)
+#pragma unroll
+        for (int i = 0; i < bit; i++) w[bit + i] = cmul(w[i], sb);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+    {
+        const int k1 = k10 + i * DK;
+        tout[(long long) k1 * M2 + n2] = cmul(LdsBuf<float2>{ lds + c * fourstep_pitch(M1) }[k1], w[i]);
     }
 }
 
@@ -117,17 +136,17 @@ __global__ __launch_bounds__((FourStepTile<(1 << L2), 8>::THREADS)) void big_row
     const float2 *tin = Tin + (long long) blockIdx.y * M + (long long) row0 * M2;
     float2 *zout = Zout + (long long) blockIdx.y * M;
 
-    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += NT) LdsBuf<float2>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = tin[e];
+    for (int e = threadIdx.x; e < BIG_ROWS * M2; e += NT) LdsBuf<float2>{ lds + (e / M2) * fourstep_pitch(M2) }[e % M2] = tin[e];
     __syncthreads();
     const int g = threadIdx.x / TG, t = threadIdx.x % TG;
     for (int r0 = 0; r0 < BIG_ROWS; r0 += G)
     {
-        LdsFFT<L2, TG>::run(LdsBuf<float2>{ lds + (r0 + g) * lds_padded(M2) }, t, tw2);
+        LdsFFT<L2, TG>::run(LdsBuf<float2>{ lds + (r0 + g) * fourstep_pitch(M2) }, t, tw2);
     }
     for (int e = threadIdx.x; e < BIG_ROWS * M2; e += NT)
     {
         const int r = e % BIG_ROWS, k2 = e / BIG_ROWS;
-        zout[(long long) (row0 + r) + (long long) M1 * k2] = LdsBuf<float2>{ lds + r * lds_padded(M2) }[k2];
+        zout[(long long) (row0 + r) + (long long) M1 * k2] = LdsBuf<float2>{ lds + r * fourstep_pitch(M2) }[k2];
     }
 }
 
@@ -235,7 +254,7 @@ static hipError_t big_cfft(int log2n, float2 *a, float2 *b, int batch, const Big
     dim3 gc, gr, bc, br;
 #define HCV_BIG_COLS(L)                                                                                                \
     case L:                                                                                                            \
-        lds1 = sizeof(float2) * FourStepTile<(1 << L), 8>::TILE * lds_padded(M1);                                      \
+        lds1 = sizeof(float2) * FourStepTile<(1 << L), 8>::TILE * fourstep_pitch(M1);                                      \
         gc = dim3(M2 / FourStepTile<(1 << L), 8>::TILE, batch);                                                        \
         bc = dim3(FourStepTile<(1 << L), 8>::THREADS);                                                                 \
         if (lds1 > 48 * 1024) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(big_cols_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds1); \
@@ -249,7 +268,7 @@ static hipError_t big_cfft(int log2n, float2 *a, float2 *b, int batch, const Big
 #undef HCV_BIG_COLS
 #define HCV_BIG_ROWS(L)                                                                                                \
     case L:                                                                                                            \
-        lds2 = sizeof(float2) * FourStepTile<(1 << L), 8>::TILE * lds_padded(M2);                                      \
+        lds2 = sizeof(float2) * FourStepTile<(1 << L), 8>::TILE * fourstep_pitch(M2);                                      \
         gr = dim3(M1 / FourStepTile<(1 << L), 8>::TILE, batch);                                                        \
         br = dim3(FourStepTile<(1 << L), 8>::THREADS);                                                                 \
         if (lds2 > 48 * 1024) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(big_rows_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds2); \

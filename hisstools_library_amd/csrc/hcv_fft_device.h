@@ -52,6 +52,11 @@ __device__ __forceinline__ C root(const C *__restrict__ tw, int m)
 // of 16 * p, which would land 64 lanes on two banks; the skew spreads them over all of them (<= 2-way conflicts).
 __host__ __device__ constexpr int lds_padded(int points) { return points + (points >> 4); }
 
+// Pitch (in elements) between the columns / rows of a four-step tile in LDS.  lds_padded(P) alone is a multiple of 16 elements:
+// the transposing phases, where adjacent lanes sit on adjacent tile lines (2 or 4 lines apart with vector I/O), would then put
+// 8 - 16 lanes on the same bank.  One more element makes the line stride odd in 8-byte units, and those phases conflict-free.
+__host__ __device__ constexpr int fourstep_pitch(int points) { return lds_padded(points) + 1; }
+
 template <class C> struct LdsBuf
 {
     C *base;
@@ -362,15 +367,23 @@ template <int LOG2M, int WG = 256> struct FFTGeom
 // Tile of one four-step workgroup: TILE adjacent columns (or rows) of P points each, all transformed at once by
 // TILE * TG threads (at most 1024).  TILE aims at 128-byte runs in each of the split arrays, within 128 KiB of LDS
 // (136 KiB with the bank padding).
+#ifndef HCV_FX_TILE_BYTES
+#define HCV_FX_TILE_BYTES 256
+#endif
 template <int P, int ELEM_BYTES> struct FourStepTile
 {
     static constexpr int TG = P / 16 < 256 ? P / 16 : 256;
-    static constexpr int WANT = 256 / ELEM_BYTES;                       // complex elements: 128 bytes per split array
+    static constexpr int WANT = HCV_FX_TILE_BYTES / ELEM_BYTES;         // complex elements: 128 bytes per split array
     static constexpr int CAP = 128 * 1024 / (P * ELEM_BYTES);
     static constexpr int TILE = CAP < WANT ? CAP : WANT;
     static constexpr int THREADS = TILE * TG < 1024 ? TILE * TG : 1024;
     static constexpr int G = THREADS / TG;                              // sub-transforms in flight
     static_assert(TILE % G == 0 && THREADS % 64 == 0, "tile geometry");
+    // workgroups of this tile a CU holds (160 KiB of LDS, 2048 threads): the register budget the kernels ask for
+    static constexpr int LDS_BYTES = TILE * (P + (P >> 4) + 1) * ELEM_BYTES;
+    static constexpr int BY_LDS = 160 * 1024 / LDS_BYTES, BY_THREADS = 2048 / THREADS;
+    static constexpr int PER_CU = BY_LDS < 1 ? 1 : (BY_LDS < BY_THREADS ? BY_LDS : BY_THREADS);
+    static constexpr int WAVES_PER_SIMD = PER_CU * THREADS / 256 < 1 ? 1 : PER_CU * THREADS / 256;   // (second launch bound, HIP semantics)
 };
 
 

@@ -357,7 +357,7 @@ namespace
                 const long long idx = (long long) n1 * M2 + col0 + cv;
                 const VT vr = *reinterpret_cast<const VT *>(re + idx), vi = *reinterpret_cast<const VT *>(im + idx);
 #pragma unroll
-                for (int j = 0; j < V; j++) LdsBuf<C>{ lds + (cv + j) * lds_padded(M1) }[n1] = C(fx_get(vr, j), fx_get(vi, j));
+                for (int j = 0; j < V; j++) LdsBuf<C>{ lds + (cv + j) * fourstep_pitch(M1) }[n1] = C(fx_get(vr, j), fx_get(vi, j));
             }
         }
         else
@@ -365,24 +365,62 @@ namespace
             for (int e = threadIdx.x; e < COLS * M1; e += NT)
             {
                 const int c = e % COLS, n1 = e / COLS;
-                LdsBuf<C>{ lds + c * lds_padded(M1) }[n1] = fx_load<T, C>(a, 0, n1 * M2 + col0 + c, M, twN);
+                LdsBuf<C>{ lds + c * fourstep_pitch(M1) }[n1] = fx_load<T, C>(a, 0, n1 * M2 + col0 + c, M, twN);
             }
         }
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
-        for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(LdsBuf<C>{ lds + (c0 + g) * lds_padded(M1) }, t, tw1);
+        for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(LdsBuf<C>{ lds + (c0 + g) * fourstep_pitch(M1) }, t, tw1);
         C *out = work + (long long) blockIdx.y * M;
         constexpr int CV = 16 / (int) sizeof(C) > 0 ? 16 / (int) sizeof(C) : 1;       // complex values per 16-byte store: 2 (float), 1 (double)
-        for (int e = threadIdx.x; e < (COLS / CV) * M1; e += NT)
+        constexpr int NI = ((COLS / CV) * M1) / NT, DK = NT / (COLS / CV);      // a thread's elements: its column pair at k1 = k10 + i DK
+        if constexpr (((COLS / CV) * M1) % NT == 0 && (NI & (NI - 1)) == 0 && NI >= 2 && NI <= 16)
         {
-            const int c = (e % (COLS / CV)) * CV, k1 = e / (COLS / CV);
+            // The pass is bound by its instruction stream, and one sincospi per element (sixteen per thread) was 40 % of it.
+            // A thread's twiddles per column are W^(n2 k10) * S^i, i < NI, with S = W^(n2 DK): the first and S, S^2, S^4, ...
+            // each from sincospi of an exactly reduced argument (1 + log2 NI calls instead of NI), the rest as products
+            // (term i = term (i - b) * S^b for its top bit b): at most log2 NI factors, each within 2 ulp.
+            const int c = ((int) threadIdx.x % (COLS / CV)) * CV, k10 = (int) threadIdx.x / (COLS / CV);
             const int n2 = col0 + c;
-            C v[CV];
+            C w[CV][NI];
 #pragma unroll
-            for (int j = 0; j < CV; j++) v[j] = cmul(LdsBuf<C>{ lds + (c + j) * lds_padded(M1) }[k1], fx_twiddle(twN, 2 * (n2 + j) * k1, M));
-            C *d = out + (long long) k1 * M2 + n2;
-            if (CV == 2) *reinterpret_cast<float4 *>(d) = make_float4((float) v[0].x, (float) v[0].y, (float) v[CV - 1].x, (float) v[CV - 1].y);
-            else d[0] = v[0];
+            for (int j = 0; j < CV; j++)
+            {
+                w[j][0] = fx_twiddle(twN, 2 * (n2 + j) * k10, M);
+#pragma unroll
+                for (int bit = 1; bit < NI; bit *= 2)
+                {
+                    // (S^bit from its own exactly reduced argument: squaring S instead would double its error every time)
+                    const C sb = fx_twiddle(twN, 2 * (n2 + j) * DK * bit, M);
+#pragma unroll
+                    for (int i = 0; i < bit; i++) w[j][bit + i] = cmul(w[j][i], sb);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+            {
+                const int k1 = k10 + i * DK;
+                C v[CV];
+#pragma unroll
+                for (int j = 0; j < CV; j++) v[j] = cmul(LdsBuf<C>{ lds + (c + j) * fourstep_pitch(M1) }[k1], w[j][i]);
+                C *d = out + (long long) k1 * M2 + n2;
+                if (CV == 2) *reinterpret_cast<float4 *>(d) = make_float4((float) v[0].x, (float) v[0].y, (float) v[CV - 1].x, (float) v[CV - 1].y);
+                else d[0] = v[0];
+            }
+        }
+        else
+        {
+            for (int e = threadIdx.x; e < (COLS / CV) * M1; e += NT)
+            {
+                const int c = (e % (COLS / CV)) * CV, k1 = e / (COLS / CV);
+                const int n2 = col0 + c;
+                C v[CV];
+#pragma unroll
+                for (int j = 0; j < CV; j++) v[j] = cmul(LdsBuf<C>{ lds + (c + j) * fourstep_pitch(M1) }[k1], fx_twiddle(twN, 2 * (n2 + j) * k1, M));
+                C *d = out + (long long) k1 * M2 + n2;
+                if (CV == 2) *reinterpret_cast<float4 *>(d) = make_float4((float) v[0].x, (float) v[0].y, (float) v[CV - 1].x, (float) v[CV - 1].y);
+                else d[0] = v[0];
+            }
         }
     }
 
@@ -408,16 +446,16 @@ namespace
             {
                 const float4 v = reinterpret_cast<const float4 *>(in)[e];
                 const int row = (2 * e) / M2, n2 = (2 * e) % M2;
-                LdsBuf<C> b = { lds + row * lds_padded(M2) };
+                LdsBuf<C> b = { lds + row * fourstep_pitch(M2) };
                 b[n2] = C(v.x, v.y);
                 b[n2 + 1] = C(v.z, v.w);
             }
         }
         else
-            for (int e = threadIdx.x; e < ROWS * M2; e += NT) LdsBuf<C>{ lds + (e / M2) * lds_padded(M2) }[e % M2] = in[e];
+            for (int e = threadIdx.x; e < ROWS * M2; e += NT) LdsBuf<C>{ lds + (e / M2) * fourstep_pitch(M2) }[e % M2] = in[e];
         __syncthreads();
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
-        for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(LdsBuf<C>{ lds + (r0 + g) * lds_padded(M2) }, t, tw2);
+        for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(LdsBuf<C>{ lds + (r0 + g) * fourstep_pitch(M2) }, t, tw2);
         const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
         typedef typename FxVec<T>::type VT;
         constexpr int V = FxVec<T>::V;
@@ -431,7 +469,7 @@ namespace
 #pragma unroll
                 for (int j = 0; j < V; j++)
                 {
-                    const C v = LdsBuf<C>{ lds + (r + j) * lds_padded(M2) }[k2];
+                    const C v = LdsBuf<C>{ lds + (r + j) * fourstep_pitch(M2) }[k2];
                     fx_put(vr, j, a.swap_out ? v.y : v.x);
                     fx_put(vi, j, a.swap_out ? v.x : v.y);
                 }
@@ -445,7 +483,7 @@ namespace
             {
                 const int r = e % ROWS, k2 = e / ROWS;
                 const int k = row0 + r + M1 * k2;
-                const C v = LdsBuf<C>{ lds + r * lds_padded(M2) }[k2];
+                const C v = LdsBuf<C>{ lds + r * fourstep_pitch(M2) }[k2];
                 if (a0.store == S_POST) post[(long long) blockIdx.y * M + k] = v;
                 else fx_store<T, C>(a, 0, k, v);
             }
@@ -617,7 +655,7 @@ namespace
     {
         typedef typename Cx<T>::type C;
         typedef FxTile<(1 << L1), (int) sizeof(C)> Tile;
-        const size_t lds = sizeof(C) * Tile::TILE * (size_t) lds_padded(1 << L1);
+        const size_t lds = sizeof(C) * Tile::TILE * (size_t) fourstep_pitch(1 << L1);
         hipError_t e = allow_big_lds(fx_cols_kernel<T, L1>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / Tile::TILE, nb), dim3(Tile::THREADS), lds, st, k, work, M2, M, q0, tw1, twN);
@@ -629,7 +667,7 @@ namespace
     {
         typedef typename Cx<T>::type C;
         typedef FxTile<(1 << L2), (int) sizeof(C)> Tile;
-        const size_t lds = sizeof(C) * Tile::TILE * (size_t) lds_padded(1 << L2);
+        const size_t lds = sizeof(C) * Tile::TILE * (size_t) fourstep_pitch(1 << L2);
         hipError_t e = allow_big_lds(fx_rows_kernel<T, L2>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((fx_rows_kernel<T, L2>), dim3(M1 / Tile::TILE, nb), dim3(Tile::THREADS), lds, st, work, k, post, M1, M, q0, tw2);

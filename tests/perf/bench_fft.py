@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--quick", action="store_true", help="a handful of complex sizes only (kernel tuning)")
+    ap.add_argument("--only", default="", help="comma-separated op:precision:log2n rows (e.g. fft:f32:16,rfft:f32:20) instead of the plan")
     args = ap.parse_args()
     rows = []
     plan = [("fft", "f32", l) for l in (4, 6, 8, 10, 12, 14, 15, 16, 18, 20, 22)]
@@ -115,6 +116,8 @@ def main():
     plan += [("rfft_zip", "f32", l) for l in (10, 14)] + [("rifft_zip", "f32", l) for l in (10, 14)] + [("rfft", "f64", l) for l in (12, 14, 18)]
     if args.quick:
         plan = [("fft", "f32", l) for l in (6, 8, 10, 12, 13, 14)] + [("fft", "f64", l) for l in (10, 12, 13)] + [("fft", "f32", 16), ("fft", "f32", 20)]
+    if args.only:
+        plan = [(o, p, int(l)) for o, p, l in (item.split(":") for item in args.only.split(","))]
     for op, prec, l2 in plan:
         r = run_case(op, prec, l2, args.gib, args.reps)
         if args.cpu and op in ("fft", "rfft", "rifft") and l2 <= 20:

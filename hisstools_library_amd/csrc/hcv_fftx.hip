@@ -164,11 +164,29 @@ namespace
         }
     };
 
+    // 16-byte vectors of the split arrays: 4 floats / 2 doubles of adjacent columns (or bins) per lane.  The tiles' rows are runs
+    // of 128 bytes per split array, so one-element-per-lane access issued four (two) times the memory instructions for the same
+    // bytes; the four-step passes are bound by exactly that issue rate, not by HBM (their scratch stays in the Infinity Cache).
+    template <class T> struct FxVec;
+    template <> struct FxVec<float> { typedef float4 type; static constexpr int V = 4; };
+    template <> struct FxVec<double> { typedef double2 type; static constexpr int V = 2; };
+    __device__ __forceinline__ float fx_get(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+    __device__ __forceinline__ double fx_get(const double2 &v, int j) { return j == 0 ? v.x : v.y; }
+    __device__ __forceinline__ void fx_put(float4 &v, int j, float x) { if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x; }
+    __device__ __forceinline__ void fx_put(double2 &v, int j, double x) { if (j == 0) v.x = x; else v.y = x; }
+    template <class T> __device__ __forceinline__ bool fx_aligned16(const T *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
     // -------------------------------------------------------------------------------------------- LDS-resident transforms
+
+#ifndef HCV_FX_STAGE_TG
+#define HCV_FX_STAGE_TG 32        // thread groups up to this size may move their transforms through LDS (below)
+#endif
 
 
     // second launch bound = waves per SIMD the register budget must allow (HIP semantics): 4 -> 128 VGPRs in float
-    template <class T, int LOG2M>
+    // STAGED (thread groups up to HCV_FX_STAGE_TG threads only): the workgroup's transforms pass through LDS on their way in and
+    // out instead of being loaded into / stored from the butterflies' registers; chosen per launch (launch_lds)
+    template <class T, int LOG2M, bool STAGED>
     __global__ __launch_bounds__((FFTGeom<LOG2M>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a0, const typename Cx<T>::type *__restrict__ tw)
     {
         typedef typename Cx<T>::type C;
@@ -187,34 +205,75 @@ namespace
         const FxK<T> a = fx_at(a0, UNI ? q0 + g : q0);
         const int soff = UNI ? 0 : g * (int) a.sstride, doff = UNI ? 0 : g * (int) a.dstride;
         const LdsBuf<C> s = { lds + g * lds_padded(M) };
-        if constexpr (TG <= 4)
+        if constexpr (STAGED && TG <= HCV_FX_STAGE_TG)
         {
-            // Sixteen or more transforms per wave (M <= 64; measured: 2^4 1.4 -> 3.8 TB/s, 2^6 +13 %, no gain from 2^7 on): with one butterfly's operands per lane a load instruction would touch 16 cache
-            // lines for 256 useful bytes.  The workgroup instead moves its G transforms through LDS with consecutive lanes on
-            // consecutive elements (one contiguous run when the batch is dense), in both directions.
-            const long long left = a0.batch - q0;
-            const int groups = left < G ? (int) left : G;
-            for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
             {
-                const int gg = e / M, n = e % M;
-                LdsBuf<C>{ lds + gg * lds_padded(M) }[n] = fx_load<T, C>(a, gg * (int) a.sstride, n, M, tw);
-            }
-            __syncthreads();
-            LdsFFT<LOG2M, TG, C>::run(s, t, tw);
-            if (a.store == S_POST)
-            {
-                if (live)
-                    for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, doff, k, M, s[k], s[(M - k) & (M - 1)], tw);
-            }
-            else
-            {
-                for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
+                // Sixteen or more transforms per wave (M <= 64; measured: 2^4 1.4 -> 3.8 TB/s, 2^6 +13 %): with one butterfly's
+                // operands per lane a load instruction would touch 16 cache lines for 256 useful bytes.  The workgroup instead
+                // moves its G transforms through LDS with consecutive lanes on consecutive elements (one contiguous run when the
+                // batch is dense), in both directions — as 16-byte vectors of the split arrays where strides and alignment allow
+                // (a quarter of the memory instructions for the same bytes).
+                typedef typename FxVec<T>::type VT;
+                constexpr int V = FxVec<T>::V;
+                const long long left = a0.batch - q0;
+                const int groups = left < G ? (int) left : G;
+                if (a.load == L_SPLIT && M % V == 0 && a.sstride % V == 0 && fx_aligned16(static_cast<const T *>(a.sa)) && fx_aligned16(a.sb))     // (wave-uniform)
                 {
-                    const int gg = e / M, k = e % M;
-                    fx_store<T, C>(a, gg * (int) a.dstride, k, LdsBuf<C>{ lds + gg * lds_padded(M) }[k]);
+                    const T *re = static_cast<const T *>(a.sa), *im = a.sb;
+                    for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
+                    {
+                        const int gg = e / (M / V), n = (e % (M / V)) * V;
+                        const long long idx = (long long) gg * a.sstride + n;
+                        const VT vr = *reinterpret_cast<const VT *>(re + idx), vi = *reinterpret_cast<const VT *>(im + idx);
+                        const LdsBuf<C> d = { lds + gg * lds_padded(M) };
+    #pragma unroll
+                        for (int j = 0; j < V; j++) d[n + j] = C(fx_get(vr, j), fx_get(vi, j));
+                    }
                 }
+                else
+                {
+                    for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
+                    {
+                        const int gg = e / M, n = e % M;
+                        LdsBuf<C>{ lds + gg * lds_padded(M) }[n] = fx_load<T, C>(a, gg * (int) a.sstride, n, M, tw);
+                    }
+                }
+                __syncthreads();
+                LdsFFT<LOG2M, TG, C>::run(s, t, tw);
+                if (a.store == S_POST)
+                {
+                    if (live)
+                        for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, doff, k, M, s[k], s[(M - k) & (M - 1)], tw);
+                }
+                else if (a.store == S_SPLIT && M % V == 0 && a.dstride % V == 0 && fx_aligned16(a.da) && fx_aligned16(a.db))                        // (wave-uniform)
+                {
+                    for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
+                    {
+                        const int gg = e / (M / V), k = (e % (M / V)) * V;
+                        const long long idx = (long long) gg * a.dstride + k;
+                        const LdsBuf<C> b = { lds + gg * lds_padded(M) };
+                        VT vr, vi;
+    #pragma unroll
+                        for (int j = 0; j < V; j++)
+                        {
+                            const C v = b[k + j];
+                            fx_put(vr, j, a.swap_out ? v.y : v.x);
+                            fx_put(vi, j, a.swap_out ? v.x : v.y);
+                        }
+                        *reinterpret_cast<VT *>(a.da + idx) = vr;
+                        *reinterpret_cast<VT *>(a.db + idx) = vi;
+                    }
+                }
+                else
+                {
+                    for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
+                    {
+                        const int gg = e / M, k = e % M;
+                        fx_store<T, C>(a, gg * (int) a.dstride, k, LdsBuf<C>{ lds + gg * lds_padded(M) }[k]);
+                    }
+                }
+                return;
             }
-            return;
         }
         const FxLoad<T, M> ld = { a, soff, tw, live };
         if (a.store == S_POST)
@@ -320,17 +379,6 @@ namespace
         return make_double2(cs, sn);
     }
 
-    // 16-byte vectors of the split arrays: 4 floats / 2 doubles of adjacent columns (or bins) per lane.  The tiles' rows are runs
-    // of 128 bytes per split array, so one-element-per-lane access issued four (two) times the memory instructions for the same
-    // bytes; the four-step passes are bound by exactly that issue rate, not by HBM (their scratch stays in the Infinity Cache).
-    template <class T> struct FxVec;
-    template <> struct FxVec<float> { typedef float4 type; static constexpr int V = 4; };
-    template <> struct FxVec<double> { typedef double2 type; static constexpr int V = 2; };
-    __device__ __forceinline__ float fx_get(const float4 &v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
-    __device__ __forceinline__ double fx_get(const double2 &v, int j) { return j == 0 ? v.x : v.y; }
-    __device__ __forceinline__ void fx_put(float4 &v, int j, float x) { if (j == 0) v.x = x; else if (j == 1) v.y = x; else if (j == 2) v.z = x; else v.w = x; }
-    __device__ __forceinline__ void fx_put(double2 &v, int j, double x) { if (j == 0) v.x = x; else v.y = x; }
-    template <class T> __device__ __forceinline__ bool fx_aligned16(const T *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
     // M = M1 * M2, n = M2*n1 + n2, k = k1 + M1*k2.   cols: for every n2 an M1-point transform over n1, times W_M^(n2 k1)
     template <class T, int L1>
@@ -612,7 +660,13 @@ namespace
         typedef typename Cx<T>::type C;
         typedef FFTGeom<L> Gm;
         const size_t lds = sizeof(C) * lds_padded(Gm::M) * Gm::G;
-        hipError_t e = allow_big_lds(fx_lds_kernel<T, L>, lds);
+        // thread groups of 8 - 32 are staged too (2^7 ... 2^9: 3.2 - 4.0 -> 5.1 - 5.5 TB/s) unless the input is the real inverse's
+        // pre-pass, whose element-wise loads are slower staged than straight into the butterflies (3.4 -> 2.9 TB/s)
+        const bool staged = Gm::TG <= 4 || (Gm::TG <= HCV_FX_STAGE_TG && k.load != L_PRE);
+        void (*kernel)(FxK<T>, const C *) = fx_lds_kernel<T, L, false>;
+        if constexpr (Gm::TG <= HCV_FX_STAGE_TG)
+            if (staged) kernel = fx_lds_kernel<T, L, true>;
+        hipError_t e = allow_big_lds(kernel, lds);
         if (e != hipSuccess) return e;
         // lane addressing is 32-bit relative to the workgroup's first transform: absurd strides go one transform per launch
         const long long reach = (long long) (Gm::G - 1) * std::max(k.sstride, k.dstride) + 4LL * Gm::M;
@@ -627,12 +681,12 @@ namespace
                 one.da += dof;
                 if (one.db) one.db += dof;
                 one.batch = 1;
-                hipLaunchKernelGGL((fx_lds_kernel<T, L>), dim3(1), dim3(Gm::THREADS), lds, st, one, tw);
+                hipLaunchKernelGGL(kernel, dim3(1), dim3(Gm::THREADS), lds, st, one, tw);
             }
             return hipGetLastError();
         }
         const long long grid = (k.batch + Gm::G - 1) / Gm::G;
-        hipLaunchKernelGGL((fx_lds_kernel<T, L>), dim3((unsigned) grid), dim3(Gm::THREADS), lds, st, k, tw);
+        hipLaunchKernelGGL(kernel, dim3((unsigned) grid), dim3(Gm::THREADS), lds, st, k, tw);
         return hipGetLastError();
     }
 

@@ -176,6 +176,28 @@ namespace
     __device__ __forceinline__ void fx_put(double2 &v, int j, double x) { if (j == 0) v.x = x; else v.y = x; }
     template <class T> __device__ __forceinline__ bool fx_aligned16(const T *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+    // pass_real_trig_table<true> for the bin pair (k, M - k), k in [0, M/2], on a split spectrum staged in LDS, in place: the
+    // arithmetic of fx_load's L_PRE branch, operand for operand (the pair is read and written by this one thread)
+    template <class T, class C>
+    __device__ __forceinline__ void fx_pre_inplace(LdsBuf<C> d, int k, int M, const C *__restrict__ tw)
+    {
+        if (k == 0)
+        {
+            const C z = d[0];
+            d[0] = C(z.x - z.y, z.x + z.y);
+            return;
+        }
+        const int m = M - k;
+        const C w = tw[k];
+        const T c = -w.x, sn = w.y;
+        const C z1 = d[k], z2 = d[m];
+        const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+        const T u1 = (c * i3) + (sn * r4);
+        const T u2 = (sn * i3) - (c * r4);
+        d[k] = C(u2 + i4, r3 + u1);
+        if (m != k) d[m] = C(u2 - i4, r3 - u1);
+    }
+
     // -------------------------------------------------------------------------------------------- LDS-resident transforms
 
 #ifndef HCV_FX_STAGE_TG
@@ -184,8 +206,9 @@ namespace
 
 
     // second launch bound = waves per SIMD the register budget must allow (HIP semantics): 4 -> 128 VGPRs in float
-    // STAGED (thread groups up to HCV_FX_STAGE_TG threads only): the workgroup's transforms pass through LDS on their way in and
-    // out instead of being loaded into / stored from the butterflies' registers; chosen per launch (launch_lds)
+    // STAGED: thread groups up to HCV_FX_STAGE_TG threads pass the workgroup's transforms through LDS on their way in and out
+    // instead of loading them into / storing them from the butterflies' registers; larger groups stage the real inverse's
+    // pre-pass.  Chosen per launch (launch_lds).
     template <class T, int LOG2M, bool STAGED>
     __global__ __launch_bounds__((FFTGeom<LOG2M>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a0, const typename Cx<T>::type *__restrict__ tw)
     {
@@ -217,7 +240,9 @@ namespace
                 constexpr int V = FxVec<T>::V;
                 const long long left = a0.batch - q0;
                 const int groups = left < G ? (int) left : G;
-                if (a.load == L_SPLIT && M % V == 0 && a.sstride % V == 0 && fx_aligned16(static_cast<const T *>(a.sa)) && fx_aligned16(a.sb))     // (wave-uniform)
+                // (the real inverse's pre-pass, L_PRE, reads the same split arrays: staged raw, combined in LDS below)
+                const bool pre = a.load == L_PRE;
+                if ((a.load == L_SPLIT || pre) && M % V == 0 && a.sstride % V == 0 && fx_aligned16(static_cast<const T *>(a.sa)) && fx_aligned16(a.sb))   // (wave-uniform)
                 {
                     const T *re = static_cast<const T *>(a.sa), *im = a.sb;
                     for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
@@ -232,21 +257,64 @@ namespace
                 }
                 else
                 {
+                    const T *re = static_cast<const T *>(a.sa), *im = a.sb;
                     for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
                     {
                         const int gg = e / M, n = e % M;
-                        LdsBuf<C>{ lds + gg * lds_padded(M) }[n] = fx_load<T, C>(a, gg * (int) a.sstride, n, M, tw);
+                        const int off = gg * (int) a.sstride;
+                        LdsBuf<C>{ lds + gg * lds_padded(M) }[n] = pre ? C(re[off + n], im[off + n]) : fx_load<T, C>(a, off, n, M, tw);
                     }
                 }
                 __syncthreads();
+                if (pre)
+                {
+                    // pass_real_trig_table<true> on the staged spectrum, in place: the thread that owns the bin pair (k, M - k)
+                    // reads both and writes both (the arithmetic of fx_load's L_PRE branch, operand for operand)
+                    for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
+                    {
+                        const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
+                        fx_pre_inplace<T, C>(LdsBuf<C>{ lds + gg * lds_padded(M) }, k, M, tw);
+                    }
+                    __syncthreads();
+                }
                 LdsFFT<LOG2M, TG, C>::run(s, t, tw);
-                if (a.store == S_POST)
+                const bool vec_out = M % V == 0 && a.dstride % V == 0 && fx_aligned16(a.da) && fx_aligned16(a.db);                                   // (wave-uniform)
+                if (a.store == S_POST && vec_out)
+                {
+                    // pass_real_trig_table<false> in place (fx_post's arithmetic, operand for operand; bin M/2 keeps the value
+                    // fx_post's second pair of stores leaves there), then out as vectors below
+                    for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
+                    {
+                        const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
+                        const LdsBuf<C> d = { lds + gg * lds_padded(M) };
+                        if (k == 0)
+                        {
+                            const C z = d[0];
+                            const T t1 = z.x + z.y, t2 = z.x - z.y;
+                            d[0] = C(t1 + t1, t2 + t2);
+                        }
+                        else
+                        {
+                            const int m = M - k;
+                            const C w = tw[k];
+                            const C z1 = d[k], z2 = d[m];
+                            const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+                            const T u1 = (w.x * i3) + (w.y * r4);
+                            const T u2 = (w.y * i3) - (w.x * r4);
+                            if (m != k) d[k] = C(r3 + u1, u2 + i4);
+                            d[m] = C(r3 - u1, u2 - i4);
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (a.store == S_POST && !vec_out)
                 {
                     if (live)
                         for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, doff, k, M, s[k], s[(M - k) & (M - 1)], tw);
                 }
-                else if (a.store == S_SPLIT && M % V == 0 && a.dstride % V == 0 && fx_aligned16(a.da) && fx_aligned16(a.db))                        // (wave-uniform)
+                else if ((a.store == S_SPLIT || a.store == S_POST) && vec_out)
                 {
+                    const bool swap = a.store == S_SPLIT && a.swap_out;
                     for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
                     {
                         const int gg = e / (M / V), k = (e % (M / V)) * V;
@@ -257,8 +325,8 @@ namespace
                         for (int j = 0; j < V; j++)
                         {
                             const C v = b[k + j];
-                            fx_put(vr, j, a.swap_out ? v.y : v.x);
-                            fx_put(vi, j, a.swap_out ? v.x : v.y);
+                            fx_put(vr, j, swap ? v.y : v.x);
+                            fx_put(vi, j, swap ? v.x : v.y);
                         }
                         *reinterpret_cast<VT *>(a.da + idx) = vr;
                         *reinterpret_cast<VT *>(a.db + idx) = vi;
@@ -272,6 +340,33 @@ namespace
                         fx_store<T, C>(a, gg * (int) a.dstride, k, LdsBuf<C>{ lds + gg * lds_padded(M) }[k]);
                     }
                 }
+                return;
+            }
+        }
+        if constexpr (UNI && STAGED)
+        {
+            // The real inverse's pre-pass straight into the butterflies costs four scattered loads and a twiddle per element
+            // (bins k and M - k of both arrays).  The group instead stages its split spectrum in LDS as 16-byte vectors,
+            // combines the bin pairs there, and runs the transform from LDS (2^12: 3.0 -> see DESIGN section 7).
+            typedef typename FxVec<T>::type VT;
+            constexpr int V = FxVec<T>::V;
+            if (a0.load == L_PRE && a0.store != S_POST && M % V == 0 && a0.sstride % V == 0 && fx_aligned16(static_cast<const T *>(a0.sa)) && fx_aligned16(a0.sb))   // (workgroup-uniform)
+            {
+                if (live)
+                {
+                    const T *re = static_cast<const T *>(a.sa), *im = a.sb;
+                    for (int e = t; e < M / V; e += TG)
+                    {
+                        const VT vr = reinterpret_cast<const VT *>(re)[e], vi = reinterpret_cast<const VT *>(im)[e];
+#pragma unroll
+                        for (int j = 0; j < V; j++) s[e * V + j] = C(fx_get(vr, j), fx_get(vi, j));
+                    }
+                }
+                __syncthreads();
+                if (live)
+                    for (int k = t; k <= M / 2; k += TG) fx_pre_inplace<T, C>(s, k, M, tw);
+                __syncthreads();
+                LdsFFT<LOG2M, TG, C>::run(LdsIO<C>{ s }, FxStore<T>{ a, doff, live }, s, t, tw);
                 return;
             }
         }
@@ -660,12 +755,11 @@ namespace
         typedef typename Cx<T>::type C;
         typedef FFTGeom<L> Gm;
         const size_t lds = sizeof(C) * lds_padded(Gm::M) * Gm::G;
-        // thread groups of 8 - 32 are staged too (2^7 ... 2^9: 3.2 - 4.0 -> 5.1 - 5.5 TB/s) unless the input is the real inverse's
-        // pre-pass, whose element-wise loads are slower staged than straight into the butterflies (3.4 -> 2.9 TB/s)
-        const bool staged = Gm::TG <= 4 || (Gm::TG <= HCV_FX_STAGE_TG && k.load != L_PRE);
+        // thread groups of up to 32 threads (2^9 points) are staged: 2^7 ... 2^9 3.2 - 4.0 -> 4.8 - 5.5 TB/s
+        // (larger groups: the instantiation that stages the real inverse's pre-pass, for those launches only — it costs the
+        // plain path registers)
         void (*kernel)(FxK<T>, const C *) = fx_lds_kernel<T, L, false>;
-        if constexpr (Gm::TG <= HCV_FX_STAGE_TG)
-            if (staged) kernel = fx_lds_kernel<T, L, true>;
+        if (Gm::TG <= HCV_FX_STAGE_TG || (k.load == L_PRE && k.store != S_POST)) kernel = fx_lds_kernel<T, L, true>;
         hipError_t e = allow_big_lds(kernel, lds);
         if (e != hipSuccess) return e;
         // lane addressing is 32-bit relative to the workgroup's first transform: absurd strides go one transform per launch

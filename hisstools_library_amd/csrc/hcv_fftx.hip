@@ -71,14 +71,21 @@ namespace
         }
         if (a.load == L_ZIP)
         {
+            // (the pair of samples as ONE load of twice the width where it lies inside the input and is aligned)
             const int i0 = 2 * n;
             if (a.src_f32)
             {
-                const float *x = static_cast<const float *>(a.sa);
-                return C(i0 < a.in_len ? (T) x[off + i0] : (T) 0, i0 + 1 < a.in_len ? (T) x[off + i0 + 1] : (T) 0);
+                const float *x = static_cast<const float *>(a.sa) + off + i0;
+                if (i0 + 1 < a.in_len && (reinterpret_cast<uintptr_t>(x) & 7) == 0)
+                {
+                    const float2 v = *reinterpret_cast<const float2 *>(x);
+                    return C((T) v.x, (T) v.y);
+                }
+                return C(i0 < a.in_len ? (T) x[0] : (T) 0, i0 + 1 < a.in_len ? (T) x[1] : (T) 0);
             }
-            const T *x = static_cast<const T *>(a.sa);
-            return C(i0 < a.in_len ? x[off + i0] : (T) 0, i0 + 1 < a.in_len ? x[off + i0 + 1] : (T) 0);
+            const T *x = static_cast<const T *>(a.sa) + off + i0;
+            if (i0 + 1 < a.in_len && (reinterpret_cast<uintptr_t>(x) & (2 * sizeof(T) - 1)) == 0) return *reinterpret_cast<const C *>(x);
+            return C(i0 < a.in_len ? x[0] : (T) 0, i0 + 1 < a.in_len ? x[1] : (T) 0);
         }
         // L_PRE: pass_real_trig_table<true> (Core.h:934-988), delivered with re/im exchanged so that the forward
         // transform that follows acts as the inverse (Core.h:1341-1346)
@@ -198,6 +205,29 @@ namespace
         if (m != k) d[m] = C(u2 - i4, r3 - u1);
     }
 
+    // pass_real_trig_table<false> for the bin pair (k, M - k), k in [0, M/2], in place on a transform's result in LDS (real part
+    // -> .x, imaginary -> .y of the split output): fx_post's arithmetic, operand for operand; bin M/2 keeps the value fx_post's
+    // second pair of stores leaves there
+    template <class T, class C>
+    __device__ __forceinline__ void fx_post_inplace(LdsBuf<C> d, int k, int M, const C *__restrict__ tw)
+    {
+        if (k == 0)
+        {
+            const C z = d[0];
+            const T t1 = z.x + z.y, t2 = z.x - z.y;
+            d[0] = C(t1 + t1, t2 + t2);
+            return;
+        }
+        const int m = M - k;
+        const C w = tw[k];
+        const C z1 = d[k], z2 = d[m];
+        const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
+        const T u1 = (w.x * i3) + (w.y * r4);
+        const T u2 = (w.y * i3) - (w.x * r4);
+        if (m != k) d[k] = C(r3 + u1, u2 + i4);
+        d[m] = C(r3 - u1, u2 - i4);
+    }
+
     // -------------------------------------------------------------------------------------------- LDS-resident transforms
 
 #ifndef HCV_FX_STAGE_TG
@@ -208,7 +238,8 @@ namespace
     // second launch bound = waves per SIMD the register budget must allow (HIP semantics): 4 -> 128 VGPRs in float
     // STAGED: thread groups up to HCV_FX_STAGE_TG threads pass the workgroup's transforms through LDS on their way in and out
     // instead of loading them into / storing them from the butterflies' registers; larger groups stage the real inverse's
-    // pre-pass.  Chosen per launch (launch_lds).
+    // pre-pass (the forward transform's post-pass the same way measured slower there: 2^11 4.4 -> 4.1 TB/s, 2^15 2.5 -> 2.2).
+    // Chosen per launch (launch_lds).
     template <class T, int LOG2M, bool STAGED>
     __global__ __launch_bounds__((FFTGeom<LOG2M>::THREADS), (sizeof(T) == 4 ? 4 : 2)) void fx_lds_kernel(FxK<T> a0, const typename Cx<T>::type *__restrict__ tw)
     {
@@ -286,24 +317,7 @@ namespace
                     for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
                     {
                         const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
-                        const LdsBuf<C> d = { lds + gg * lds_padded(M) };
-                        if (k == 0)
-                        {
-                            const C z = d[0];
-                            const T t1 = z.x + z.y, t2 = z.x - z.y;
-                            d[0] = C(t1 + t1, t2 + t2);
-                        }
-                        else
-                        {
-                            const int m = M - k;
-                            const C w = tw[k];
-                            const C z1 = d[k], z2 = d[m];
-                            const T r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
-                            const T u1 = (w.x * i3) + (w.y * r4);
-                            const T u2 = (w.y * i3) - (w.x * r4);
-                            if (m != k) d[k] = C(r3 + u1, u2 + i4);
-                            d[m] = C(r3 - u1, u2 - i4);
-                        }
+                        fx_post_inplace<T, C>(LdsBuf<C>{ lds + gg * lds_padded(M) }, k, M, tw);
                     }
                     __syncthreads();
                 }

@@ -773,7 +773,8 @@ namespace
         // (larger groups: the instantiation that stages the real inverse's pre-pass, for those launches only — it costs the
         // plain path registers)
         void (*kernel)(FxK<T>, const C *) = fx_lds_kernel<T, L, false>;
-        if (Gm::TG <= HCV_FX_STAGE_TG || (k.load == L_PRE && k.store != S_POST)) kernel = fx_lds_kernel<T, L, true>;
+        // (not the 1024-thread groups, one 2^14-point transform per CU: 2.27 -> 1.9 - 2.3 TB/s with the two extra barriers)
+        if (Gm::TG <= HCV_FX_STAGE_TG || (k.load == L_PRE && k.store != S_POST && Gm::TG < 1024)) kernel = fx_lds_kernel<T, L, true>;
         hipError_t e = allow_big_lds(kernel, lds);
         if (e != hipSuccess) return e;
         // lane addressing is 32-bit relative to the workgroup's first transform: absurd strides go one transform per launch

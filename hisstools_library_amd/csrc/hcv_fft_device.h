@@ -11,9 +11,24 @@ namespace hcv
 // small helpers
 // ------------------------------------------------------------------------------------------------
 
+// Complex float arithmetic is written on 2-vectors (re, im): the adds are then one v_pk_add_f32 each and the products two
+// packed instructions with the broadcast / swap in their operand selects.  Left as scalar component arithmetic the SLP
+// vectoriser pairs components of DIFFERENT values and pays for it in register moves (a third of the vector instructions of
+// the LDS transform kernels).  HCV_FFT_PACKED=0 keeps the component forms.
+#ifndef HCV_FFT_PACKED
+#define HCV_FFT_PACKED 1
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cmulv(v2f a, v2f b) { return a.xx * b + a.yy * v2f{ -b.y, b.x }; }
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
+#if HCV_FFT_PACKED
+    const v2f r = cmulv(v2f{ a.x, a.y }, v2f{ b.x, b.y });
+    return make_float2(r.x, r.y);
+#else
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
 }
 
 // 16-byte streaming load that bypasses cache retention (global_load_dwordx4 ... nt)
@@ -113,6 +128,62 @@ template <bool ONES, class C> __device__ __forceinline__ void dft16(C *u, C w1, 
 #pragma unroll
     for (int q1 = 0; q1 < 4; q1++) radix4(u[4 * q1], u[4 * q1 + 1], u[4 * q1 + 2], u[4 * q1 + 3]);   // u[4 q1 + q2] = X[q1 + 4 q2]
 }
+
+// The radix-16 and radix-4 butterflies for float on 2-vectors (see cmul above).
+#if HCV_FFT_PACKED
+__device__ __forceinline__ v2f mulkv(v2f v, float cr, float ci) { return v.xx * v2f{ cr, ci } + v.yy * v2f{ -ci, cr }; }
+__device__ __forceinline__ void radix4v(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
+{
+    const v2f a = x0 + x2, c = x0 - x2, e = x1 + x3, f = x1 - x3;
+    const v2f d = v2f{ f.y, -f.x };                          // -i * (x1 - x3)
+    x0 = a + e;
+    x1 = c + d;
+    x2 = a - e;
+    x3 = c - d;
+}
+__device__ __forceinline__ void radix4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
+{
+    v2f a = v2f{ x0.x, x0.y }, b = v2f{ x1.x, x1.y }, c = v2f{ x2.x, x2.y }, d = v2f{ x3.x, x3.y };
+    radix4v(a, b, c, d);
+    x0 = make_float2(a.x, a.y);
+    x1 = make_float2(b.x, b.y);
+    x2 = make_float2(c.x, c.y);
+    x3 = make_float2(d.x, d.y);
+}
+template <bool ONES> __device__ __forceinline__ void dft16(float2 *u, float2 w1, float2 w2, float2 w3)
+{
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    v2f v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = v2f{ u[i].x, u[i].y };
+#pragma unroll
+    for (int b = 0; b < 4; b++) radix4v(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    if (!ONES)
+    {
+        const v2f t1 = v2f{ w1.x, w1.y }, t2 = v2f{ w2.x, w2.y }, t3 = v2f{ w3.x, w3.y };
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++)
+        {
+            v[4 * q1 + 1] = cmulv(v[4 * q1 + 1], t1);
+            v[4 * q1 + 2] = cmulv(v[4 * q1 + 2], t2);
+            v[4 * q1 + 3] = cmulv(v[4 * q1 + 3], t3);
+        }
+    }
+    v[4 + 1] = mulkv(v[4 + 1], c1, -s1);
+    v[4 + 2] = mulkv(v[4 + 2], h, -h);
+    v[4 + 3] = mulkv(v[4 + 3], s1, -c1);
+    v[8 + 1] = mulkv(v[8 + 1], h, -h);
+    v[8 + 2] = v2f{ v[8 + 2].y, -v[8 + 2].x };
+    v[8 + 3] = mulkv(v[8 + 3], -h, -h);
+    v[12 + 1] = mulkv(v[12 + 1], s1, -c1);
+    v[12 + 2] = mulkv(v[12 + 2], -h, -h);
+    v[12 + 3] = mulkv(v[12 + 3], -c1, s1);
+#pragma unroll
+    for (int q1 = 0; q1 < 4; q1++) radix4v(v[4 * q1], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) u[i] = make_float2(v[i].x, v[i].y);
+}
+#endif
 
 // Where a pass takes its inputs from / puts its outputs: the LDS buffer itself ...
 template <class C> struct LdsIO

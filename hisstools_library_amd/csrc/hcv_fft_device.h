@@ -18,6 +18,12 @@ namespace hcv
 #ifndef HCV_FFT_PACKED
 #define HCV_FFT_PACKED 1
 #endif
+#ifndef HCV_FFT_RADIX8
+#define HCV_FFT_RADIX8 1        // log2 sizes 4n + 3, float, last pass stored directly: one radix-8 tail pass instead of radix-4 +
+                                // radix-2 (LdsFFT::run).  Complex 2^11 +4 %, real inverse 2^12 +6-8 %; NOT where the last pass goes
+                                // back to LDS (the real forward transform: -4 %) and not in double (156 registers instead of 130:
+                                // real forward 2^12 -12 %): profiles/r02_fft_radix8_ab.txt
+#endif
 #ifndef HCV_FFT_RADIX32
 #define HCV_FFT_RADIX32 1       // odd log2 sizes: a radix-32 first pass instead of a radix-2 tail (LdsFFT::run)
 #endif
@@ -395,6 +401,69 @@ struct LdsFFT
         if (Dst::is_lds) __syncthreads();
     }
 
+    // Radix-8 pass for LOG2M = 4 n + 3: the radix-4 and radix-2 tails in one trip through LDS.  X[q] = E[q] + W8^q O[q],
+    // X[q + 4] = E[q] - W8^q O[q] with E / O the 4-point DFTs of the (twiddled) even / odd inputs; two butterflies per thread.
+    static constexpr int NB8 = M / 8 > 0 ? M / 8 : 1;
+    static constexpr int BPT8 = (NB8 + TG - 1) / TG;
+    template <class Src, class Dst>
+    __device__ static __forceinline__ void pass8(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
+    {
+        typedef decltype(C().x) R;
+        const R h = (R) 0.70710678118654752440;
+        C u[BPT8][8];
+        C tw7[BPT8][7];                                     // (table loads in front of the LDS reads and the barrier, as in pass16)
+#pragma unroll
+        for (int b = 0; b < BPT8; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB8 % TG == 0 || i < NB8)
+            {
+                const int step = (i & (p - 1)) * ((2 * M) / (8 * p));
+#pragma unroll
+                for (int r = 1; r < 8; r++) tw7[b][r - 1] = root<LOG2M>(tw, r * step);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BPT8; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB8 % TG == 0 || i < NB8)
+            {
+#pragma unroll
+                for (int r = 0; r < 8; r++) u[b][r] = src(i + r * NB8);
+            }
+        }
+        if (Src::is_lds && Dst::is_lds) __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BPT8; b++)
+        {
+            const int i = tid + b * TG;
+            if (NB8 % TG == 0 || i < NB8)
+            {
+                const int k = i & (p - 1);
+                const int j = ((i - k) << 3) + k;
+#pragma unroll
+                for (int r = 1; r < 8; r++) u[b][r] = cmul(u[b][r], tw7[b][r - 1]);
+                radix4(u[b][0], u[b][2], u[b][4], u[b][6]);          // E[0..3] in slots 0, 2, 4, 6
+                radix4(u[b][1], u[b][3], u[b][5], u[b][7]);          // O[0..3] in slots 1, 3, 5, 7
+                const C o0 = u[b][1];
+                const C o1 = mulk(u[b][3], h, -h);
+                const C o2 = C(u[b][5].y, -u[b][5].x);
+                const C o3 = mulk(u[b][7], -h, -h);
+                const C e0 = u[b][0], e1 = u[b][2], e2 = u[b][4], e3 = u[b][6];
+                dst(j, C(e0.x + o0.x, e0.y + o0.y));
+                dst(j + p, C(e1.x + o1.x, e1.y + o1.y));
+                dst(j + 2 * p, C(e2.x + o2.x, e2.y + o2.y));
+                dst(j + 3 * p, C(e3.x + o3.x, e3.y + o3.y));
+                dst(j + 4 * p, C(e0.x - o0.x, e0.y - o0.y));
+                dst(j + 5 * p, C(e1.x - o1.x, e1.y - o1.y));
+                dst(j + 6 * p, C(e2.x - o2.x, e2.y - o2.y));
+                dst(j + 7 * p, C(e3.x - o3.x, e3.y - o3.y));
+            }
+        }
+        if (Dst::is_lds) __syncthreads();
+    }
+
     template <class Src, class Dst>
     __device__ static __forceinline__ void pass2(const Src &src, const Dst &dst, int tid, const C *__restrict__ tw, int p)
     {
@@ -485,6 +554,13 @@ struct LdsFFT
                 }
             }
         }
+#if HCV_FFT_RADIX8
+        if constexpr (TAIL4 && TAIL2 && N16 >= 1 && !St::is_lds && sizeof(C) == 8)
+        {
+            pass8(io, st, tid, tw, p);
+            return;
+        }
+#endif
         if constexpr (TAIL4)
         {
             if constexpr (N16 == 0)

@@ -603,6 +603,9 @@ template <int LOG2M, int WG = 256> struct FFTGeom
 // Tile of one four-step workgroup: TILE adjacent columns (or rows) of P points each, all transformed at once by
 // TILE * TG threads (at most 1024).  TILE aims at 128-byte runs in each of the split arrays, within 128 KiB of LDS
 // (136 KiB with the bank padding).
+#ifndef HCV_FX_TILE_CAP64
+#define HCV_FX_TILE_CAP64 1
+#endif
 #ifndef HCV_FX_TILE_BYTES
 #define HCV_FX_TILE_BYTES 256
 #endif
@@ -610,7 +613,9 @@ template <int P, int ELEM_BYTES> struct FourStepTile
 {
     static constexpr int TG = P / 16 < 256 ? P / 16 : 256;
     static constexpr int WANT = HCV_FX_TILE_BYTES / ELEM_BYTES;         // complex elements: 128 bytes per split array
-    static constexpr int CAP = 128 * 1024 / (P * ELEM_BYTES);
+    // LDS budget per tile: 64 KiB (two workgroups per CU) while that still leaves 64-byte runs, else 128 KiB (one)
+    static constexpr int CAP64 = 64 * 1024 / (P * ELEM_BYTES), CAP128 = 128 * 1024 / (P * ELEM_BYTES);
+    static constexpr int CAP = (HCV_FX_TILE_CAP64 && CAP64 * ELEM_BYTES >= 128) ? CAP64 : CAP128;
     static constexpr int TILE = CAP < WANT ? CAP : WANT;
     static constexpr int THREADS = TILE * TG < 1024 ? TILE * TG : 1024;
     static constexpr int G = THREADS / TG;                              // sub-transforms in flight

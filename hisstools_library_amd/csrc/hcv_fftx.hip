@@ -261,101 +261,99 @@ namespace
         const LdsBuf<C> s = { lds + g * lds_padded(M) };
         if constexpr (STAGED && TG <= HCV_FX_STAGE_TG)
         {
+            // Sixteen or more transforms per wave (M <= 64; measured: 2^4 1.4 -> 3.8 TB/s, 2^6 +13 %): with one butterfly's
+            // operands per lane a load instruction would touch 16 cache lines for 256 useful bytes.  The workgroup instead
+            // moves its G transforms through LDS with consecutive lanes on consecutive elements (one contiguous run when the
+            // batch is dense), in both directions — as 16-byte vectors of the split arrays where strides and alignment allow
+            // (a quarter of the memory instructions for the same bytes).
+            typedef typename FxVec<T>::type VT;
+            constexpr int V = FxVec<T>::V;
+            const long long left = a0.batch - q0;
+            const int groups = left < G ? (int) left : G;
+            // (the real inverse's pre-pass, L_PRE, reads the same split arrays: staged raw, combined in LDS below)
+            const bool pre = a.load == L_PRE;
+            if ((a.load == L_SPLIT || pre) && M % V == 0 && a.sstride % V == 0 && fx_aligned16(static_cast<const T *>(a.sa)) && fx_aligned16(a.sb))   // (wave-uniform)
             {
-                // Sixteen or more transforms per wave (M <= 64; measured: 2^4 1.4 -> 3.8 TB/s, 2^6 +13 %): with one butterfly's
-                // operands per lane a load instruction would touch 16 cache lines for 256 useful bytes.  The workgroup instead
-                // moves its G transforms through LDS with consecutive lanes on consecutive elements (one contiguous run when the
-                // batch is dense), in both directions — as 16-byte vectors of the split arrays where strides and alignment allow
-                // (a quarter of the memory instructions for the same bytes).
-                typedef typename FxVec<T>::type VT;
-                constexpr int V = FxVec<T>::V;
-                const long long left = a0.batch - q0;
-                const int groups = left < G ? (int) left : G;
-                // (the real inverse's pre-pass, L_PRE, reads the same split arrays: staged raw, combined in LDS below)
-                const bool pre = a.load == L_PRE;
-                if ((a.load == L_SPLIT || pre) && M % V == 0 && a.sstride % V == 0 && fx_aligned16(static_cast<const T *>(a.sa)) && fx_aligned16(a.sb))   // (wave-uniform)
+                const T *re = static_cast<const T *>(a.sa), *im = a.sb;
+                for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
                 {
-                    const T *re = static_cast<const T *>(a.sa), *im = a.sb;
-                    for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
-                    {
-                        const int gg = e / (M / V), n = (e % (M / V)) * V;
-                        const long long idx = (long long) gg * a.sstride + n;
-                        const VT vr = *reinterpret_cast<const VT *>(re + idx), vi = *reinterpret_cast<const VT *>(im + idx);
-                        const LdsBuf<C> d = { lds + gg * lds_padded(M) };
-    #pragma unroll
-                        for (int j = 0; j < V; j++) d[n + j] = C(fx_get(vr, j), fx_get(vi, j));
-                    }
+                    const int gg = e / (M / V), n = (e % (M / V)) * V;
+                    const long long idx = (long long) gg * a.sstride + n;
+                    const VT vr = *reinterpret_cast<const VT *>(re + idx), vi = *reinterpret_cast<const VT *>(im + idx);
+                    const LdsBuf<C> d = { lds + gg * lds_padded(M) };
+#pragma unroll
+                    for (int j = 0; j < V; j++) d[n + j] = C(fx_get(vr, j), fx_get(vi, j));
                 }
-                else
+            }
+            else
+            {
+                const T *re = static_cast<const T *>(a.sa), *im = a.sb;
+                for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
                 {
-                    const T *re = static_cast<const T *>(a.sa), *im = a.sb;
-                    for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
-                    {
-                        const int gg = e / M, n = e % M;
-                        const int off = gg * (int) a.sstride;
-                        LdsBuf<C>{ lds + gg * lds_padded(M) }[n] = pre ? C(re[off + n], im[off + n]) : fx_load<T, C>(a, off, n, M, tw);
-                    }
+                    const int gg = e / M, n = e % M;
+                    const int off = gg * (int) a.sstride;
+                    LdsBuf<C>{ lds + gg * lds_padded(M) }[n] = pre ? C(re[off + n], im[off + n]) : fx_load<T, C>(a, off, n, M, tw);
+                }
+            }
+            __syncthreads();
+            if (pre)
+            {
+                // pass_real_trig_table<true> on the staged spectrum, in place: the thread that owns the bin pair (k, M - k)
+                // reads both and writes both (the arithmetic of fx_load's L_PRE branch, operand for operand)
+                for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
+                {
+                    const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
+                    fx_pre_inplace<T, C>(LdsBuf<C>{ lds + gg * lds_padded(M) }, k, M, tw);
                 }
                 __syncthreads();
-                if (pre)
-                {
-                    // pass_real_trig_table<true> on the staged spectrum, in place: the thread that owns the bin pair (k, M - k)
-                    // reads both and writes both (the arithmetic of fx_load's L_PRE branch, operand for operand)
-                    for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
-                    {
-                        const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
-                        fx_pre_inplace<T, C>(LdsBuf<C>{ lds + gg * lds_padded(M) }, k, M, tw);
-                    }
-                    __syncthreads();
-                }
-                LdsFFT<LOG2M, TG, C>::run(s, t, tw);
-                const bool vec_out = M % V == 0 && a.dstride % V == 0 && fx_aligned16(a.da) && fx_aligned16(a.db);                                   // (wave-uniform)
-                if (a.store == S_POST && vec_out)
-                {
-                    // pass_real_trig_table<false> in place (fx_post's arithmetic, operand for operand; bin M/2 keeps the value
-                    // fx_post's second pair of stores leaves there), then out as vectors below
-                    for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
-                    {
-                        const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
-                        fx_post_inplace<T, C>(LdsBuf<C>{ lds + gg * lds_padded(M) }, k, M, tw);
-                    }
-                    __syncthreads();
-                }
-                if (a.store == S_POST && !vec_out)
-                {
-                    if (live)
-                        for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, doff, k, M, s[k], s[(M - k) & (M - 1)], tw);
-                }
-                else if ((a.store == S_SPLIT || a.store == S_POST) && vec_out)
-                {
-                    const bool swap = a.store == S_SPLIT && a.swap_out;
-                    for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
-                    {
-                        const int gg = e / (M / V), k = (e % (M / V)) * V;
-                        const long long idx = (long long) gg * a.dstride + k;
-                        const LdsBuf<C> b = { lds + gg * lds_padded(M) };
-                        VT vr, vi;
-    #pragma unroll
-                        for (int j = 0; j < V; j++)
-                        {
-                            const C v = b[k + j];
-                            fx_put(vr, j, swap ? v.y : v.x);
-                            fx_put(vi, j, swap ? v.x : v.y);
-                        }
-                        *reinterpret_cast<VT *>(a.da + idx) = vr;
-                        *reinterpret_cast<VT *>(a.db + idx) = vi;
-                    }
-                }
-                else
-                {
-                    for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
-                    {
-                        const int gg = e / M, k = e % M;
-                        fx_store<T, C>(a, gg * (int) a.dstride, k, LdsBuf<C>{ lds + gg * lds_padded(M) }[k]);
-                    }
-                }
-                return;
             }
+            LdsFFT<LOG2M, TG, C>::run(s, t, tw);
+            const bool vec_out = M % V == 0 && a.dstride % V == 0 && fx_aligned16(a.da) && fx_aligned16(a.db);                                   // (wave-uniform)
+            if (a.store == S_POST && vec_out)
+            {
+                // pass_real_trig_table<false> in place (fx_post's arithmetic, operand for operand; bin M/2 keeps the value
+                // fx_post's second pair of stores leaves there), then out as vectors below
+                for (int e = threadIdx.x; e < groups * (M / 2 + 1); e += Gm::THREADS)
+                {
+                    const int gg = e / (M / 2 + 1), k = e % (M / 2 + 1);
+                    fx_post_inplace<T, C>(LdsBuf<C>{ lds + gg * lds_padded(M) }, k, M, tw);
+                }
+                __syncthreads();
+            }
+            if (a.store == S_POST && !vec_out)
+            {
+                if (live)
+                    for (int k = t; k <= M / 2; k += TG) fx_post<T, C>(a, doff, k, M, s[k], s[(M - k) & (M - 1)], tw);
+            }
+            else if ((a.store == S_SPLIT || a.store == S_POST) && vec_out)
+            {
+                const bool swap = a.store == S_SPLIT && a.swap_out;
+                for (int e = threadIdx.x; e < groups * (M / V); e += Gm::THREADS)
+                {
+                    const int gg = e / (M / V), k = (e % (M / V)) * V;
+                    const long long idx = (long long) gg * a.dstride + k;
+                    const LdsBuf<C> b = { lds + gg * lds_padded(M) };
+                    VT vr, vi;
+#pragma unroll
+                    for (int j = 0; j < V; j++)
+                    {
+                        const C v = b[k + j];
+                        fx_put(vr, j, swap ? v.y : v.x);
+                        fx_put(vi, j, swap ? v.x : v.y);
+                    }
+                    *reinterpret_cast<VT *>(a.da + idx) = vr;
+                    *reinterpret_cast<VT *>(a.db + idx) = vi;
+                }
+            }
+            else
+            {
+                for (int e = threadIdx.x; e < groups * M; e += Gm::THREADS)
+                {
+                    const int gg = e / M, k = e % M;
+                    fx_store<T, C>(a, gg * (int) a.dstride, k, LdsBuf<C>{ lds + gg * lds_padded(M) }[k]);
+                }
+            }
+            return;
         }
         if constexpr (UNI && STAGED)
         {

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace hcv
 {
 
@@ -17,6 +19,9 @@ namespace hcv
 // the LDS transform kernels).  HCV_FFT_PACKED=0 keeps the component forms.
 #ifndef HCV_FFT_PACKED
 #define HCV_FFT_PACKED 1
+#endif
+#ifndef HCV_FFT_LDS_BASE
+#define HCV_FFT_LDS_BASE 1      // radix-16 / radix-32 passes address LDS as one padded base + constant multiples (LdsFFT::pass16)
 #endif
 #ifndef HCV_FFT_RADIX8
 #define HCV_FFT_RADIX8 1        // log2 sizes 4n + 3, float, last pass stored directly: one radix-8 tail pass instead of radix-4 +
@@ -257,8 +262,19 @@ struct LdsFFT
             const int i = tid + b * TG;
             if (NB16 % TG == 0 || i < NB16)
             {
+                if constexpr (std::is_same<Src, LdsIO<C>>::value && NB16 % 16 == 0 && HCV_FFT_LDS_BASE)
+                {
+                    // (the padded index of i + r NB16 is that of i plus r (NB16 + NB16 / 16) — NB16 is a multiple of 16 —
+                    // so the sixteen reads are one base address and compile-time offsets instead of a shift and an add each)
+                    const C *bp = src.s.base + (i + (i >> 4));
 #pragma unroll
-                for (int r = 0; r < 16; r++) u[b][r] = src(i + r * NB16);
+                    for (int r = 0; r < 16; r++) u[b][r] = bp[r * (NB16 + NB16 / 16)];
+                }
+                else
+                {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) u[b][r] = src(i + r * NB16);
+                }
             }
         }
         if (Src::is_lds && Dst::is_lds) __syncthreads();
@@ -285,10 +301,24 @@ struct LdsFFT
                     }
                     dft16<false>(u[b], tw6[b][0], tw6[b][1], tw6[b][2]);
                 }
+                if constexpr (std::is_same<Dst, LdsIO<C>>::value && HCV_FFT_LDS_BASE)
+                {
+                    // (likewise the writes: bin q goes to j + q p; p = 1 in the first pass with j a multiple of 16, else p is a
+                    // multiple of 16: one padded base and q times a per-pass stride)
+                    C *bp = dst.s.base + (j + (j >> 4));
+                    const int pp = FIRST ? 1 : p + (p >> 4);
 #pragma unroll
-                for (int q2 = 0; q2 < 4; q2++)
+                    for (int q2 = 0; q2 < 4; q2++)
 #pragma unroll
-                    for (int q1 = 0; q1 < 4; q1++) dst(j + (q1 + 4 * q2) * p, u[b][4 * q1 + q2]);
+                        for (int q1 = 0; q1 < 4; q1++) bp[(q1 + 4 * q2) * pp] = u[b][4 * q1 + q2];
+                }
+                else
+                {
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                        for (int q1 = 0; q1 < 4; q1++) dst(j + (q1 + 4 * q2) * p, u[b][4 * q1 + q2]);
+                }
             }
         }
         if (Dst::is_lds) __syncthreads();
@@ -345,8 +375,17 @@ struct LdsFFT
                     {
                         const int q = q1 + 4 * q2, at = 4 * q1 + q2;             // (dft16 leaves bin q1 + 4 q2 in slot 4 q1 + q2)
                         const C t = (q == 0) ? o[b][at] : mulk(o[b][at], (R) CS[q], (R) -SN[q]);
-                        dst(j + q, C(e[b][at].x + t.x, e[b][at].y + t.y));
-                        dst(j + q + 16, C(e[b][at].x - t.x, e[b][at].y - t.y));
+                        if constexpr (std::is_same<Dst, LdsIO<C>>::value && HCV_FFT_LDS_BASE)
+                        {
+                            C *bp = dst.s.base + (j + (j >> 4));                   // (j is a multiple of 32: offsets q + (q >> 4))
+                            bp[q] = C(e[b][at].x + t.x, e[b][at].y + t.y);
+                            bp[q + 17] = C(e[b][at].x - t.x, e[b][at].y - t.y);
+                        }
+                        else
+                        {
+                            dst(j + q, C(e[b][at].x + t.x, e[b][at].y + t.y));
+                            dst(j + q + 16, C(e[b][at].x - t.x, e[b][at].y - t.y));
+                        }
                     }
             }
         }

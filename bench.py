@@ -34,6 +34,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU):
 `--sharding grid` forces the input split on weak scaling too ((N/2) x 2 ranks).  BENCH_BACKEND=gloo lets several ranks
 share one GPU to check the paths on a one-GPU box.
 
+On one GPU the default run also carries `config.also`: the digest (value, roofline, self-check error) of a child bench of the
+64x64 / 10 s @ 48 kHz shape north_star states its HBM target on (`--also ""` skips it, `--also c4` picks another workload).
+
 The CPU baseline leg (rank 0, N = 1 only) times the UNMODIFIED reference (oracle/_ref, when the prebuilt library
 travelled with the repo; else the C port) on a bounded sub-matrix of the same workload on one host core.
 """
@@ -303,6 +306,10 @@ def main():
     ap.add_argument("--no-self-check", action="store_true", help="skip the comparison with the CPU leg's output after the timed region")
     ap.add_argument("--realtime-block", type=int, default=128,
                     help="also measure paced real-time calls of this many samples through the host-pointer and device-pointer entry points (0 = skip)")
+    ap.add_argument("--also", default="ns64",
+                    help="one GPU only: after the headline, run this workload too (a child bench with its own self-check against the CPU "
+                         "reference; no batched / real-time / extended legs) and attach its digest as config.also — by default the 64x64 / "
+                         "10 s @ 48 kHz shape north_star sets the HBM target on ('' = skip; skipped when it is the headline itself)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -668,10 +675,39 @@ def main():
             line["cpu_baseline"] = cpu
         if cpu_all is not None:
             line["cpu_baseline_all_cores"] = cpu_all
+        if args.also and args.also != args.workload and world == 1 and not args.ir_file:
+            line["config"]["also"] = also_leg(args.also, local)
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def also_leg(workload, device, steps=40, warmup=5, timeout=420):
+    """A second workload after the headline, in a child process (its own engine, inputs, timed region and self-check against the
+    reference CPU leg): the digest of the child's bench line.  Never takes the headline down."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "",
+           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "0", "--realtime-block", "0"]
+    env = dict(os.environ, LOCAL_RANK=str(device), RANK="0", WORLD_SIZE="1")     # the same GPU as the headline
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        rows = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or not rows:
+            return {"workload": workload, "error": f"child bench rc {out.returncode}: {out.stderr[-300:]}"}
+        d = json.loads(rows[-1])
+    except Exception as e:
+        return {"workload": workload, "error": str(e)}
+    rf, sc = d.get("roofline", {}), d.get("config", {}).get("self_check") or {}
+    return {
+        "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+        "ms_per_step": d["ms_per_step"], "realtime_factor": d["config"].get("realtime_factor"),
+        "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
+                                            "launches", "steady_launches", "traffic", "traffic_source")},
+        "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches")},
+        "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
+        "seconds": round(time.perf_counter() - t0, 1),
+    }
 
 
 def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6):

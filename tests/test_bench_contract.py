@@ -26,7 +26,7 @@ def test_bench_refuses_to_run_without_a_gpu():
 def test_bench_options_exist():
     out = run_bench("--help", timeout=120)
     assert out.returncode == 0
-    for opt in ("--gpus", "--steps", "--warmup", "--workload", "--sharding", "--scaling", "--realtime-block"):
+    for opt in ("--gpus", "--steps", "--warmup", "--workload", "--sharding", "--scaling", "--realtime-block", "--also"):
         assert opt in out.stdout
 
 
@@ -70,7 +70,7 @@ def test_shard_plans_cover_the_matrix_exactly_once():
 
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
-    out = run_bench("--workload", "c3", "--steps", "5", "--warmup", "2", "--no-all-cores", "--extended-ratio", "0")
+    out = run_bench("--workload", "c3", "--steps", "5", "--warmup", "2", "--no-all-cores", "--extended-ratio", "0", "--also", "c2")
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [line for line in out.stdout.splitlines() if line.startswith("{")]
     assert len(lines) == 1                                                              # ONE JSON line
@@ -89,3 +89,7 @@ def test_bench_line_has_the_contract_fields():
     assert rt["host_pointers"]["p99_ms"] > 0 and rt["device_pointers"]["p99_ms"] > 0 and rt["finite"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "Msamples/s" and c["sample"]
+    a = d["config"]["also"]                                                             # the second workload's digest (default: the 64x64 / 10 s shape)
+    assert "error" not in a, a
+    assert a["workload"].startswith("c2:") and a["value"] > 0 and a["self_check"]["ok"] and a["self_check"]["max_rel_err"] <= 1e-5
+    assert a["roofline"]["bound"] in ("hbm", "launch") and a["roofline"]["avg_launch_ms"] > 0

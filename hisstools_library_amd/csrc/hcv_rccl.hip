@@ -45,7 +45,8 @@ namespace
                     if ((a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
             if (!a.lib)
             {
-                a.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+                const char *why = dlerror();                  // (cleared by the call: read once)
+                a.error = std::string("librccl could not be loaded: ") + (why ? why : "not found");
                 return;
             }
             auto sym = [&](const char *name) { return dlsym(a.lib, name); };

@@ -198,6 +198,7 @@ namespace hcv
         hipStream_t mPipeStream = nullptr;
         hipEvent_t mEvPipe[2] = { nullptr, nullptr };
         bool mPrevPipe2 = false;
+        bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block

@@ -468,13 +468,22 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     else if (!pipeline)
         HCV_TRY(wt(serial ? mStream : mStages[last]->stream, mEvEmit[q ^ 1]));
     mPrevDirect = direct_in;
-    // HCV_PIPE2 (default OFF — measured slower): serial whole-hop blocks of small engines put their forward transforms on a second
-    // stream (see enqueue_stage).  c3's block is rfft 15.5 us -> MAC 7.3 -> reduce 5.2 -> inverse 11.3 in a row, so with the next
-    // block's transforms under the current block's MAC and inverse an asynchronous caller should pay max(15.5, 24) per block;
-    // in fact the two cross-stream hand-overs per block cost more than the overlap gives: c3 0.0459 -> 0.0497 ms per block,
-    // c2 0.0329 -> 0.0400.  Kept for the record and for a runtime with cheaper cross-queue dependencies.
-    static const bool allow_pipe2 = std::getenv("HCV_PIPE2") && std::atoi(std::getenv("HCV_PIPE2")) != 0;
-    blk.pipe2 = allow_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr;
+    // Two-stream pipeline of a small engine's whole-hop blocks (enqueue_stage): the NEXT block's forward transforms on a second stream
+    // beside the current block's MAC, reduction and inverse.  The two cross-stream hand-overs it adds cost about 10 us per block, so it
+    // pays only where both halves of the chain are longer than that.  Measured with the steps timed bare (no HIP events in the chain,
+    // which had hidden the gain in the first measurement): c3 (8 -> 1; transforms 13.5 us | MAC 7.3 + reduction 4.2 + inverse 8.5)
+    // 0.0335 -> 0.0307 ms per block; c1 (13 | 10) 0.0233 -> 0.0258 and c2 (4096-point transforms: 9 | 15) 0.0228 -> 0.0320 lose.
+    // Hence the rule: 16384-point transforms and up, and a tail whose MAC needs more slices than the inverse folds (the separate
+    // reduction launch is what makes the second half long).  Only asynchronous callers gain — a call that waits for its block pays the
+    // hand-overs and overlaps nothing.  HCV_PIPE2 = 0 / 1 forces the choice.
+    static const int pipe2_env = std::getenv("HCV_PIPE2") ? std::atoi(std::getenv("HCV_PIPE2")) : -1;
+    bool want_pipe2 = pipe2_env > 0;
+    if (pipe2_env < 0 && !mCallWaits && !mStages.empty())
+    {
+        const Stage &tl = *mStages[last];
+        want_pipe2 = tl.log2n >= 14 && tl.last_ksplit > 8;
+    }
+    blk.pipe2 = want_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr;
     if (blk.pipe2)
     {
         if (!mPrevPipe2 || ctl_was_dirty)
@@ -597,6 +606,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
     const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
     if (zero_copy)
     {
+        mCallWaits = true;
         if (!enqueue_chunk(mPinInDev, B, mPinOutDev, B, nin_act, nout_act, B)) return false;
     }
     else
@@ -608,6 +618,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
             HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
             mCtlDirty = true;
         }
+        mCallWaits = true;
         if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
         HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
     }
@@ -689,6 +700,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
                                          hipMemcpyHostToDevice, mStream));
             mCtlDirty = true;
         }
+        mCallWaits = true;
         if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
         if (out_stride == (int64_t) B)
             HCV_TRY(hipMemcpyAsync(outs_host + pos, mDevOut, sizeof(float) * (size_t) B * nout_act, hipMemcpyDeviceToHost, mStream));
@@ -720,6 +732,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             return true;
         }
         if (!update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
+        mCallWaits = sync;
         for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
         {
             const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);

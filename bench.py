@@ -306,11 +306,13 @@ def main():
     ap.add_argument("--no-self-check", action="store_true", help="skip the comparison with the CPU leg's output after the timed region")
     ap.add_argument("--realtime-block", type=int, default=128,
                     help="also measure paced real-time calls of this many samples through the host-pointer and device-pointer entry points (0 = skip)")
-    ap.add_argument("--also", default="ns64",
+    ap.add_argument("--also", default=None,
                     help="one GPU only: after the headline, run this workload too (a child bench with its own self-check against the CPU "
                          "reference; no batched / real-time / extended legs) and attach its digest as config.also — by default the 64x64 / "
-                         "10 s @ 48 kHz shape north_star sets the HBM target on ('' = skip; skipped when it is the headline itself)")
+                         "10 s @ 48 kHz shape north_star sets the HBM target on, when the headline is the default workload ('' = skip)")
     args = ap.parse_args()
+    if args.also is None:
+        args.also = "ns64" if args.workload == "c5" else ""
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:

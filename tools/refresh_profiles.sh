@@ -10,7 +10,7 @@ for w in ${WORKLOADS:-c5 ns64 c4}; do
   python bench.py --workload $w ${BENCH_EXTRA:-} 2>/dev/null | grep '^{' > $OUT/bench_$w.json
   D=gpurun_out/prof_$w
   rm -rf $D
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python bench.py --workload $w --no-cpu-baseline --batched-block 0 --extended-ratio 0 --realtime-block 0 2>/dev/null | grep '^{' > $OUT/r02_${w}_bench_under_rocprof.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python bench.py --workload $w --also "" --no-cpu-baseline --batched-block 0 --extended-ratio 0 --realtime-block 0 2>/dev/null | grep '^{' > $OUT/r02_${w}_bench_under_rocprof.json
   T=$(find $D -name "*kernel_trace.csv" | head -1)
   S=$(find $D -name "*kernel_stats.csv" | head -1)
   [ -n "$S" ] && head -40 "$S" > $OUT/r02_${w}_kernel_stats.csv

@@ -197,6 +197,8 @@ namespace hcv
         // multiply-accumulate and inverse (the block's time is a chain of latency-bound launches; asynchronous callers overlap them)
         hipStream_t mPipeStream = nullptr;
         hipEvent_t mEvPipe[2] = { nullptr, nullptr };
+        hipStream_t mPipeStream2 = nullptr; // three-deep pipeline: the MAC (+ reduction) of a pipelined block; its inverse stays on the main stream
+        hipEvent_t mEvPipeB[2] = { nullptr, nullptr };
         bool mPrevPipe2 = false;
         bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine

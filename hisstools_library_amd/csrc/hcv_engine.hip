@@ -182,6 +182,8 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipEventCreateWithFlags(&mEvHostDone, hipEventDisableTiming));
     HCV_TRY(hipStreamCreateWithFlags(&mPipeStream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipe[k], hipEventDisableTiming));
+    HCV_TRY(hipStreamCreateWithFlags(&mPipeStream2, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeB[k], hipEventDisableTiming));
     HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
 
     // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
@@ -389,6 +391,7 @@ Engine::~Engine()
     DeviceGuard dg(mDevice);
     if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);
     if (mPipeStream) (void) hipStreamSynchronize(mPipeStream);
+    if (mPipeStream2) (void) hipStreamSynchronize(mPipeStream2);
     if (mInStream) (void) hipStreamSynchronize(mInStream);
     if (mTdStream) (void) hipStreamSynchronize(mTdStream);
     for (Stage *st : mStages)
@@ -440,8 +443,12 @@ Engine::~Engine()
     if (mStageTailHead) (void) hipFree(mStageTailHead);
     if (mCtlStream) (void) hipStreamDestroy(mCtlStream);
     if (mPipeStream) (void) hipStreamDestroy(mPipeStream);
+    if (mPipeStream2) (void) hipStreamDestroy(mPipeStream2);
     for (int k = 0; k < 2; k++)
+    {
         if (mEvPipe[k]) (void) hipEventDestroy(mEvPipe[k]);
+        if (mEvPipeB[k]) (void) hipEventDestroy(mEvPipeB[k]);
+    }
     if (mGhostHist) (void) hipFree(mGhostHist);
     if (mRetireTmp) (void) hipFree(mRetireTmp);
     if (mGhostPin) (void) hipHostFree(mGhostPin);

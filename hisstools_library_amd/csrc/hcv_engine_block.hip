@@ -143,6 +143,16 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw,
                                           mPipeStream));
         HCV_TRY(hipEventRecord(mEvPipe[q], mPipeStream));
+        // three deep (HCV_PIPE3, default OFF — measured slower): the MAC and its reduction on a stream of their own, the inverse alone on
+        // the main stream, so that the block rate would be the longest of the three parts instead of MAC + reduction + inverse.  The
+        // main stream still ends every block (its inverse waits for the MAC, which waited for the transforms), so everything that
+        // orders itself behind the main stream — synchronize(), control work, the next unpipelined block — is behind the whole block
+        // as before; Y is double buffered by block parity, and the inverse of block n - 1 ends (st.done) before this block's
+        // transforms, hence its MAC, start.  Correct (the parity / restart / steady-state suites pass with it forced on every small
+        // engine) but the third hand-over costs more than the two-deep pipeline's remaining serial part: c3 0.0311 -> 0.039-0.041 ms
+        // per block (13.5 | 12 | 8.5 us of kernels), c1 0.0233 -> 0.0356 forced (profiles/r02d_pipe3_ab.txt).
+        static const bool pipe3 = std::getenv("HCV_PIPE3") && std::atoi(std::getenv("HCV_PIPE3")) != 0;
+        if (pipe3 && mPipeStream2 && tail_head_here && blk.direct_out) sM = mPipeStream2;
         HCV_TRY(hipStreamWaitEvent(sM, mEvPipe[q], 0));
     }
     else if (direct_in)
@@ -213,7 +223,13 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const long long w_elems = (long long) T * nout_act * st.M;
         static const int fold_max_w = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
         const bool fold_w = pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial);
-        if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sI));
+        if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sM != sI ? sM : sI));
+        if (sM != sI)
+        {
+            // (three-deep pipeline: hand the reduced spectra over to the inverse on the main stream)
+            HCV_TRY(hipEventRecord(mEvPipeB[q], sM));
+            HCV_TRY(hipStreamWaitEvent(sI, mEvPipeB[q], 0));
+        }
         if (blk.direct_out)
         {
             // the inverse delivers the block itself; "emit" of this block = the end of this launch

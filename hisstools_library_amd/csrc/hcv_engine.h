@@ -197,6 +197,10 @@ namespace hcv
         // multiply-accumulate and inverse (the block's time is a chain of latency-bound launches; asynchronous callers overlap them)
         hipStream_t mPipeStream = nullptr;
         hipEvent_t mEvPipe[2] = { nullptr, nullptr };
+        hipEvent_t mEvPipeEnd[4] = { nullptr, nullptr, nullptr, nullptr };   // ends of the last four pipelined blocks
+        uint64_t mPipeSeq = 0;              // pipelined blocks enqueued so far
+        uint32_t mPipeRun = 0;              // consecutive pipelined single-hop blocks before the one being enqueued
+        uint32_t mPipeSince = 0;            // pipelined blocks since the pipe stream was last lined up behind the main stream
         hipStream_t mPipeStream2 = nullptr; // three-deep pipeline: the MAC (+ reduction) of a pipelined block; its inverse stays on the main stream
         hipEvent_t mEvPipeB[2] = { nullptr, nullptr };
         bool mPrevPipe2 = false;

@@ -182,6 +182,7 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipEventCreateWithFlags(&mEvHostDone, hipEventDisableTiming));
     HCV_TRY(hipStreamCreateWithFlags(&mPipeStream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipe[k], hipEventDisableTiming));
+    for (int k = 0; k < 4; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeEnd[k], hipEventDisableTiming));
     HCV_TRY(hipStreamCreateWithFlags(&mPipeStream2, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeB[k], hipEventDisableTiming));
     HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
@@ -449,6 +450,8 @@ Engine::~Engine()
         if (mEvPipe[k]) (void) hipEventDestroy(mEvPipe[k]);
         if (mEvPipeB[k]) (void) hipEventDestroy(mEvPipeB[k]);
     }
+    for (int k = 0; k < 4; k++)
+        if (mEvPipeEnd[k]) (void) hipEventDestroy(mEvPipeEnd[k]);
     if (mGhostHist) (void) hipFree(mGhostHist);
     if (mRetireTmp) (void) hipFree(mRetireTmp);
     if (mGhostPin) (void) hipHostFree(mGhostPin);

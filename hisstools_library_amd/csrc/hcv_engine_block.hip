@@ -139,7 +139,19 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         // two-stream pipeline of a small engine: this block's transforms run on the pipe stream, beside the previous block's
         // multiply-accumulate and inverse on the main stream.  The ring slots they write are read by the MAC of the block two
         // back at the latest (R = Pcap + 2 Tmax), hence the wait for that block's end; the MAC of this block waits for them.
-        HCV_TRY(hipStreamWaitEvent(mPipeStream, st.done[q], 0));
+        // Single-hop blocks need less: the ring holds Pcap + 2 Tmax >= Pcap + 4 spectra and a whole-hop MAC reads Pcap + 1 of them, so
+        // the slot of hop n was last read by the MAC of block n - 4.  Waiting for the end of block n - 3 instead of block n - 2
+        // takes the wait off the cycle (transforms of n | MAC .. inverse of n - 1): with the closer event the transforms can only
+        // start when block n - 2 has ended and, hand-over included, end after block n - 1 does.  (HCV_PIPE_DEPTH = 1: the closer event.)
+        // An event record costs the recording stream about 4 us here, so a pipelined block records ONE end event (mEvPipeEnd, a ring of
+        // four) in place of st.done[q]; the first block after the pipe stream was lined up behind the main stream (mEvSerial) needs
+        // no wait at all.
+        static const bool far_wait = !(std::getenv("HCV_PIPE_DEPTH") && std::atoi(std::getenv("HCV_PIPE_DEPTH")) < 2);
+        if (mPipeSince >= 2)                // (blocks from before the line-up are behind mEvSerial, which this stream has waited for)
+        {
+            const bool far = far_wait && T == 1 && mPipeRun >= 3 && mPipeSince >= 3 && st.Tmax >= 2;
+            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvPipeEnd[(mPipeSeq - (far ? 3 : 2)) & 3], 0));
+        }
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw,
                                           mPipeStream));
         HCV_TRY(hipEventRecord(mEvPipe[q], mPipeStream));
@@ -242,7 +254,13 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold_w ? pw.ksplit : 1, w_elems, h_first - 1, T, (int) nout_act, st.timeline, st.tl_len,
                                              st.tl_len - 1, st.tw, &st.big, sI));   // h_first - 1: emitted with NO latency (hop h at h*M)
         }
-        if (blk.pipe2) HCV_TRY(hipEventRecord(st.done[q], sI));    // (serial blocks record no events otherwise)
+        if (blk.pipe2)
+        {
+            HCV_TRY(hipEventRecord(mEvPipeEnd[mPipeSeq & 3], sI));    // (serial blocks record no events otherwise)
+            mPipeSeq++;
+            mPipeSince++;
+            mPipeRun = T == 1 ? mPipeRun + 1 : 0;
+        }
         HCV_TRY(rec(st.done[q], sI));
         HCV_TRY(wt(mStream, st.done[q]));
         st.pre_hop = -1;
@@ -507,8 +525,12 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             // the pipe stream starts behind everything the main stream holds so far (earlier blocks, control work)
             HCV_TRY(hipEventRecord(mEvSerial, mStream));
             HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvSerial, 0));
+            mPipeRun = 0;
+            mPipeSince = 0;
         }
     }
+    else
+        mPipeRun = mPipeSince = 0;
     mPrevPipe2 = blk.pipe2;
 
     if (td)

@@ -200,6 +200,7 @@ namespace hcv
         hipEvent_t mEvPipeEnd[4] = { nullptr, nullptr, nullptr, nullptr };   // ends of the last four pipelined blocks
         uint64_t mPipeSeq = 0;              // pipelined blocks enqueued so far
         uint32_t mPipeRun = 0;              // consecutive pipelined single-hop blocks before the one being enqueued
+        int64_t mPipeRecA = -1, mPipeRecB = -1;   // the last two pipelined blocks that recorded an end event (sequence numbers)
         uint32_t mPipeSince = 0;            // pipelined blocks since the pipe stream was last lined up behind the main stream
         hipStream_t mPipeStream2 = nullptr; // three-deep pipeline: the MAC (+ reduction) of a pipelined block; its inverse stays on the main stream
         hipEvent_t mEvPipeB[2] = { nullptr, nullptr };

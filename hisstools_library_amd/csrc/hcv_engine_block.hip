@@ -147,10 +147,17 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         // four) in place of st.done[q]; the first block after the pipe stream was lined up behind the main stream (mEvSerial) needs
         // no wait at all.
         static const bool far_wait = !(std::getenv("HCV_PIPE_DEPTH") && std::atoi(std::getenv("HCV_PIPE_DEPTH")) < 2);
-        if (mPipeSince >= 2)                // (blocks from before the line-up are behind mEvSerial, which this stream has waited for)
+        // In a run of single-hop blocks only every second block records its end (HCV_PIPE_SPARSE = 0: every block): the transforms of
+        // block n need the MAC of block n - 4 done, and the newer of the last two recorded ends that is not younger than n - 3 — or,
+        // failing that, the latest one — covers it.
+        const long long cur = (long long) mPipeSeq;
+        const bool far = far_wait && T == 1 && mPipeRun >= 3 && mPipeSince >= 3 && st.Tmax >= 2;
+        blk.pipe_far = far;
+        if (mPipeSince >= 2 && mPipeRecA >= 0)      // (blocks from before the line-up are behind mEvSerial, which this stream has waited for)
         {
-            const bool far = far_wait && T == 1 && mPipeRun >= 3 && mPipeSince >= 3 && st.Tmax >= 2;
-            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvPipeEnd[(mPipeSeq - (far ? 3 : 2)) & 3], 0));
+            const long long need = cur - (far ? 4 : 2);            // the block whose MAC must have ended
+            const long long pick = (mPipeRecB >= need && mPipeRecB >= 0) ? mPipeRecB : mPipeRecA;
+            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvPipeEnd[pick & 3], 0));
         }
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw,
                                           mPipeStream));
@@ -256,7 +263,14 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         }
         if (blk.pipe2)
         {
-            HCV_TRY(hipEventRecord(mEvPipeEnd[mPipeSeq & 3], sI));    // (serial blocks record no events otherwise)
+            // (serial blocks record no events otherwise; in a run of single-hop blocks every second one does)
+            static const bool sparse = !(std::getenv("HCV_PIPE_SPARSE") && std::atoi(std::getenv("HCV_PIPE_SPARSE")) == 0);
+            if (!(sparse && blk.pipe_far) || (long long) mPipeSeq - mPipeRecA >= 2)
+            {
+                HCV_TRY(hipEventRecord(mEvPipeEnd[mPipeSeq & 3], sI));
+                mPipeRecB = mPipeRecA;
+                mPipeRecA = (int64_t) mPipeSeq;
+            }
             mPipeSeq++;
             mPipeSince++;
             mPipeRun = T == 1 ? mPipeRun + 1 : 0;
@@ -503,19 +517,24 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(wt(serial ? mStream : mStages[last]->stream, mEvEmit[q ^ 1]));
     mPrevDirect = direct_in;
     // Two-stream pipeline of a small engine's whole-hop blocks (enqueue_stage): the NEXT block's forward transforms on a second stream
-    // beside the current block's MAC, reduction and inverse.  The two cross-stream hand-overs it adds cost about 10 us per block, so it
-    // pays only where both halves of the chain are longer than that.  Measured with the steps timed bare (no HIP events in the chain,
-    // which had hidden the gain in the first measurement): c3 (8 -> 1; transforms 13.5 us | MAC 7.3 + reduction 4.2 + inverse 8.5)
-    // 0.0335 -> 0.0307 ms per block; c1 (13 | 10) 0.0233 -> 0.0258 and c2 (4096-point transforms: 9 | 15) 0.0228 -> 0.0320 lose.
-    // Hence the rule: 16384-point transforms and up, and a tail whose MAC needs more slices than the inverse folds (the separate
-    // reduction launch is what makes the second half long).  Only asynchronous callers gain — a call that waits for its block pays the
-    // hand-overs and overlaps nothing.  HCV_PIPE2 = 0 / 1 forces the choice.
+    // beside the current block's MAC, reduction and inverse.  A cross-stream hand-over is dear on this stack — the wait on the
+    // transforms' event plus the end record cost the main stream about 10 us per block, an event record alone 4-8 us — so it pays only
+    // where both halves of the chain are longer than that, and the engine records as few events as the ring's margin allows (in a run
+    // of single-hop blocks every second block, enqueue_stage).  Measured with the steps timed bare (the MAC's HIP events in the chain
+    // had hidden the gain in the first measurement), ms per 8192-sample block, serial -> pipelined:
+    //   c3 (8 -> 1; transforms 13.5 us | MAC 7.3 + reduction 4.2 + inverse 8.5)   0.0335 -> 0.0270
+    //   c1 (1 x 1, 16384-point stage; 13 | 10)                                     0.0233 -> 0.0212
+    //   c2 (1 x 1, 4096-point stage, four hops per block; 9 | 15)                  0.0228 -> 0.0355  (loses: multi-hop blocks keep the
+    //                                                                              closer wait and an end record per block)
+    // Hence the rule: single-workgroup transforms of 16384 points and up.  Only asynchronous callers gain — a call that waits for its
+    // block pays the hand-overs and overlaps nothing (c3 synchronous steps 0.044 -> 0.057 when forced).  HCV_PIPE2 = 0 / 1 forces
+    // the choice.
     static const int pipe2_env = std::getenv("HCV_PIPE2") ? std::atoi(std::getenv("HCV_PIPE2")) : -1;
     bool want_pipe2 = pipe2_env > 0;
     if (pipe2_env < 0 && !mCallWaits && !mStages.empty())
     {
         const Stage &tl = *mStages[last];
-        want_pipe2 = tl.log2n >= 14 && tl.last_ksplit > 8;
+        want_pipe2 = tl.log2n >= 14;
     }
     blk.pipe2 = want_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr;
     if (blk.pipe2)
@@ -527,10 +546,14 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvSerial, 0));
             mPipeRun = 0;
             mPipeSince = 0;
+            mPipeRecA = mPipeRecB = -1;
         }
     }
     else
+    {
         mPipeRun = mPipeSince = 0;
+        mPipeRecA = mPipeRecB = -1;
+    }
     mPrevPipe2 = blk.pipe2;
 
     if (td)

@@ -142,6 +142,7 @@ struct Engine::Block
     size_t last = 0;                    // index of the last stage
     bool td_any = false, td_check = false, whole_hops = false, entering = false, leaving = false, head_fft = false, td = false;
     bool serial = false, full_matrix = false;
+    bool pipe_far = false;              // ... in a run of single-hop blocks (its transforms wait for the block three or four back)
     bool pipe2 = false;                 // serial whole-hop block with its forward transforms on the pipe stream
     bool direct_out = false;            // whole-hop block: the inverse writes the caller's block itself, no timeline, no emit launch
     bool direct_in = false;             // the (only) running stage's forward FFTs read the caller's block themselves: no scatter launch

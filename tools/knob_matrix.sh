@@ -2,7 +2,7 @@
 # The scheduling knobs change the schedule, never the result: the parity, steady-state and restart suites under each of them.
 # Usage on the GPU box: tools/knob_matrix.sh   (one line per knob setting)
 for kv in HCV_DEFER=0 HCV_TAIL_HEAD=0 HCV_HEAD_FFT=0 HCV_PIPELINE=0 HCV_TAIL_GATE=1 HCV_BG_SLICES=3 HCV_ONE_STREAM=1 HCV_SERIAL=0 HCV_SERIAL=1 \
-          HCV_DIRECT_IN=0 HCV_DIRECT_OUT=0 HCV_FOLD_REDUCE=0 HCV_PIPE2=1 HCV_PIPE2=0 "HCV_PIPE2=1 HCV_PIPE3=1" HCV_MAC_PREFETCH=0 HCV_ZERO_COPY=0 HCV_SERIAL_KSPLIT=8; do
+          HCV_DIRECT_IN=0 HCV_DIRECT_OUT=0 HCV_FOLD_REDUCE=0 HCV_PIPE2=1 HCV_PIPE2=0 "HCV_PIPE2=1 HCV_PIPE3=1" "HCV_PIPE2=1 HCV_PIPE_SPARSE=0" "HCV_PIPE2=1 HCV_PIPE_DEPTH=1" HCV_MAC_PREFETCH=0 HCV_ZERO_COPY=0 HCV_SERIAL_KSPLIT=8; do
   echo -n "$kv: "
   env $kv python -m pytest tests/test_gpu_parity.py tests/test_pair_restart_gpu.py tests/test_steady_state_gpu.py tests/test_restart_golden.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -1
 done

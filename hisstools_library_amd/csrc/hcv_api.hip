@@ -8,9 +8,11 @@
 #include "hcv_engine.h"
 #include "hcv_api_common.h"
 #include "hcv_rccl.h"
+#include "hcv_shard_pool.h"
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -459,9 +461,11 @@ struct hcv_shard
     std::unique_ptr<Matrix> m;
     uint32_t in_lo = 0, in_hi = 0, out_lo = 0, out_hi = 0;
     int row = 0, col = 0, device = 0;
-    float *part = nullptr;              // input-split layouts: this shard's partial output block [nout_local][maxBlock], on its device
-    hipEvent_t evPart = nullptr;        // ... of the current call is complete
-    hipEvent_t evDone = nullptr;        // row root: the sum of the current call has read every partial block of the row group
+    // input-split layouts: this shard's partial output block [nout_local][maxBlock] on its device, twice — block b of the object
+    // goes to part[b & 1], so that the row root's sum of block b - 1 never stands between this shard and its next block
+    float *part[2] = { nullptr, nullptr };
+    hipEvent_t evPart = nullptr;        // ... of the current block is complete
+    hipEvent_t evDone[2] = { nullptr, nullptr };    // row root: the sum of the last block of that parity has read every partial block of the row group
 };
 
 struct hcv_shards
@@ -470,6 +474,9 @@ struct hcv_shards
     int go = 1, gi = 1, home = 0;
     uint32_t nin = 1, nout = 1, maxBlock = 0;
     bool diag = false;
+    bool peer_ok = true;                // every device in play maps every other's memory (needed by the device-pointer entry points only)
+    uint64_t blocks = 0;                // device-pointer blocks so far (parity of the partial-block buffers)
+    std::unique_ptr<hcv::ShardPool> pool;   // one enqueue thread per shard after the first (null: the calling thread does them all)
 
     hcv_shard *owner(uint32_t in, uint32_t out)
     {
@@ -479,13 +486,17 @@ struct hcv_shards
     }
     ~hcv_shards()
     {
+        pool.reset();
         for (hcv_shard &x : s)
         {
             (void) hipSetDevice(x.device);
             if (x.m && x.m->engine) x.m->engine->synchronize();
-            if (x.part) (void) hipFree(x.part);
+            for (int q = 0; q < 2; q++)
+            {
+                if (x.part[q]) (void) hipFree(x.part[q]);
+                if (x.evDone[q]) (void) hipEventDestroy(x.evDone[q]);
+            }
             if (x.evPart) (void) hipEventDestroy(x.evPart);
-            if (x.evDone) (void) hipEventDestroy(x.evDone);
         }
     }
 };
@@ -625,9 +636,9 @@ static void split_range(uint32_t n, uint32_t parts, uint32_t index, uint32_t &lo
 static hcv_convolver *make_sharded(uint32_t numIns, uint32_t numOuts, bool parallel, uint64_t maxLength, bool zeroLatency, uint32_t A, uint32_t B,
                                    uint32_t C, uint32_t D, const int *devices, int n, uint32_t maxBlock)
 {
-    if (!devices || n < 1 || !numOuts)
+    if (!devices || n < 1 || n > 64 || !numOuts)
     {
-        set_error("sharded Convolver: needs at least one device and one output");
+        set_error("sharded Convolver: needs 1 .. 64 devices and at least one output");
         return nullptr;
     }
     const int count = hcv_device_count();
@@ -671,22 +682,41 @@ static hcv_convolver *make_sharded(uint32_t numIns, uint32_t numOuts, bool paral
             ok = hipSetDevice(x.device) == hipSuccess;
             // every device reads the caller's buffers (on the home device) and the row root reads its group's partial blocks
             // directly, over xGMI: peer access both ways between the devices in play
+            // (the host-pointer path stages through each engine's own pinned buffers and needs none of this: a box without
+            // peer-to-peer keeps the object, and only the device-pointer entry points refuse)
             for (int k = 0; k < n && ok; k++)
                 if (devices[k] != x.device)
                 {
                     const hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) sh.peer_ok = false;
                     (void) hipGetLastError();
                 }
             if (ok && gi > 1)
             {
-                ok = hipMalloc(&x.part, sizeof(float) * (size_t) (x.out_hi - x.out_lo) * sh.maxBlock) == hipSuccess &&
-                     hipEventCreateWithFlags(&x.evPart, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&x.evDone, hipEventDisableTiming) == hipSuccess &&
-                     hipEventRecord(x.evDone, x.m->engine->main_stream()) == hipSuccess;
+                const size_t bytes = sizeof(float) * (size_t) (x.out_hi - x.out_lo) * sh.maxBlock;
+                ok = hipMalloc(&x.part[0], bytes) == hipSuccess && hipMalloc(&x.part[1], bytes) == hipSuccess &&
+                     hipEventCreateWithFlags(&x.evPart, hipEventDisableTiming) == hipSuccess;
+                for (int q = 0; q < 2 && ok; q++)
+                    ok = hipEventCreateWithFlags(&x.evDone[q], hipEventDisableTiming) == hipSuccess &&
+                         hipEventRecord(x.evDone[q], x.m->engine->main_stream()) == hipSuccess;
             }
             if (!ok) set_error("sharded Convolver: device set-up failed (peer access / allocation)");
         }
+    // Enqueue threads (HCV_SHARD_THREADS = 0 / 1 forces the choice): by default when the shards really are on several devices —
+    // each device has its own queues and the HIP calls of the shards run side by side; engines sharing ONE device (the test
+    // box's stand-in for a node) contend for that device's runtime locks and gain little.
+    if (ok && sh.s.size() > 1 && sh.s.size() <= 64)
+    {
+        std::vector<int> devs;
+        bool distinct = false;
+        for (const hcv_shard &x : sh.s)
+        {
+            devs.push_back(x.device);
+            distinct = distinct || x.device != sh.s[0].device;
+        }
+        const char *env = std::getenv("HCV_SHARD_THREADS");
+        if (env ? std::atoi(env) != 0 : distinct) sh.pool.reset(new hcv::ShardPool((int) devs.size(), devs.data()));
+    }
     if (prev >= 0) (void) hipSetDevice(prev);
     if (!ok) return nullptr;
     return h.release();
@@ -722,7 +752,11 @@ extern "C" hcv_convolver *hcv_convolver_create_on(uint32_t numIns, uint32_t numO
     latency_sizes(latency, zero, A, B, C, D);
     numIns = numIns < 1 ? 1 : numIns;                       // Convolver.cpp:8
     std::vector<int> devs;
-    if (device < 0 && env_devices(devs)) return make_sharded(numIns, numOuts, false, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), maxBlock);
+    if (device < 0 && env_devices(devs))
+    {
+        if (hcv_convolver *h = make_sharded(numIns, numOuts, false, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), maxBlock)) return h;
+        std::fprintf(stderr, "hisstools_amd: HCV_DEVICES could not be honoured (%s); using one device\n", tlsError.c_str());
+    }
     return wrap(make_matrix(numIns, numOuts, false, 16384, zero, A, B, C, D, device < 0 ? gDefaultDevice : device, maxBlock, nullptr));
 }
 
@@ -738,7 +772,11 @@ extern "C" hcv_convolver *hcv_convolver_create_parallel(uint32_t numIO, int late
     latency_sizes(latency, zero, A, B, C, D);
     numIO = numIO < 1 ? 1 : numIO;                          // Convolver.cpp:27
     std::vector<int> devs;
-    if (env_devices(devs)) return make_sharded(numIO, numIO, true, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), 0);
+    if (env_devices(devs))
+    {
+        if (hcv_convolver *h = make_sharded(numIO, numIO, true, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), 0)) return h;
+        std::fprintf(stderr, "hisstools_amd: HCV_DEVICES could not be honoured (%s); using one device\n", tlsError.c_str());
+    }
     return wrap(make_matrix(numIO, numIO, true, 16384, zero, A, B, C, D, gDefaultDevice, 0, nullptr));
 }
 
@@ -815,6 +853,11 @@ extern "C" int hcv_convolver_set_f32_dev(hcv_convolver *h, uint32_t inChan, uint
         // (the IR lies on the home device; a shard elsewhere reads it over the peer mapping)
         hcv_shard *x = nullptr;
         const int rc = shard_pair(h, inChan, outChan, HCV_ERR_OUT_CHAN_OUT_OF_RANGE, x);
+        if (rc < 0 && !h->sh->peer_ok && x->device != h->sh->home)
+        {
+            set_error("sharded Convolver: no peer access between the devices; load this pair through host pointers (hcv_convolver_set_f32)");
+            return HCV_ERR_MEM_UNAVAILABLE;
+        }
         return rc >= 0 ? rc : x->m->set(inChan, outChan, input_dev, length, resize != 0, true);
     }
     Matrix &m = *h->m;
@@ -892,45 +935,107 @@ extern "C" int hcv_convolver_resize(hcv_convolver *h, uint32_t inChan, uint32_t 
 // One call of a sharded object, host pointers: every shard's block is begun (inputs staged, kernels and download enqueued on
 // its own device) before the first is waited for, so the devices run side by side; an input-split row group's partial blocks
 // are added up as they are delivered (root first, which overwrites).
+namespace
+{
+    // one block of a sharded object's host-pointer call, as the shard workers see it
+    struct HostJob
+    {
+        hcv_shards *sh;
+        const float *const *ins;
+        float *const *outs;
+        size_t pos;
+        uint32_t B, ni, no;
+        std::string err[64];
+    };
+
+    void shard_active(const hcv_shards &sh, const hcv_shard &x, uint32_t ni, uint32_t no, uint32_t &a_ni, uint32_t &a_no)
+    {
+        a_no = no > x.out_lo ? std::min(no, x.out_hi) - x.out_lo : 0;
+        a_ni = sh.diag ? a_no : (ni > x.in_lo ? std::min(ni, x.in_hi) - x.in_lo : 0);
+    }
+
+    // phase 1: stage the shard's inputs, enqueue its block and the download on its own device
+    bool host_begin_job(void *ctx, int k)
+    {
+        HostJob &j = *static_cast<HostJob *>(ctx);
+        hcv_shard &x = j.sh->s[(size_t) k];
+        uint32_t a_ni, a_no;
+        shard_active(*j.sh, x, j.ni, j.no, a_ni, a_no);
+        if (!a_no || (x.col > 0 && !a_ni)) return true;
+        const float *ip[64];
+        std::vector<const float *> big;
+        const float **rows = ip;
+        if (a_ni > 64) { big.resize(a_ni); rows = big.data(); }
+        for (uint32_t i = 0; i < a_ni; i++) rows[i] = j.ins[x.in_lo + i] + j.pos;
+        if (x.m->engine->process_begin(rows, a_ni, a_no, j.B)) return true;
+        if (k < 64) j.err[k] = x.m->engine->last_error();
+        return false;
+    }
+
+    // phase 2, run for the ROOT of every row group: wait for and deliver the group's blocks in column order (the root's block
+    // overwrites the caller's rows, the others are added: NToMonoConvolve.cpp:39-42 across the shards)
+    bool host_end_job(void *ctx, int k)
+    {
+        HostJob &j = *static_cast<HostJob *>(ctx);
+        hcv_shards &sh = *j.sh;
+        for (int c = 0; c < sh.gi; c++)
+        {
+            hcv_shard &x = sh.s[(size_t) k + (size_t) c];
+            uint32_t a_ni, a_no;
+            shard_active(sh, x, j.ni, j.no, a_ni, a_no);
+            if (!a_no || (x.col > 0 && !a_ni)) continue;
+            float *op[64];
+            std::vector<float *> big;
+            float **rows = op;
+            if (a_no > 64) { big.resize(a_no); rows = big.data(); }
+            for (uint32_t o = 0; o < a_no; o++) rows[o] = j.outs[x.out_lo + o] + j.pos;
+            if (!x.m->engine->process_end(rows, a_no, j.B, /* accumulate */ x.col > 0))
+            {
+                if (k < 64) j.err[k] = x.m->engine->last_error();
+                return false;
+            }
+        }
+        return true;
+    }
+
+    bool run_shards(hcv_shards &sh, hcv::ShardPool::Fn fn, void *ctx, uint64_t mask)
+    {
+        if (sh.pool) return sh.pool->run(fn, ctx, mask);
+        bool ok = true;
+        for (size_t k = 0; k < sh.s.size() && ok; k++)
+            if (mask >> k & 1) ok = fn(ctx, (int) k);
+        return ok;
+    }
+}
+
+// One call of a sharded object, host pointers: every shard's block is begun (inputs staged, kernels and download enqueued on
+// its own device) before the first is waited for, so the devices run side by side; an input-split row group's partial blocks
+// are added up as they are delivered (root first, which overwrites).  With enqueue threads (hcv_shard_pool.h) the shards' begin
+// halves run side by side on the host too, and so do the row groups' end halves.
 static int sharded_process_host(hcv_convolver *h, const float *const *ins, float *const *outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
     hcv_shards &sh = *h->sh;
-    const uint32_t no = (uint32_t) std::min<size_t>(numOuts, sh.nout);
-    const uint32_t ni = sh.diag ? no : (uint32_t) std::min<size_t>(numIns, sh.nin);
-    std::vector<const float *> ip(std::max<uint32_t>(sh.nin, 1));
-    std::vector<float *> op(std::max<uint32_t>(sh.nout, 1));
-    struct Act { uint32_t ni, no; };
-    std::vector<Act> act(sh.s.size());
-    for (size_t k = 0; k < sh.s.size(); k++)
+    HostJob j;
+    j.sh = &sh;
+    j.ins = ins;
+    j.outs = outs;
+    j.no = (uint32_t) std::min<size_t>(numOuts, sh.nout);
+    j.ni = sh.diag ? j.no : (uint32_t) std::min<size_t>(numIns, sh.nin);
+    uint64_t all = 0, roots = 0;
+    for (size_t k = 0; k < sh.s.size() && k < 64; k++)
     {
-        const hcv_shard &x = sh.s[k];
-        act[k].no = no > x.out_lo ? std::min(no, x.out_hi) - x.out_lo : 0;
-        act[k].ni = sh.diag ? act[k].no : (ni > x.in_lo ? std::min(ni, x.in_hi) - x.in_lo : 0);
+        all |= uint64_t(1) << k;
+        if (sh.s[k].col == 0) roots |= uint64_t(1) << k;
     }
     for (size_t pos = 0; pos < numSamples; pos += sh.maxBlock)
     {
-        const uint32_t B = (uint32_t) std::min<size_t>(sh.maxBlock, numSamples - pos);
-        for (size_t k = 0; k < sh.s.size(); k++)
+        j.pos = pos;
+        j.B = (uint32_t) std::min<size_t>(sh.maxBlock, numSamples - pos);
+        if (!run_shards(sh, host_begin_job, &j, all) || !run_shards(sh, host_end_job, &j, roots))
         {
-            hcv_shard &x = sh.s[k];
-            if (!act[k].no || (x.col > 0 && !act[k].ni)) continue;
-            for (uint32_t i = 0; i < act[k].ni; i++) ip[i] = ins[x.in_lo + i] + pos;
-            if (!x.m->engine->process_begin(ip.data(), act[k].ni, act[k].no, B))
-            {
-                set_error(x.m->engine->last_error());
-                return -1;
-            }
-        }
-        for (size_t k = 0; k < sh.s.size(); k++)
-        {
-            hcv_shard &x = sh.s[k];
-            if (!act[k].no || (x.col > 0 && !act[k].ni)) continue;
-            for (uint32_t o = 0; o < act[k].no; o++) op[o] = outs[x.out_lo + o] + pos;
-            if (!x.m->engine->process_end(op.data(), act[k].no, B, /* accumulate */ x.col > 0))
-            {
-                set_error(x.m->engine->last_error());
-                return -1;
-            }
+            for (const std::string &e : j.err)
+                if (!e.empty()) { set_error(e); break; }
+            return -1;
         }
     }
     return 0;
@@ -1074,57 +1179,109 @@ extern "C" int hcv_convolver_process_f64(hcv_convolver *h, const double *const *
 // and write their output rows in the caller's buffers directly (peer access over xGMI for the shards on other devices): no
 // staging copies.  Input-split layouts: each shard of a row group emits its partial block into a buffer of its own, the
 // group's root waits for them (events across devices) and one kernel on the root's stream writes their sum to the caller's rows.
+namespace
+{
+    struct DevJob
+    {
+        hcv_shards *sh;
+        const float *ins;
+        float *outs;
+        size_t in_stride, out_stride, pos, B;
+        uint32_t ni, no;
+        int par;                         // parity of the partial-block buffers for this block
+    };
+
+    // phase 1: the shard's block on its own device — into the caller's rows (row sharding), or into its partial block
+    bool dev_block_job(void *ctx, int k)
+    {
+        DevJob &j = *static_cast<DevJob *>(ctx);
+        hcv_shards &sh = *j.sh;
+        hcv_shard &x = sh.s[(size_t) k];
+        uint32_t a_ni, a_no;
+        shard_active(sh, x, j.ni, j.no, a_ni, a_no);
+        if (!a_no) return true;
+        Engine &e = *x.m->engine;
+        const float *src = j.ins + (size_t) x.in_lo * j.in_stride + j.pos;
+        if (sh.gi == 1)
+            return e.process_dev(src, (int64_t) j.in_stride, j.outs + (size_t) x.out_lo * j.out_stride + j.pos, (int64_t) j.out_stride, a_ni, a_no, j.B, false);
+        hcv_shard &root = sh.s[(size_t) k - (size_t) x.col];
+        // the root's sum of the block two back read this buffer: every writer of this block follows it (`after`: a streamed
+        // whole-hop block writes from its last stage's stream, not from the main stream)
+        if (!e.process_dev(src, (int64_t) j.in_stride, x.part[j.par], (int64_t) sh.maxBlock, a_ni, a_no, j.B, false, root.evDone[j.par])) return false;
+        int prev = -1;
+        (void) hipGetDevice(&prev);
+        bool ok = (prev == x.device || hipSetDevice(x.device) == hipSuccess) && hipEventRecord(x.evPart, e.main_stream()) == hipSuccess;
+        if (prev >= 0 && prev != x.device) (void) hipSetDevice(prev);
+        return ok;
+    }
+
+    // phase 2, for the root of every row group: wait for the group's partial blocks (events across devices) and write their sum
+    // to the caller's rows with one kernel on the root's stream
+    bool dev_sum_job(void *ctx, int k)
+    {
+        DevJob &j = *static_cast<DevJob *>(ctx);
+        hcv_shards &sh = *j.sh;
+        hcv_shard &root = sh.s[(size_t) k];
+        uint32_t a_ni, a_no;
+        shard_active(sh, root, j.ni, j.no, a_ni, a_no);
+        if (!a_no) return true;
+        hipStream_t rs = root.m->engine->main_stream();
+        int prev = -1;
+        (void) hipGetDevice(&prev);
+        bool ok = prev == root.device || hipSetDevice(root.device) == hipSuccess;
+        hcv::PartSources ps;
+        ps.count = sh.gi;
+        for (int c = 0; c < sh.gi && ok; c++)
+        {
+            ps.part[c] = sh.s[(size_t) k + (size_t) c].part[j.par];
+            if (c) ok = hipStreamWaitEvent(rs, sh.s[(size_t) k + (size_t) c].evPart, 0) == hipSuccess;
+        }
+        ok = ok && hcv::launch_sum_parts(ps, (long long) sh.maxBlock, (int) j.B, (int) a_no, j.outs + (size_t) root.out_lo * j.out_stride + j.pos,
+                                         (long long) j.out_stride, rs) == hipSuccess;
+        ok = ok && hipEventRecord(root.evDone[j.par], rs) == hipSuccess;
+        if (prev >= 0 && prev != root.device) (void) hipSetDevice(prev);
+        return ok;
+    }
+}
+
+// One call of a sharded object, device pointers (both buffers on the home device).  Every shard's kernels read their input rows
+// and write their output rows in the caller's buffers directly (peer access over xGMI for the shards on other devices): no
+// staging copies.  Input-split layouts: each shard of a row group emits its partial block into a buffer of its own, the
+// group's root waits for them (events across devices) and one kernel on the root's stream writes their sum to the caller's rows.
 static int sharded_process_dev(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride, size_t numIns, size_t numOuts,
                                size_t numSamples, int sync)
 {
     hcv_shards &sh = *h->sh;
-    const uint32_t no = (uint32_t) std::min<size_t>(numOuts, sh.nout);
-    const uint32_t ni = sh.diag ? no : (uint32_t) std::min<size_t>(numIns, sh.nin);
+    if (!sh.peer_ok)
+    {
+        set_error("sharded Convolver: no peer access between the devices; use the host-pointer entry point (hcv_convolver_process_f32)");
+        return -1;
+    }
+    DevJob j;
+    j.sh = &sh;
+    j.ins = ins_dev;
+    j.outs = outs_dev;
+    j.in_stride = in_stride;
+    j.out_stride = out_stride;
+    j.no = (uint32_t) std::min<size_t>(numOuts, sh.nout);
+    j.ni = sh.diag ? j.no : (uint32_t) std::min<size_t>(numIns, sh.nin);
+    uint64_t all = 0, roots = 0;
+    for (size_t k = 0; k < sh.s.size() && k < 64; k++)
+    {
+        all |= uint64_t(1) << k;
+        if (sh.s[k].col == 0) roots |= uint64_t(1) << k;
+    }
     int prev = -1;
     (void) hipGetDevice(&prev);
     bool ok = true;
     for (size_t pos = 0; pos < numSamples && ok; pos += sh.maxBlock)
     {
-        const size_t B = std::min<size_t>(sh.maxBlock, numSamples - pos);
-        for (size_t k = 0; k < sh.s.size() && ok; k++)
-        {
-            hcv_shard &x = sh.s[k];
-            const uint32_t a_no = no > x.out_lo ? std::min(no, x.out_hi) - x.out_lo : 0;
-            const uint32_t a_ni = sh.diag ? a_no : (ni > x.in_lo ? std::min(ni, x.in_hi) - x.in_lo : 0);
-            if (!a_no) continue;
-            Engine &e = *x.m->engine;
-            const float *src = ins_dev + (size_t) x.in_lo * in_stride + pos;
-            if (sh.gi == 1)
-            {
-                ok = e.process_dev(src, (int64_t) in_stride, outs_dev + (size_t) x.out_lo * out_stride + pos, (int64_t) out_stride, a_ni, a_no, B, false);
-                continue;
-            }
-            hcv_shard &root = sh.s[k - (size_t) x.col];
-            ok = hipSetDevice(x.device) == hipSuccess;
-            // the root's sum of the previous block must have read this shard's partial block before emit overwrites it
-            ok = ok && hipStreamWaitEvent(e.main_stream(), root.evDone, 0) == hipSuccess;
-            ok = ok && e.process_dev(src, (int64_t) in_stride, x.part, (int64_t) sh.maxBlock, a_ni, a_no, B, false);
-            ok = ok && hipEventRecord(x.evPart, e.main_stream()) == hipSuccess;
-        }
-        if (sh.gi > 1)
-            for (size_t k = 0; k < sh.s.size() && ok; k += (size_t) sh.gi)
-            {
-                hcv_shard &root = sh.s[k];
-                const uint32_t a_no = no > root.out_lo ? std::min(no, root.out_hi) - root.out_lo : 0;
-                if (!a_no) continue;
-                hipStream_t rs = root.m->engine->main_stream();
-                ok = hipSetDevice(root.device) == hipSuccess;
-                hcv::PartSources ps;
-                ps.count = sh.gi;
-                for (int c = 0; c < sh.gi && ok; c++)
-                {
-                    ps.part[c] = sh.s[k + (size_t) c].part;
-                    if (c) ok = hipStreamWaitEvent(rs, sh.s[k + (size_t) c].evPart, 0) == hipSuccess;
-                }
-                ok = ok && hcv::launch_sum_parts(ps, (long long) sh.maxBlock, (int) B, (int) a_no, outs_dev + (size_t) root.out_lo * out_stride + pos,
-                                                 (long long) out_stride, rs) == hipSuccess;
-                ok = ok && hipEventRecord(root.evDone, rs) == hipSuccess;
-            }
+        j.pos = pos;
+        j.B = std::min<size_t>(sh.maxBlock, numSamples - pos);
+        j.par = (int) (sh.blocks++ & 1);
+        ok = run_shards(sh, dev_block_job, &j, all);
+        // (the sums wait for events the block jobs recorded: phase 2 starts when every shard's phase 1 has returned)
+        if (ok && sh.gi > 1) ok = run_shards(sh, dev_sum_job, &j, roots);
     }
     if (prev >= 0) (void) hipSetDevice(prev);
     if (!ok)

@@ -34,10 +34,23 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace hcv
 {
+    // one step of a bounded spin-wait on the host (the audio thread's lock poll, the shard pool's hand-offs)
+    inline void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        __asm__ __volatile__("yield" ::: "memory");
+#else
+        std::this_thread::yield();
+#endif
+    }
+
     struct StageCfg
     {
         uint32_t fft_size = 0;      // power of two, 2^5 .. 2^20
@@ -102,16 +115,20 @@ namespace hcv
         bool process_begin(const float *const *ins, uint32_t nin_act, uint32_t nout_act, uint32_t B);
         bool process_end(float *const *outs, uint32_t nout_act, uint32_t B, bool accumulate);
         // device-resident call: ins/outs are [rows][stride] float on this GPU.  Asynchronous unless sync=true.
+        // `after` (optional): an event of ANOTHER engine or device that every kernel of this call which writes `outs` must follow
+        // (the sharded object's row root has then read the previous contents of a partial block, hcv_api.hip)
         bool process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
-                         bool sync);
+                         bool sync, hipEvent_t after = nullptr);
         // synchronous call on PINNED host memory the caller registered (hcv_host_register): [rows][stride] blocks given by their
         // host address and their device mapping.  Small blocks run on the mapping in place; larger ones are moved by the copy
         // engines straight from / to the caller's memory (no staging memcpy on the host).
         bool process_pinned(const float *ins_host, const float *ins_map, int64_t in_stride, float *outs_host, float *outs_map, int64_t out_stride,
                             uint32_t nin_act, uint32_t nout_act, uint64_t n);
         bool synchronize();
-        // for the layers that combine several engines (shards, collectives): the stream every block's emit — the only writer of
-        // the caller's output buffer — runs on
+        // for the layers that combine several engines (shards, collectives): the stream that ENDS every block — the emit launch, or
+        // a wait for the stage stream whose inverse wrote the caller's block (direct output); work enqueued on it after a call
+        // follows the call's output.  It is NOT the only writer of the output buffer: a streamed whole-hop block writes it from the
+        // last stage's stream, which is why a dependency of the NEXT call's writes on foreign work goes through process_dev's `after`.
         hipStream_t main_stream() const { return mStream; }
 
         // The audio-thread contract (MemorySwap::attempt, MonoConvolve.cpp:181-183): process never waits for a control call's
@@ -209,6 +226,7 @@ namespace hcv
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
+        bool mExtDirty = false;             // the main stream was made to wait for a foreign event (process_dev `after`): a streamed block fans it out
         uint64_t mBlockCount = 0;
 
         // rings and staging

@@ -193,6 +193,8 @@ bool Engine::init(const EngineCfg &cfg)
 
     HCV_TRY(hipMalloc(&mHist, sizeof(float) * mCfg.nin * mHistLen));
     HCV_TRY(hipMemset(mHist, 0, sizeof(float) * mCfg.nin * mHistLen));
+    // (retire_pair's frame, allocated here so that no swap section under the engine lock ever allocates)
+    if (nmax) HCV_TRY(hipMalloc(&mRetireTmp, sizeof(float) * nmax));
     HCV_TRY(hipMalloc(&mDevIn, sizeof(float) * mCfg.nin * mMaxBlock));
     HCV_TRY(hipMalloc(&mDevOut, sizeof(float) * mCfg.nout * mMaxBlock));
     HCV_TRY(hipHostMalloc(&mPinIn, sizeof(float) * mCfg.nin * mMaxBlock, hipHostMallocMapped));
@@ -628,24 +630,42 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     return true;
 }
 
+// One private memory pool per device for the control path, shared by the engines on it: freed blocks stay in the pool (release
+// threshold = everything) instead of going back to the driver at the next synchronisation, and the device's DEFAULT pool — other
+// hipFreeAsync users of the process, PyTorch among them — keeps its own policy.
+static hipMemPool_t ctl_pool(int device)
+{
+    static std::mutex mtx;
+    static std::map<int, hipMemPool_t> pools;
+    std::lock_guard<std::mutex> g(mtx);
+    auto it = pools.find(device);
+    if (it != pools.end()) return it->second;
+    hipMemPool_t pool = nullptr;
+    hipMemPoolProps props;
+    std::memset(&props, 0, sizeof(props));
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = device;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool)
+    {
+        uint64_t keep = ~uint64_t(0);
+        (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    else
+        pool = nullptr;             // (allocation then falls back to the device's default pool, policy untouched)
+    (void) hipGetLastError();
+    pools[device] = pool;
+    return pool;
+}
+
 hipError_t Engine::ctl_alloc(void **p, size_t bytes)
 {
     static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
     if (async)
     {
-        static std::once_flag once;
-        std::call_once(once, [&]()
-        {
-            // keep freed blocks in the pool instead of returning them to the driver at the next synchronisation
-            hipMemPool_t pool = nullptr;
-            if (hipDeviceGetDefaultMemPool(&pool, mDevice) == hipSuccess && pool)
-            {
-                uint64_t keep = ~uint64_t(0);
-                (void) hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-            (void) hipGetLastError();
-        });
-        const hipError_t e = hipMallocAsync(p, bytes, mCtlStream);
+        hipMemPool_t pool = ctl_pool(mDevice);
+        const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);
         if (e == hipSuccess) return e;
         (void) hipGetLastError();
         return e;

@@ -475,6 +475,10 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     }
     mPrevSerial = serial;
     if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
+    // a foreign event the main stream waits for (process_dev `after`) binds a streamed block's stage streams like control work;
+    // a serial block runs on the main stream and is behind it already
+    if (mExtDirty && !serial) mCtlDirty = true;
+    mExtDirty = false;
     // control work queued on the main stream (IR spectra, reset fills, regrown buffers) must land before this block
     const bool ctl_was_dirty = mCtlDirty;
     if (mCtlDirty)
@@ -632,7 +636,7 @@ bool Engine::lock_for_audio(std::unique_lock<std::mutex> &lk)
     bool got = false;
     while (waited < kAudioLockBudgetNs)
     {
-        for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+        for (int k = 0; k < 32; k++) cpu_relax();
         got = lk.try_lock();
         waited = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         if (got) break;
@@ -777,7 +781,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
 }
 
 bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint64_t n,
-                         bool sync)
+                         bool sync, hipEvent_t after)
 {
     DeviceGuard dg(mDevice);
     nout_act = std::min(nout_act, mCfg.nout);
@@ -793,6 +797,13 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             return true;
         }
         if (!update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
+        if (after)
+        {
+            // serial blocks write `outs` from the main stream; a streamed block's writer (a stage stream's inverse, or emit behind
+            // it) is reached through the control-work fan-out of enqueue_chunk
+            HCV_TRY(hipStreamWaitEvent(mStream, after, 0));
+            mExtDirty = true;
+        }
         mCallWaits = sync;
         for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
         {

@@ -222,12 +222,6 @@ bool Engine::retire_pair(size_t pair)
         const long long P = std::min<long long>(st.pact[pair], h_r);
         if (P <= 0) continue;
         if (mTailHeadPrev) continue;        // whole-hop mode: every block delivers all it computes, no stage has anything pending
-        if (!mRetireTmp)
-        {
-            uint32_t nmax = 0;
-            for (Stage *sp : mStages) nmax = std::max(nmax, sp->N);
-            HCV_TRY(hipMalloc(&mRetireTmp, sizeof(float) * nmax));
-        }
         MacShape sh = mac_shape(st, /* P */ (int) P, /* Pcap */ st.hparts(),
                                 /* nin */ 1, /* nin_alloc */ 1, /* nout */ 1, /* diag */ 0,
                                 /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / st.M));

@@ -1,0 +1,77 @@
+"""BASELINE configs 3 and 4 at FULL size with DENSE (decaying-noise) impulse responses against the reference arithmetic
+(the CPU oracle, bit-identical to the unmodified reference on the golden vectors) — not only impulse IRs and float64 truth.
+
+config 3: NToMonoConvolve 8 -> 1, 5 s IRs (NToMonoConvolve.cpp:35-43: out = sum_i Mono_i(ins[i]); MonoConvolve.cpp:179-201).
+config 4: Convolver 64x64, 2 s IRs (Convolver.cpp:138-154); rows {0, 7, 8, 63} — first / last row of the first output tile of
+          eight, first row of the second, last row of the matrix — so that the 64-input sum order of the OT = 8 / split-K launch is
+          compared with the reference's sequential per-pair sums at config-4 size.
+
+Tolerance: max|y - y_ref| <= 1e-5 * max|y_ref| per output channel for many-input sums.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_SUM = 1e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hisstools_library_amd as H
+    assert H.load().hcv_device_count() > 0, "no GPU visible: the HIP path cannot run (and there is no fallback)"
+    return H
+
+
+def test_config3_dense_full_size_vs_oracle(H, oracle):
+    """8 -> 1, L = 240 000 dense IRs, 300 000 samples: the stream runs past the IR length, so every one of the tail's 29
+    partitions per input is live at the end; hop-sized calls (whole-hop mode, the bench's steps) and ragged calls."""
+    nin, L, S = 8, 240000, 300000
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    irs = [oracle.synth_ir(i, 0, L) for i in range(nin)]
+    ref = oracle.NToMonoConvolve(nin, L, 0)
+    ref.setResetOffset(0)
+    gpu = H.NToMonoConvolve(nin, L, 0)
+    cnv = H.Convolver(nin, 1, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=8192)
+    for i in range(nin):
+        assert ref.set(i, irs[i], True) == 0 and gpu.set(i, irs[i], True) == 0 and cnv.set(i, 0, irs[i], True) == 0
+    y_ref = ref.run(xs, 2048)
+    y = gpu.run(xs, [4096, 333, 8192, 128, 20000])
+    assert rel_err(y, y_ref) < TOL_SUM, rel_err(y, y_ref)
+    assert rel_err(y[-40000:], y_ref[-40000:]) < TOL_SUM
+    # the bench's shape of call: whole 8192-sample hops through the Convolver-level object (one uniform convolution per block)
+    yc = cnv.run(xs[:, : 36 * 8192], 1, 8192)[0]
+    assert rel_err(yc, y_ref[: 36 * 8192]) < TOL_SUM, rel_err(yc, y_ref[: 36 * 8192])
+    tail = cnv.stage_stats()[-1]
+    assert tail["fft_size"] == 16384 and tail["partitions"] == 29
+
+
+def test_config4_dense_rows_vs_oracle(H, oracle):
+    """64x64, L = 96 000 dense IRs on every pair; rows 0, 7, 8, 63 against oracle.Convolver(64, 4) holding the same IRs;
+    16 hops of 8192 (past the IR length: P = 11 partitions all live, the unchecked split-K instantiation)."""
+    nin = nout = 64
+    L, B, hops = 96000, 8192, 16
+    S = hops * B
+    rows = [0, 7, 8, 63]
+    xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
+    ref = oracle.Convolver(nin, len(rows), 0)
+    ref.setResetOffset(0)
+    for o in range(nout):
+        for i in range(nin):
+            # (rows that are not compared still carry full-length dense IRs: their traffic is part of the launch)
+            h = oracle.synth_ir(i, o, L - 37 * ((i + o) % 5))
+            assert c.set(i, o, h, True) == 0
+            if o in rows:
+                assert ref.set(i, rows.index(o), h, True) == 0
+    c.clear_stats()
+    y = c.run(xs, nout, B)
+    y_ref, _ = ref.stream_timed(xs, len(rows), 2048)
+    for k, o in enumerate(rows):
+        assert rel_err(y[o], y_ref[k]) < TOL_SUM, (o, rel_err(y[o], y_ref[k]))
+        assert rel_err(y[o][-3 * B:], y_ref[k][-3 * B:]) < TOL_SUM
+    tail = c.stage_stats()[-1]
+    assert tail["partitions"] == 11 and tail["out_tile"] == 8 and tail["ksplit"] > 1 and tail["hop_tile"] == 1
+    assert tail["mac_steady_launches"] >= 3, tail

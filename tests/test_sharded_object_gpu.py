@@ -213,3 +213,112 @@ def test_random_cases_through_sharded_objects(monkeypatch):
         assert err <= fuzz_parity.TOL, (seed, kind, desc, err)
         ran += kind in ("convolver", "parallel")
     assert ran >= 20
+
+
+def _sparse_sharded_case(H, torch, nin, nout, L, hops, taps, seed, ndev, tol_vs_one, B=8192):
+    """BASELINE config shapes through ONE object over `ndev` engines (all on the one GPU of the test box): sparse taps spread over
+    the whole IR, built and streamed in HBM; compared with the unsharded HIP object and with the exact float64 answer (a
+    gain-weighted sum of delayed inputs, computed with torch: shifted adds, nothing of this library)."""
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(seed)
+    S = hops * B
+    P = -(-(L - B) // B)
+    pairs = nin * nout
+    delays = rng.randint(0, L, size=(nout, nin, taps))
+    walk = (np.arange(pairs) % P) * B + B + rng.randint(0, B, size=pairs)       # every tail partition index carries a tap of some pair
+    delays[:, :, 0] = np.minimum(walk, L - 1).reshape(nout, nin)
+    gains = rng.uniform(-1, 1, size=(nout, nin, taps))
+    one = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
+    many = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B, devices=[0] * ndev)
+    assert many.num_shards() == ndev
+    h = torch.zeros(L, dtype=torch.float32, device=dev)
+    for o in range(nout):
+        for i in range(nin):
+            idx = torch.from_numpy(delays[o, i]).to(dev)
+            h.index_put_((idx,), torch.from_numpy(gains[o, i].astype(np.float32)).to(dev), accumulate=True)
+            torch.cuda.synchronize()
+            assert one.set_dev(i, o, h.data_ptr(), L, True) == 0 and many.set_dev(i, o, h.data_ptr(), L, True) == 0
+            h.index_fill_(0, idx, 0.0)
+    xs = torch.from_numpy(rng.uniform(-1, 1, size=(nin, S)).astype(np.float32)).to(dev)
+    ys = [torch.zeros((nout, S), dtype=torch.float32, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for c, y in zip((one, many), ys):
+        for pos in range(0, S, B):                                   # asynchronous hop-sized calls back to back, one wait
+            c.process_dev(xs.data_ptr() + 4 * pos, S, y.data_ptr() + 4 * pos, S, nin, nout, B)
+        c.synchronize()
+    x64 = xs.to(torch.float64)
+    for o in range(nout):
+        t = torch.zeros(S, dtype=torch.float64, device=dev)
+        for i in range(nin):
+            for k in range(taps):
+                d = int(delays[o, i, k])
+                if d < S:
+                    t[d:] += float(np.float32(gains[o, i, k])) * x64[i, : S - d]
+        peak = float(t.abs().max())
+        e_truth = float((ys[1][o].to(torch.float64) - t).abs().max()) / peak
+        e_one = float((ys[1][o] - ys[0][o]).abs().max()) / peak
+        assert e_truth < 1e-5 and e_one < tol_vs_one, (o, e_truth, e_one)
+    return many
+
+
+def test_config4_shape_64x64_2s_eight_shards(H):
+    """BASELINE config 4 as stated — Convolver 64x64, 2 s @ 48 kHz IRs, channel pairs sharded eight ways — through ONE object:
+    output rows split over 8 engines (8 rows x 64 inputs each, no exchange; Convolver.cpp:138-154 per row).  Row sharding leaves
+    each row's arithmetic unchanged: <= 1e-6 of the unsharded HIP output."""
+    torch = pytest.importorskip("torch")
+    many = _sparse_sharded_case(H, torch, 64, 64, 96000, 16, 2, seed=404, ndev=8, tol_vs_one=1e-6)
+    tail = many.stage_stats()[-1]                                    # (statistics of the first shard)
+    assert tail["num_ins"] == 64 and tail["num_outs"] == 8 and tail["partitions"] == 11
+
+
+def test_config3_shape_8to1_5s_eight_shards_input_split(H):
+    """BASELINE config 3's matrix (8 -> 1, 5 s IRs) over 8 engines: a pure input split — every shard convolves ONE input and the
+    per-output sum of NToMonoConvolve.cpp:39-42 is taken across the shards (sum_parts on the root's stream).  The sum order
+    changes: <= 1e-5 of the unsharded HIP output."""
+    torch = pytest.importorskip("torch")
+    many = _sparse_sharded_case(H, torch, 8, 1, 240000, 40, 3, seed=303, ndev=8, tol_vs_one=1e-5)
+    tail = many.stage_stats()[-1]
+    assert tail["num_ins"] == 1 and tail["num_outs"] == 1 and tail["partitions"] == 29
+
+
+@pytest.mark.parametrize("nin,nout,ndev,tol", [(4, 4, 2, 1e-6), (8, 1, 4, 1e-5), (6, 2, 4, 1e-5), (9, 9, 8, 1e-6)])
+def test_sharded_object_enqueue_threads(H, oracle, monkeypatch, nin, nout, ndev, tol):
+    """One persistent enqueue thread per shard (hcv_shard_pool.h; the default when the shards are on several devices, forced here
+    on the one GPU): host-pointer calls (begin halves side by side, row groups' end halves side by side) and device-pointer
+    calls (blocks side by side, then the row roots' sums) give the unsharded object's stream; many small calls hammer the
+    post / report hand-off, pauses longer than the workers' spin window send them to sleep on their futex."""
+    import time
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("HCV_SHARD_THREADS", "1")
+    L, S, B = 20000, 6 * 8192, 8192
+    irs = {(i, o): oracle.synth_ir(i, o, L - 300 * i - 70 * o) for i in range(nin) for o in range(nout)}
+    xs_h = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    one = H.Convolver(nin, nout, 0, maxBlock=B)
+    many = H.Convolver(nin, nout, 0, maxBlock=B, devices=[0] * ndev)
+    for c in (one, many):
+        _load(c, irs)
+    blocks = [64] * 200 + [8192, 100, 3000, 8192]
+    y1, yn = one.run(xs_h, nout, blocks), many.run(xs_h, nout, blocks)
+    for o in range(nout):
+        assert rel_err(yn[o], y1[o]) < tol, (o, rel_err(yn[o], y1[o]))
+    xs = torch.from_numpy(xs_h).to(dev)
+    ys = [torch.zeros((nout, S), device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for c, y in zip((one, many), ys):
+        c.reset()
+        for k, pos in enumerate(range(0, S, B)):
+            if k == 3:
+                time.sleep(0.01)                                       # the workers go to sleep; the next call wakes them
+            c.process_dev(xs.data_ptr() + 4 * pos, S, y.data_ptr() + 4 * pos, S, nin, nout, B)
+        c.synchronize()
+    a, b = ys[0].cpu().numpy(), ys[1].cpu().numpy()
+    for o in range(nout):
+        assert rel_err(b[o], a[o]) < tol, (o, rel_err(b[o], a[o]))
+    # control calls from this thread while the workers exist, then a destroy with sleeping workers
+    assert many.set(nin - 1, nout - 1, irs[(0, 0)], True) == 0 and one.set(nin - 1, nout - 1, irs[(0, 0)], True) == 0
+    y1b, ynb = one.run(xs_h[:, :9000], nout, 1000), many.run(xs_h[:, :9000], nout, 1000)
+    for o in range(nout):
+        assert rel_err(ynb[o], y1b[o]) < max(tol, 2e-6)
+    time.sleep(0.01)
+    del many

@@ -34,8 +34,14 @@ N > 1 (launched by torch.distributed.run, one rank per GPU):
 `--sharding grid` forces the input split on weak scaling too ((N/2) x 2 ranks).  BENCH_BACKEND=gloo lets several ranks
 share one GPU to check the paths on a one-GPU box.
 
-On one GPU the default run also carries `config.also`: the digest (value, roofline, self-check error) of a child bench of the
-64x64 / 10 s @ 48 kHz shape north_star states its HBM target on (`--also ""` skips it, `--also c4` picks another workload).
+`config.also` — every BASELINE config under the same clock.  A run with no --workload / --scaling (what the driver calls) carries,
+besides the headline, the digests (value, ms per step, roofline object, self-check error, one-core CPU figure) of further workloads:
+    one GPU   child benches of ns64 (the 64x64 / 10 s @ 48 kHz shape north_star states its HBM target on; with paced real-time legs
+              at 128 / 64 / 32 samples per call), c4 (the same legs), c3, c2 and c1;
+    N > 1     in process, on the same ranks, STRONG-scaled: c4 — BASELINE config 4 as stated, the 64x64 matrix split over the ranks by
+              output rows — and c3 — 8 -> 1 split by inputs, one all-reduce per step; each with a self-check in which every rank
+              streams its block (collective included) and rank 0 compares with the reference CPU leg.
+`--also ""` skips them, `--also c4,c2` picks others.  The headline itself is unchanged by them (N = 1: same engine, same steps).
 
 The CPU baseline leg (rank 0, N = 1 only) times the UNMODIFIED reference (oracle/_ref, when the prebuilt library
 travelled with the repo; else the C port) on a bounded sub-matrix of the same workload on one host core.
@@ -206,7 +212,7 @@ def cpu_baseline(workload, hops=64):
     }
 
 
-def cpu_baseline_all_cores(workload, max_threads=64, hops=16):
+def cpu_baseline_all_cores(workload, max_threads=64, hops=8):
     """The only parallel decomposition the reference API admits (it has no threads of its own): one Convolver per host
     thread over disjoint output rows.  Each thread streams its own (sub_in x 1) Convolver with the workload's IR length;
     the IR set is synthesised once and shared.  Returns the summed rate as a whole-matrix-equivalent output rate."""
@@ -219,7 +225,10 @@ def cpu_baseline_all_cores(workload, max_threads=64, hops=16):
     backend = "ref" if kind == "reference" else "port"
     threads = max(1, min(os.cpu_count() or 1, max_threads))
     tail, p_tail = stage_layout(L, layout)[-1]
-    sub_in = min(nin, 4 if p_tail > 100 else 8)
+    # the leg is bounded to about ten seconds: what it costs is the warm-up (P hops at a growing partition count — the reference
+    # only multiplies partitions that have seen input, PartitionedConvolve.cpp:285,322), so long tails stream ONE pair per thread
+    # and time eight hops; the per-pair work (IR length, partitioning, call size) is the workload's
+    sub_in = min(nin, 1 if p_tail > 100 else 8)
     hop = tail // 2
     warm, S = p_tail * hop, hops * hop
     irs = [O.synth_ir(i, 0, L) for i in range(sub_in)]
@@ -283,20 +292,20 @@ def shard_plan(nin, nout, world, rank, scaling, sharding):
     return {"nin_total": nin, "nout_total": nout * go, "go": go, "gi": gi, "row": row, "col": col, "in": (i_lo, i_hi), "out": (row * nout, (row + 1) * nout)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default c5 (the config the metric's HBM clause is quoted on)")
     ap.add_argument("--block", type=int, default=8192)
     ap.add_argument("--batched-block", type=int, default=65536, help="also time offline-style calls of this many samples (0 = skip)")
     ap.add_argument("--tail-ratio", type=int, default=0, help="run the HEADLINE on the extended far-tail ladder (0 = reference partitioning)")
     ap.add_argument("--extended-ratio", type=int, default=8, help="also measure the extended far-tail ladder with this ratio (0 = skip)")
     ap.add_argument("--ir-file", default="", help="WAVE / AIFF / AIFC file with real impulse responses instead of the synthetic ones")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank brings its own nout output rows (per-GPU work fixed).  strong: the workload's matrix is fixed and split "
-                         "over the ranks — output rows first, inputs too when there are fewer rows than ranks (then one all-reduce per step)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak (default): every rank brings its own nout output rows (per-GPU work fixed).  strong: the workload's matrix is fixed and "
+                         "split over the ranks — output rows first, inputs too when there are fewer rows than ranks (then one all-reduce per step)")
     ap.add_argument("--sharding", default="rows", choices=["rows", "grid"],
                     help="weak scaling only.  rows: every rank owns output rows and all inputs, no data-path collective (default).  grid: (N/2) x 2 "
                          "ranks — the two ranks of a row group each convolve half of the inputs and sum their partial outputs with one RCCL "
@@ -306,14 +315,25 @@ def main():
     ap.add_argument("--no-self-check", action="store_true", help="skip the comparison with the CPU leg's output after the timed region")
     ap.add_argument("--realtime-block", type=int, default=128,
                     help="also measure paced real-time calls of this many samples through the host-pointer and device-pointer entry points (0 = skip)")
+    ap.add_argument("--realtime-extra", default="", help="further paced call sizes, comma separated (e.g. 64,32): p50 / p99 / max against their budgets")
     ap.add_argument("--also", default=None,
-                    help="one GPU only: after the headline, run this workload too (a child bench with its own self-check against the CPU "
-                         "reference; no batched / real-time / extended legs) and attach its digest as config.also — by default the 64x64 / "
-                         "10 s @ 48 kHz shape north_star sets the HBM target on, when the headline is the default workload ('' = skip)")
-    args = ap.parse_args()
-    if args.also is None:
-        args.also = "ns64" if args.workload == "c5" else ""
+                    help="further workloads after the headline, comma separated, each with its own engine, timed region, roofline object and "
+                         "self-check against the CPU reference; their digests go to config.also.  One GPU: child processes; default (headline "
+                         "= the default workload) ns64,c4,c3,c2,c1 — the north-star shape and every other BASELINE config.  N > 1 ranks: run "
+                         "in process by all ranks with STRONG scaling; default c4,c3 — BASELINE config 4 as stated (64x64 split over the "
+                         "ranks by output rows) and config 3's input split with one all-reduce per step.  '' = none")
+    ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)       # a child bench of an `also` leg: a digest-sized run
+    args = ap.parse_args(argv)
+    args.default_run = args.workload is None and args.scaling is None and not args.ir_file and not args.tail_ratio and args.sharding == "rows"
+    if args.workload is None:
+        args.workload = "c5"
+    if args.scaling is None:
+        args.scaling = "weak"
+    return args
 
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # convenience: re-launch ourselves one rank per GPU
@@ -321,7 +341,6 @@ def main():
                "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -341,9 +360,86 @@ def main():
             dist.init_process_group(backend)
     if args.sharding == "grid" and (world < 2 or world % 2 or args.scaling != "weak"):
         raise SystemExit("--sharding grid needs weak scaling and an even number of ranks (>= 2)")
+    ctx = {"world": world, "rank": rank, "local": local, "dev": dev, "backend": backend}
 
+    also = args.also
+    if also is None:
+        also = ("ns64,c4,c3,c2,c1" if world == 1 else "c4,c3") if args.default_run else ""
+    also = [w for w in also.split(",") if w and (w != args.workload or world > 1)]
+
+    line = bench_line(args, ctx)
+
+    if also and not args.ir_file:
+        digests = []
+        if world == 1:
+            for w in also:
+                digests.append(also_leg(w, local))
+        else:
+            # N > 1: the further workloads run IN PROCESS on the same ranks and process group, STRONG-scaled — the workload's own
+            # matrix split over the ranks (c4: 64x64 by output rows, no exchange; c3: 8 -> 1 by inputs, one all-reduce per step)
+            for w in also:
+                digests.append(strong_leg(w, args, ctx))
+        if rank == 0 and line is not None:
+            line["config"]["also"] = digests
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def strong_leg(workload, args, ctx, steps=40, warmup=5):
+    """N > 1: one more workload on the ranks the headline ran on, strong-scaled, with a self-check in which EVERY rank streams its
+    share (the collective of an input-split layout included) and rank 0 compares with the reference CPU leg.  Returns the digest
+    (rank 0) or None."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.scaling, a.sharding = workload, "strong", "rows"
+    a.steps, a.warmup = min(args.steps, steps), min(args.warmup, warmup)
+    a.batched_block, a.extended_ratio, a.realtime_block, a.realtime_extra, a.tail_ratio = 0, 0, 0, "", 0
+    a.no_all_cores, a.no_cpu_baseline, a.leg = True, False, True         # (the bounded CPU leg is this leg's checker; --no-self-check skips both)
+    if args.no_self_check:
+        a.no_cpu_baseline = True
+    t0 = time.perf_counter()
+    try:
+        d = bench_line(a, ctx)
+    except SystemExit as e:         # e.g. a matrix that cannot be split over this many ranks
+        return {"workload": workload, "scaling": "strong", "error": str(e)}
+    if d is None:
+        return None
+    out = digest_of(d)
+    out.pop("cpu_baseline", None)       # (every rank computed the bounded reference at once: a checker here, not a clean one-core timing)
+    out["scaling"] = "strong"
+    out["sharding"] = d["config"].get("sharding")
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def digest_of(d):
+    """What config.also keeps of a bench line"""
+    rf, sc = d.get("roofline", {}), d.get("config", {}).get("self_check") or {}
+    out = {
+        "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "n_gpus": d["n_gpus"], "steps": d["steps"], "warmup": d["warmup"],
+        "ms_per_step": d["ms_per_step"], "realtime_factor": d["config"].get("realtime_factor"),
+        "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
+                                            "launches", "steady_launches", "traffic", "traffic_source", "profiled_ms_per_step")},
+        "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches", "error") if k in sc},
+        "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
+    }
+    rt = d.get("config", {}).get("realtime")
+    if rt:
+        out["realtime"] = rt
+    return out
+
+
+def bench_line(args, ctx):
+    """One workload on the ranks of `ctx`: engine, inputs, timed region, roofline object, CPU legs, self-check.  Returns the JSON
+    line as a dict on rank 0, None elsewhere."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     import hisstools_library_amd as H
 
+    world, rank, local, dev, backend = ctx["world"], ctx["rank"], ctx["local"], ctx["dev"], ctx["backend"]
     nin_w, nout_w, L, fs, layout = WORKLOADS[args.workload]
     B = args.block
     plan = shard_plan(nin_w, nout_w, world, rank, args.scaling, args.sharding)
@@ -374,6 +470,8 @@ def main():
         buf[:, :take] = torch.from_numpy(data[:, :take]).to(dev)
         file_irs = buf
 
+    rccl_direct = reduce_path and backend == "nccl" and not os.environ.get("BENCH_TORCH_ALLREDUCE")
+
     def run(tail_ratio, steps, warmup, batched_block, keep=False):
         """Build an engine (reference partitioning, or the extended far-tail ladder), load the synthetic IRs (decaying
         noise, unit L2 norm) into HBM, reach steady state, then time `steps` process calls of B samples."""
@@ -401,7 +499,6 @@ def main():
         # reduce path over RCCL: the library enqueues ncclAllReduce on the engine's own stream behind the block — no host
         # synchronisation between convolution and collective, so the exchange overlaps the next block's FFTs and MAC.  The
         # communicator of a row group is made from a unique id its first rank draws (distributed through torch's store).
-        rccl_direct = reduce_path and backend == "nccl" and not os.environ.get("BENCH_TORCH_ALLREDUCE")
         if rccl_direct:
             ids = [None] * world
             dist.all_gather_object(ids, H.rccl_unique_id() if plan["col"] == 0 else None)
@@ -518,40 +615,62 @@ def main():
     elapsed, stats, finite, batched, t_load, conv = run(args.tail_ratio, args.steps, args.warmup, BB, keep=True)
 
     # ---- CPU legs (rank 0, one GPU): the unmodified reference on the box's host cores; the one-core leg's output is the
-    # reference of the self-check below
+    # reference of the self-check below.  (A strong-scaled leg of an N > 1 run — `--leg` — checks itself too: there EVERY rank
+    # computes the bounded reference, a second or two, instead of idling in a collective while rank 0 does.)
     cpu, cpu_all = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    check_all_ranks = world > 1 and args.leg and args.scaling == "strong" and not args.no_self_check
+    if ((rank == 0 and world == 1) or check_all_ranks) and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(args.workload)
+            cpu = cpu_baseline(args.workload, hops=16 if check_all_ranks else 64)
         except Exception as e:      # the baseline must never take the GPU number down with it
             cpu = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
 
     # ---- self-check: the same engine, reset, streams the CPU leg's inputs (the other inputs silent) in the same B-sample
     # steps as the timed region — through the ramp-up (partition bounds checked) into the steady state (the timed kernel
-    # instantiation) — and the CPU leg's output rows are compared sample by sample
+    # instantiation) — and the CPU leg's output rows are compared sample by sample.  On N > 1 ranks every rank streams its own
+    # block of the matrix (its share of the CPU leg's inputs; on the reduce path the all-reduce of every step included) and
+    # rank 0 compares the rows it holds.
     self_check = None
-    if cpu is not None and cpu.get("_outs") is not None and not args.no_self_check and not args.tail_ratio:
+    have_ref = cpu is not None and cpu.get("_outs") is not None
+    if world > 1 and check_all_ranks:
+        flag = torch.tensor([1.0 if have_ref else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        have_ref = bool(flag.item() > 0.5)
+    if have_ref and not args.no_self_check and not args.tail_ratio:
         try:
             sub_in, sub_out, S_chk = cpu["_sub"]
             ref = cpu["_outs"]
             S_run = -(-S_chk // B) * B
-            xc = torch.zeros((nin, S_run), device=dev, dtype=torch.float32)
-            for i in range(sub_in):
-                xc[i, :S_chk] = torch.from_numpy(synth_audio(i, S_chk)).to(dev)
+            xc = torch.zeros((max(nin, 1), S_run), device=dev, dtype=torch.float32)
+            for i in range(in_lo, min(in_hi, sub_in)):
+                xc[i - in_lo, :S_chk] = torch.from_numpy(synth_audio(i, S_chk)).to(dev)
             yc = torch.zeros((nout, S_run), device=dev, dtype=torch.float32)
             conv.reset()
             conv.clear_stats()
             for pos in range(0, S_run, B):
-                conv.process_dev(xc.data_ptr() + 4 * pos, S_run, yc.data_ptr() + 4 * pos, S_run, nin, nout, B)
+                if not reduce_path:
+                    conv.process_dev(xc.data_ptr() + 4 * pos, S_run, yc.data_ptr() + 4 * pos, S_run, nin, nout, B)
+                elif rccl_direct:
+                    conv.process_dev_allreduce(xc.data_ptr() + 4 * pos, S_run, yc.data_ptr() + 4 * pos, S_run, nin, nout, B)
+                else:
+                    conv.process_dev(xc.data_ptr() + 4 * pos, S_run, yb.data_ptr(), B, nin, nout, B)
+                    conv.synchronize()
+                    dist.all_reduce(yb, op=dist.ReduceOp.SUM, group=row_group)
+                    yc[:, pos:pos + B] = yb
+                    torch.cuda.synchronize()
             conv.synchronize()
-            got = yc[:sub_out, :S_chk].cpu().numpy().astype(np.float64)
+            rows = [o for o in range(sub_out) if out_lo <= o < out_hi]        # (rank 0 holds the first rows of the matrix)
+            got = yc[[o - out_lo for o in rows], :S_chk].cpu().numpy().astype(np.float64) if rows else np.zeros((0, S_chk))
             st_chk = conv.stage_stats()[-1]
-            errs = [float(np.abs(got[o] - ref[o]).max() / np.abs(ref[o]).max()) for o in range(sub_out)]
-            tail_span = slice(S_chk - 64 * (stages[-1][0] // 2), S_chk)       # the span the CPU leg timed: every partition live
-            err_tail = max(float(np.abs(got[o][tail_span] - ref[o][tail_span]).max() / np.abs(ref[o]).max()) for o in range(sub_out))
+            errs = [float(np.abs(got[k] - ref[o]).max() / np.abs(ref[o]).max()) for k, o in enumerate(rows)] or [float("nan")]
+            n_hops_ref = 16 if check_all_ranks else 64
+            tail_span = slice(S_chk - n_hops_ref * (stages[-1][0] // 2), S_chk)       # the span the CPU leg timed: every partition live
+            err_tail = max([float(np.abs(got[k][tail_span] - ref[o][tail_span]).max() / np.abs(ref[o]).max()) for k, o in enumerate(rows)] or [float("nan")])
             self_check = {"max_rel_err": float(f"{max(errs):.3e}"), "max_rel_err_steady_span": float(f"{err_tail:.3e}"),
-                          "against": f"{cpu['kind']} CPU leg: output rows 0..{sub_out - 1} from inputs 0..{sub_in - 1} (the other inputs silent), "
-                                     f"{S_chk} samples in {B}-sample steps after a reset, on the timed engine and spectra",
+                          "against": f"{cpu['kind']} CPU leg: output rows {rows[0] if rows else '-'}..{rows[-1] if rows else '-'} from inputs 0..{sub_in - 1} (the other "
+                                     f"inputs silent), {S_chk} samples in {B}-sample steps after a reset, on the timed engine(s) and spectra"
+                                     + (f"; every one of the {world} ranks streamed its block" + (", all-reduce per step included" if reduce_path else "")
+                                        if world > 1 else ""),
                           "tolerance": 1e-5, "ok": bool(max(errs) <= 1e-5),
                           "mac_launches": int(st_chk["mac_launches"]), "mac_steady_launches": int(st_chk["mac_steady_launches"])}
             del xc, yc
@@ -563,7 +682,8 @@ def main():
     realtime = None
     if args.realtime_block and world == 1 and not args.tail_ratio:
         try:
-            realtime = realtime_leg(conv, np, torch, dev, nin, nout, fs, args.realtime_block, stages)
+            extra = [int(v) for v in args.realtime_extra.split(",") if v.strip()]
+            realtime = realtime_leg(conv, np, torch, dev, nin, nout, fs, args.realtime_block, stages, extra_blocks=extra)
         except Exception as e:
             realtime = {"error": str(e)}
     del conv
@@ -699,19 +819,17 @@ def main():
             line["cpu_baseline"] = cpu
         if cpu_all is not None:
             line["cpu_baseline_all_cores"] = cpu_all
-        if args.also and args.also != args.workload and world == 1 and not args.ir_file:
-            line["config"]["also"] = also_leg(args.also, local)
-        print(json.dumps(line), flush=True)
-
-    if world > 1:
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 def also_leg(workload, device, steps=40, warmup=5, timeout=420):
-    """A second workload after the headline, in a child process (its own engine, inputs, timed region and self-check against the
-    reference CPU leg): the digest of the child's bench line.  Never takes the headline down."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "",
-           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "0", "--realtime-block", "0"]
+    """A further workload after the headline, in a child process (its own engine, inputs, timed region and self-check against the
+    reference CPU leg): the digest of the child's bench line.  The two 64x64 shapes also run the paced real-time legs (128-, 64-
+    and 32-sample calls).  Never takes the headline down."""
+    rt = ["--realtime-block", "128", "--realtime-extra", "64,32"] if workload in ("ns64", "c4") else ["--realtime-block", "0"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "", "--leg",
+           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "0"] + rt
     env = dict(os.environ, LOCAL_RANK=str(device), RANK="0", WORLD_SIZE="1")     # the same GPU as the headline
     t0 = time.perf_counter()
     try:
@@ -722,19 +840,12 @@ def also_leg(workload, device, steps=40, warmup=5, timeout=420):
         d = json.loads(rows[-1])
     except Exception as e:
         return {"workload": workload, "error": str(e)}
-    rf, sc = d.get("roofline", {}), d.get("config", {}).get("self_check") or {}
-    return {
-        "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
-        "ms_per_step": d["ms_per_step"], "realtime_factor": d["config"].get("realtime_factor"),
-        "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
-                                            "launches", "steady_launches", "traffic", "traffic_source")},
-        "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches")},
-        "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
-        "seconds": round(time.perf_counter() - t0, 1),
-    }
+    dg = digest_of(d)
+    dg["seconds"] = round(time.perf_counter() - t0, 1)
+    return dg
 
 
-def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6):
+def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6, extra_blocks=()):
     """Paced real-time calls on the engine the headline ran on (every partition live): call k is issued no earlier than
     k * RB / fs.  `host`: hcv_convolver_process_f32 (host pointers in, host pointers out — what HISSTools::Convolver::process
     does); `device`: hcv_convolver_process_f32_dev with sync (HBM-resident audio).  Milliseconds per call."""
@@ -778,6 +889,27 @@ def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6):
     out["host_pointers"] = paced(host_call)
     out["device_pointers"] = paced(dev_call)
     out["finite"] = bool(np.isfinite(yout).all() and torch.isfinite(yd).all().item())
+    fed = 2 * (8 + ncalls) * RB
+    # smaller hosts (64- and 32-sample callbacks: 1.33 / 0.67 ms budgets at 48 kHz), host pointers only — what such a host calls
+    for EB in extra_blocks:
+        if EB <= 0 or EB > RB:
+            continue
+        n_e = max(64, int(0.4 * fs / EB))
+        ts = np.zeros(n_e)
+        t_start = time.perf_counter()
+        for k in range(n_e):
+            while time.perf_counter() < t_start + k * EB / fs:
+                pass
+            t0 = time.perf_counter()
+            if L.hcv_convolver_process_f32(conv.h, ip, op, nin, nout, EB) != 0:
+                raise RuntimeError("process_f32 failed")
+            ts[k] = time.perf_counter() - t0
+        ts *= 1e3
+        b_e = 1e3 * EB / fs
+        out.setdefault("small_blocks", {})[str(EB)] = {
+            "budget_ms": round(b_e, 4), "calls": n_e, "p50_ms": round(float(np.percentile(ts, 50)), 4), "p99_ms": round(float(np.percentile(ts, 99)), 4),
+            "max_ms": round(float(ts.max()), 4), "over_budget": int((ts > b_e).sum())}
+        fed += n_e * EB
     # the headline's step through HOST pointers (what every existing caller of HISSTools::Convolver::process does): one
     # synchronous call of `hop` samples per step — pinned staging copies, PCIe both ways and the wait included.  Never `value`.
     hop = stages[-1][0] // 2
@@ -788,7 +920,7 @@ def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6):
     nsteps = 24
     # the paced legs fed 2 x (8 + ncalls) calls of RB samples: bring the stream back to a hop boundary, so that these steps are
     # the headline's (whole, aligned hops) and not a run of unaligned 8192-sample calls through every stage
-    pad = (-(2 * (8 + ncalls) * RB)) % hop
+    pad = (-fed) % hop
     if pad and L.hcv_convolver_process_f32(conv.h, ih, oh, nin, nout, pad) != 0:
         raise RuntimeError("process_f32 failed")
 

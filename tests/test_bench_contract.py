@@ -89,7 +89,8 @@ def test_bench_line_has_the_contract_fields():
     assert rt["host_pointers"]["p99_ms"] > 0 and rt["device_pointers"]["p99_ms"] > 0 and rt["finite"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "Msamples/s" and c["sample"]
-    a = d["config"]["also"]                                                             # the second workload's digest (default: the 64x64 / 10 s shape)
+    assert len(d["config"]["also"]) == 1                                                # digests of the further workloads (default: ns64, c4, c3, c2, c1)
+    a = d["config"]["also"][0]
     assert "error" not in a, a
     assert a["workload"].startswith("c2:") and a["value"] > 0 and a["self_check"]["ok"] and a["self_check"]["max_rel_err"] <= 1e-5
     assert a["roofline"]["bound"] in ("hbm", "launch") and a["roofline"]["avg_launch_ms"] > 0

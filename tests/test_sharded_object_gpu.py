@@ -201,6 +201,32 @@ def test_bench_two_ranks_share_the_gpu(workload, flags):
         assert f"({nin}x{nout} over 2 GPU)" in d["config"]["workload"]
 
 
+def test_bench_default_two_ranks_attach_strong_legs():
+    """A bare `bench.py --gpus 2` (what the driver's scaling run calls, here with two ranks on the one GPU over gloo): the headline
+    stays the weak-scaled default workload, and config.also carries BASELINE config 4 as stated — the 64x64 matrix split over the
+    ranks by output rows — and config 3's input split with one all-reduce per step, each strong-scaled on the same ranks with a
+    self-check in which every rank streams its share."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batched-block", "0",
+           "--extended-ratio", "0", "--realtime-block", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "(16x32 over 2 GPU)" in d["config"]["workload"] and d["value"] > 0
+    legs = d["config"]["also"]
+    assert [a["workload"].split(":")[0] for a in legs] == ["c4", "c3"]
+    for a, shape, word in zip(legs, ("(64x64 over 2 GPU)", "(8x1 over 2 GPU)"), ("output rows per rank", "all-reduce")):
+        assert "error" not in a, a
+        assert a["scaling"] == "strong" and a["n_gpus"] == 2 and shape in a["workload"] and word in a["sharding"]
+        assert a["value"] > 0 and a["self_check"]["ok"] and a["self_check"]["max_rel_err"] <= 1e-5, a
+
+
 def test_random_cases_through_sharded_objects(monkeypatch):
     """The randomised differential test (tests/perf/fuzz_parity.py: random matrices, latencies, call sizes, live IR swaps, clears and
     resets) with HCV_DEVICES set, so that every Convolver it builds is ONE object over two engines."""

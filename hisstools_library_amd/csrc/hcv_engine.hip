@@ -262,6 +262,7 @@ bool Engine::init(const EngineCfg &cfg)
         mStages.push_back(st);
         st->tw = twiddles(mDevice, st->log2n, &mErr);
         if (!st->tw) return false;
+        fft_split_prepare(st->log2n);               // (tables of the residue-split transforms, hcv_fft_split.hip)
         if (!alloc_stage(*st)) return false;
     }
     if (mLeadSlot) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages.back()->M));

@@ -241,7 +241,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         if (!wcheck && pw.nt) st.steady_launches++;
         const long long w_elems = (long long) T * nout_act * st.M;
         static const int fold_max_w = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
-        const bool fold_w = pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial);
+        // (every workgroup of a residue-split inverse stages the WHOLE spectrum: it takes the one summed slice)
+        const bool fold_w = pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial) &&
+                            !(blk.direct_out && fft_split_applies(st.log2n, T * (int) nout_act));
         if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sM != sI ? sM : sI));
         if (sM != sI)
         {
@@ -537,8 +539,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     bool want_pipe2 = pipe2_env > 0;
     if (pipe2_env < 0 && !mCallWaits && !mStages.empty())
     {
+        // (not where the residue-split transforms run, hcv_fft_split.hip: spread over 9 CUs instead of one the transforms are no
+        // longer the long part of the chain, and the serial chain beats the hand-overs — c1 0.0179 against 0.0200 ms per block)
         const Stage &tl = *mStages[last];
-        want_pipe2 = tl.log2n >= 14;
+        const int hops = (int) (B / tl.M);
+        want_pipe2 = tl.log2n >= 14 && !fft_split_applies(tl.log2n, hops * (int) rows_in);
     }
     blk.pipe2 = want_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr;
     if (blk.pipe2)

@@ -39,6 +39,16 @@ namespace hcv
     hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
                                  const float2 *tw, hipStream_t st);
 
+    // ---- residue-split transforms (hcv_fft_split.hip): one hop transform over several workgroups that share nothing, for blocks
+    //      of a few transforms.  `applies` = the rule (HCV_FFT_SPLIT = 0 / 1 forces it); `prepare` uploads the sub-transform tables
+    //      of the current device ahead of the first launch.
+    bool fft_split_applies(int log2n, int transforms);
+    void fft_split_prepare(int log2n);
+    hipError_t launch_rfft_frames_direct_split(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride,
+                                               long long n0, long long h_first, int T, int nin, float2 *X, int R, const float2 *tw, hipStream_t st);
+    hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
+                                       const float2 *tw, hipStream_t st);
+
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,
                                int R, const float2 *tw, const BigFFTWork &w, hipStream_t st);
     hipError_t big_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork &w, hipStream_t st);

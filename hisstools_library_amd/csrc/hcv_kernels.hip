@@ -716,6 +716,7 @@ hipError_t launch_rfft_frames_direct(int log2n, float *hist, long long hist_stri
 {
     if (T <= 0 || nin <= 0) return hipSuccess;
     if (is_big_fft(log2n)) return hipErrorInvalidValue;
+    if (fft_split_applies(log2n, T * nin)) return launch_rfft_frames_direct_split(log2n, hist, hist_stride, hist_mask, in, in_stride, n0, h_first, T, nin, X, R, tw, st);
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();
@@ -797,6 +798,7 @@ hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long k
 {
     if (T <= 0 || nout <= 0) return hipSuccess;
     if (is_big_fft(log2n)) return hipErrorInvalidValue;
+    if (fft_split_applies(log2n, T * nout)) return launch_rifft_emit_split(log2n, Y, ksplit, ks_stride, T, nout, out, out_stride, tw, st);
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
         size_t lds = fft_lds_bytes<L>();

@@ -1,0 +1,54 @@
+"""The residue-split hop transforms (hcv_fft_split.hip: one real transform over R/2 + 1 forward / R/2 inverse workgroups that share
+nothing; replaces hisstools_rfft / hisstools_rifft per hop, HISSTools_FFT.cpp:226-248, for blocks of a few transforms).
+
+By default they serve whole-hop blocks of at most 16 transforms of 16384 points (the 1 x 1 and 8 -> 1 engines: BASELINE configs 1
+and 3), so the default suites already run them.  Here every split radix that is built is FORCED for both transform sizes
+(HCV_FFT_SPLIT=1 — read once per process, hence the child processes) and the parity suites that drive whole-hop blocks are run
+under it: oracle, golden vectors and float64 truth, tolerance as stated in those files (2e-6 / 1e-5 of the output peak).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SUITE = ["tests/test_small_engine_pipeline_gpu.py", "tests/test_configs_dense_gpu.py::test_config3_dense_full_size_vs_oracle",
+         "tests/test_gpu_parity.py::test_config2_shape_partitioned_10s", "tests/test_gpu_parity.py::test_config3_shape_8to1_5s_impulse_irs",
+         "tests/test_pair_restart_gpu.py", "tests/test_steady_state_gpu.py::test_dense_irs_16x16_steady_state_vs_oracle"]
+
+
+@pytest.mark.parametrize("env", [{"HCV_FFT_SPLIT_R14": "4", "HCV_FFT_SPLIT_R12": "3"}, {"HCV_FFT_SPLIT_R14": "3", "HCV_FFT_SPLIT_R12": "2"},
+                                 {"HCV_FFT_SPLIT_R14": "5", "HCV_FFT_SPLIT_R12": "4"}])
+def test_parity_suites_with_split_transforms_forced(env):
+    e = dict(os.environ, HCV_FFT_SPLIT="1", **env)
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", "mono or config1 or config2 or config3 or pipelined or restart or dense or swap"]
+                         + SUITE + ["tests/test_gpu_parity.py"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
+def test_split_off_matches_split_on_bitwise_in_neither_direction_but_to_rounding():
+    """the same 8 -> 1 stream with the split transforms (default) and without (HCV_FFT_SPLIT=0): two different factorizations of
+    the same transforms, equal to rounding (<= 2e-6 of the peak), and both within tolerance of the float64 truth"""
+    code = ("import numpy as np, hisstools_library_amd as H\n"
+            "from oracle import oracle as O\n"
+            "nin, L, S = 8, 100000, 20 * 8192\n"
+            "xs = np.stack([O.synth_audio(i, S) for i in range(nin)])\n"
+            "c = H.Convolver(nin, 1, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=8192)\n"
+            "for i in range(nin): assert c.set(i, 0, O.synth_ir(i, 0, L), True) == 0\n"
+            "np.save(__import__('sys').argv[1], c.run(xs, 1, 8192))\n")
+    import numpy as np
+    import tempfile
+    ys = []
+    with tempfile.TemporaryDirectory() as d:
+        for k, mode in enumerate(("0", "1")):
+            path = os.path.join(d, f"y{k}.npy")
+            out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HCV_FFT_SPLIT=mode))
+            assert out.returncode == 0, out.stderr[-2000:]
+            ys.append(np.load(path))
+    peak = np.abs(ys[0]).max()
+    assert np.abs(ys[0] - ys[1]).max() <= 2e-6 * peak
+    assert np.abs(ys[0] - ys[1]).max() > 0           # (they ARE different code paths)

@@ -176,7 +176,8 @@ namespace hcv
         void collect_events();
         // exact per-pair restart (hcv_ghost.hip): ghost spectra of the input before the restart, the pair's pending output retired
         struct GhostEvent;
-        bool mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream);
+        bool mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream,
+                 bool fuse_reduce = false);
         bool retire_pair(size_t pair);
         bool make_ghost_event(const std::vector<size_t> &pairs);
         bool rebuild_ghost_tables();

@@ -308,6 +308,8 @@ bool Engine::alloc_stage(Stage &st)
     st.Y = st.Yq[0];
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
+    HCV_TRY(hipMalloc(&st.tickets, sizeof(unsigned) * kMacTickets));
+    HCV_TRY(hipMemset(st.tickets, 0, sizeof(unsigned) * kMacTickets));
     HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) kBgSlices * mCfg.nout * st.M));
     HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
     if (is_big_fft(st.log2n))
@@ -363,6 +365,7 @@ void Engine::free_stage(Stage &st)
         st.mac_done[k] = nullptr;
     }
     if (st.hv) (void) hipFree(st.hv);
+    if (st.tickets) (void) hipFree(st.tickets);
     if (st.gh_start) (void) hipFree(st.gh_start);
     if (st.gh_ent) (void) hipFree(st.gh_ent);
     st.gh_start = nullptr;

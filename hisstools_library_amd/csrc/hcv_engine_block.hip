@@ -229,8 +229,14 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
         MacPlan pw;
         mac_plan(sw, pw);
+        // HCV_FUSE_REDUCE = 1 (default OFF — measured slower): a small engine's split-K slices added up by the MAC launch itself (its
+        // last workgroup per bin block, in reduce_partials' order: bit-identical), one launch less in a chain of four.  The
+        // publication costs more than the launch it saves: 8 -> 1, MAC 7.7 us + reduction 4.1 against 13.9 fused with write-through
+        // stores and L1-bypassing loads, 26 with agent-scope fences
+        static const bool fuse_env = std::getenv("HCV_FUSE_REDUCE") && std::atoi(std::getenv("HCV_FUSE_REDUCE")) != 0;
+        const bool fused = fuse_env && serial && st.tickets && mac_can_fuse_reduce(pw);
         if (!begin_event()) return false;
-        if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM)) return false;
+        if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM, fused)) return false;
         if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
         st.launches++;
         st.hops += (uint64_t) T;
@@ -242,9 +248,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const long long w_elems = (long long) T * nout_act * st.M;
         static const int fold_max_w = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
         // (every workgroup of a residue-split inverse stages the WHOLE spectrum: it takes the one summed slice)
-        const bool fold_w = pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial) &&
+        const bool fold_w = !fused && pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial) &&
                             !(blk.direct_out && fft_split_applies(st.log2n, T * (int) nout_act));
-        if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sM != sI ? sM : sI));
+        if (!fold_w && !fused) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sM != sI ? sM : sI));
         if (sM != sI)
         {
             // (three-deep pipeline: hand the reduced spectra over to the inverse on the main stream)
@@ -607,9 +613,20 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     blk.tail_gate = tail_gate;
 
 
+    // XCD pinning (hcv_kernels.h: xcd_pin_for): a serial whole-hop block whose live spectra and input ring fit ONE XCD's L2 with
+    // room to spare keeps its three or four tiny launches on one XCD, so that each kernel finds its predecessor's output in that
+    // L2 instead of fetching it from the memory side (c1: 0.0182 -> 0.0169 ms per block; c2, 3.85 MB of spectra, loses 10 %)
+    const bool pin_block = serial && whole_hops && !mStages.empty() &&
+                           (double) (mStages[last]->live_parts + (uint64_t) rows_in * mStages[last]->R) * mStages[last]->M * sizeof(float2) <= 1.5 * 1048576.0;
+    xcd_pin_hint(pin_block);
     // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     for (size_t sj = 0; sj < mStages.size(); sj++)
-        if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj)) return false;
+        if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj))
+        {
+            xcd_pin_hint(false);
+            return false;
+        }
+    xcd_pin_hint(false);
 
     if (!blk.direct_out)
     {

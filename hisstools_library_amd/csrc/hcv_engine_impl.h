@@ -97,6 +97,7 @@ struct Engine::Stage
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
+    unsigned *tickets = nullptr;        // kMacTickets arrival counters of the fused split-K epilogue (zero between launches)
     // exact per-pair restart: device table of the live ghost entries of this stage, grouped by output
     int *gh_start = nullptr;            // [nout + 1]
     GhostEntry *gh_ent = nullptr;       // [pairs]

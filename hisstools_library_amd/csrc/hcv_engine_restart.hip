@@ -200,9 +200,10 @@ bool Engine::make_ghost_event(const std::vector<size_t> &pairs)
 }
 
 // spectral_mac + the ghost products of the restarted pairs it reaches (every MAC of a stage goes through here)
-bool Engine::mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream)
+bool Engine::mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream,
+                 bool fuse_reduce)
 {
-    HCV_TRY(launch_spectral_mac(s, pl, st.X, H, Y, st.hv, h_first, check, stream));
+    HCV_TRY(launch_spectral_mac(s, pl, st.X, H, Y, st.hv, h_first, check, stream, fuse_reduce ? st.tickets : nullptr));
     if (st.gh_count && h_first + s.T - 1 >= st.gh_min_hr && h_first - st.gh_max_hr <= (long long) s.P)
         HCV_TRY(launch_ghost_mac(s, H, Y, h_first, st.gh_start, st.gh_ent, nullptr, stream));
     return true;

@@ -189,14 +189,20 @@ namespace
 template <int LOG2N, int LOG2R, bool DIRECT>
 __global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ hist, long long hist_stride, long long hist_mask, const float *__restrict__ in,
                                                           long long in_stride, long long n0, long long h_first, int nin, float2 *__restrict__ X, int Rring,
-                                                          const float2 *__restrict__ tw, const float2 *__restrict__ tws)
+                                                          const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S, NW = R / 2 + 1, TG = 256;
     __shared__ __attribute__((aligned(16))) float2 lds[lds_padded(S)];
     __shared__ __attribute__((aligned(16))) float2 tl[S];
     __shared__ float2 wr[R];
     const int tid = threadIdx.x;
-    const int r = blockIdx.x % NW, q = blockIdx.x / NW;
+    int bx = blockIdx.x;
+    if (pin >= 0)
+    {
+        if ((bx & 7) != pin) return;
+        bx >>= 3;
+    }
+    const int r = bx % NW, q = bx / NW;
     const int t = q / nin, i = q % nin;
     const long long h = h_first + t;
     const LdsBuf<float2> s = { lds };
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ his
 // the spectrum is staged into LDS).
 template <int LOG2N, int LOG2R>
 __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, int nout, float *__restrict__ out,
-                                                                long long out_stride, const float2 *__restrict__ tw, const float2 *__restrict__ tws)
+                                                                long long out_stride, const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S, NW = R / 2, TG = 256;
     extern __shared__ __attribute__((aligned(16))) float2 dyn[];
@@ -265,7 +271,13 @@ __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__r
     float2 *tl = dyn + M + lds_padded(S);                // [S] the sub-transform's twiddles
     float2 *wr = tl + S;                                 // [R] W_R^j
     const int tid = threadIdx.x;
-    const int j = blockIdx.x % NW, q = blockIdx.x / NW;
+    int bx = blockIdx.x;
+    if (pin >= 0)
+    {
+        if ((bx & 7) != pin) return;
+        bx >>= 3;
+    }
+    const int j = bx % NW, q = bx / NW;
     const int t = q / nout, o = q % nout;
     if (tid < R)
     {
@@ -352,7 +364,7 @@ static const float2 *sub_table(int log2s)
     return twiddles(dev, log2s + 1, &err);               // (2 S)-th roots, S entries: what LdsFFT<LOG2S> indexes
 }
 
-// HCV_FFT_SPLIT: 0 = never, 1 = wherever a split kernel exists, unset = blocks of at most kSplitMaxTransforms transforms of 16384 points
+// HCV_FFT_SPLIT: 0 = never, 1 = wherever a split kernel exists, unset = blocks of at most kSplitMaxTransforms transforms (16384 or 4096 points)
 static int split_mode()
 {
     static const int m = std::getenv("HCV_FFT_SPLIT") ? std::atoi(std::getenv("HCV_FFT_SPLIT")) : -1;
@@ -366,7 +378,7 @@ bool fft_split_applies(int log2n, int transforms)
     if (m == 0 || transforms <= 0) return false;
     if (log2n != 14 && log2n != 12) return false;
     if (m > 0) return transforms <= 1024;
-    return log2n == 14 && transforms <= kSplitMaxTransforms;
+    return transforms <= kSplitMaxTransforms;
 }
 
 static int split_radix_log2(int log2n)
@@ -389,8 +401,9 @@ static hipError_t launch_rfft_split_t(float *hist, long long hist_stride, long l
     const float2 *tws = sub_table(LOG2N - LOG2R);
     if (!tws) return hipErrorInvalidValue;
     constexpr int NW = (1 << LOG2R) / 2 + 1;
-    hipLaunchKernelGGL((rfft_split_kernel<LOG2N, LOG2R, true>), dim3(NW * T * nin), dim3(256), 0, st, hist, hist_stride, hist_mask, in, in_stride, n0, h_first,
-                       nin, X, R, tw, tws);
+    const int pin = xcd_pin_for((long long) NW * T * nin);
+    hipLaunchKernelGGL((rfft_split_kernel<LOG2N, LOG2R, true>), dim3(NW * T * nin * (pin >= 0 ? 8 : 1)), dim3(256), 0, st, hist, hist_stride, hist_mask, in, in_stride,
+                       n0, h_first, nin, X, R, tw, tws, pin);
     return hipGetLastError();
 }
 
@@ -426,7 +439,9 @@ static hipError_t launch_rifft_split_t(const float2 *Y, int ksplit, long long ks
             if (dev >= 0 && dev < 64) allowed[dev] = true;
         }
     }
-    hipLaunchKernelGGL((rifft_split_emit_kernel<LOG2N, LOG2R>), dim3(NW * T * nout), dim3(256), lds, st, Y, ksplit, ks_stride, nout, out, out_stride, tw, tws);
+    const int pin = xcd_pin_for((long long) NW * T * nout);
+    hipLaunchKernelGGL((rifft_split_emit_kernel<LOG2N, LOG2R>), dim3(NW * T * nout * (pin >= 0 ? 8 : 1)), dim3(256), lds, st, Y, ksplit, ks_stride, nout, out, out_stride,
+                       tw, tws, pin);
     return hipGetLastError();
 }
 

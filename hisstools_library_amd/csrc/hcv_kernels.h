@@ -39,6 +39,13 @@ namespace hcv
     hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
                                  const float2 *tw, hipStream_t st);
 
+    // ---- XCD pinning of tiny launches (HCV_XCD_PIN): a chain of kernels of a few workgroups each hands its data from kernel to
+    //      kernel through memory; workgroup b of a launch runs on XCD b % 8 (observed, never relied on for correctness), so a
+    //      launch of 8 x as many workgroups of which only those with b % 8 == 0 work keeps the whole chain on ONE XCD and its
+    //      hand-overs in that XCD's L2.  Returns the XCD to pin a launch of `workgroups` to (one-dimensional grids), or -1.
+    int xcd_pin_for(long long workgroups);
+    void xcd_pin_hint(bool on);     // set by the engine around a block's enqueue (thread-local): "this block's chain is tiny and its data fits one L2"
+
     // ---- residue-split transforms (hcv_fft_split.hip): one hop transform over several workgroups that share nothing, for blocks
     //      of a few transforms.  `applies` = the rule (HCV_FFT_SPLIT = 0 / 1 forces it); `prepare` uploads the sub-transform tables
     //      of the current device ahead of the first launch.
@@ -77,11 +84,17 @@ namespace hcv
         int bx, by, tz;             // threads along bins, hop tiles per workgroup, hop-tile blocks
         int binblocks, outtiles, ksplit, kper;
         int nt;                     // stream H with nontemporal loads
+        int inwg;                   // > 0: the k-slices are the waves of ONE workgroup (this many, 64 lanes = 128 bins each) and are added
+                                    // up in LDS — ksplit = 1, no partial sums in memory, no reduce_partials launch (small engines)
     };
     void mac_plan(const MacShape &s, MacPlan &pl);
     hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st);
+    // tickets (optional): kMacTickets zeroed counters; when the plan allows it (mac_can_fuse_reduce) the launch adds its split-K
+    // slices up into slice 0 itself, in reduce_partials' order, and no reduce_partials launch is needed
+    constexpr int kMacTickets = 1024;
+    bool mac_can_fuse_reduce(const MacPlan &pl);
     hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
-                                   long long h_first, bool check, hipStream_t st);
+                                   long long h_first, bool check, hipStream_t st, unsigned *tickets = nullptr);
 
     // ---- exact per-pair restart (hcv_ghost.hip) ----
     struct GhostEntry

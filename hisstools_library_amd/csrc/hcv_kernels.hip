@@ -404,10 +404,46 @@ __global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_rows_kernel(
 
 // Split-K epilogue: Y[0][e] = sum_ks Y[ks][e].  One float4 per thread, the ksplit strided loads of a thread are
 // independent (issued back to back), neighbouring threads are contiguous: a plain coalesced streaming reduction.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict__ Y, int ksplit, long long ks_stride4, long long n4)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict__ Y, int ksplit, long long ks_stride4, long long n4, int pin, int fast)
 {
-    const long long e = blockIdx.x * (long long) blockDim.x + threadIdx.x;
+    int bx = blockIdx.x;
+    if (pin >= 0)
+    {
+        if ((bx & 7) != pin) return;
+        bx >>= 3;
+    }
+    const long long e = bx * (long long) blockDim.x + threadIdx.x;
     if (e >= n4) return;
+    if (fast && ksplit <= 33)
+    {
+        // few slices (the small engines' launch-bound chains): every slice's load in flight at once — the slices were written a
+        // moment ago by workgroups all over the chip and come from the memory side, two microseconds a trip — then the same sums
+        // in the same order as the loop below
+        float4 v[33];
+#pragma unroll
+        for (int k = 0; k < 33; k++)
+            if (k < ksplit) v[k] = Y[(long long) k * ks_stride4 + e];
+        float4 s = v[0];
+        const int quads = (ksplit - 1) / 4;
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+            if (g < quads)
+            {
+                const float4 a = v[1 + 4 * g], b = v[2 + 4 * g], c = v[3 + 4 * g], d = v[4 + 4 * g];
+                s.x += (a.x + b.x) + (c.x + d.x);
+                s.y += (a.y + b.y) + (c.y + d.y);
+                s.z += (a.z + b.z) + (c.z + d.z);
+                s.w += (a.w + b.w) + (c.w + d.w);
+            }
+#pragma unroll
+        for (int k = 1; k < 33; k++)
+            if (k > 4 * quads && k < ksplit)
+            {
+                s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w;
+            }
+        Y[e] = s;
+        return;
+    }
     float4 s = Y[e];
     int ks = 1;
     for (; ks + 3 < ksplit; ks += 4)
@@ -687,6 +723,18 @@ __global__ void fold_copy_kernel(float *__restrict__ dst, const float *__restric
         default: return hipErrorInvalidValue;                                                                          \
     }
 
+static thread_local bool tlsPinHint = false;
+void xcd_pin_hint(bool on) { tlsPinHint = on; }
+
+int xcd_pin_for(long long workgroups)
+{
+    // HCV_XCD_PIN: 0 never, 1 every tiny launch, unset = the launches of blocks the engine marked (xcd_pin_hint)
+    static const int mode = std::getenv("HCV_XCD_PIN") ? std::atoi(std::getenv("HCV_XCD_PIN")) : -1;
+    static const int limit = std::getenv("HCV_XCD_PIN_MAX") ? std::atoi(std::getenv("HCV_XCD_PIN_MAX")) : 32;
+    if (mode == 0 || workgroups <= 0 || workgroups > limit) return -1;
+    return (mode > 0 || tlsPinHint) ? 0 : -1;
+}
+
 template <int L> static inline size_t fft_lds_bytes() { return sizeof(float2) * lds_padded(FFTGeom<L>::M) * FFTGeom<L>::G; }
 
 template <typename K> static hipError_t allow_lds(K kernel, size_t bytes)
@@ -815,7 +863,10 @@ hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, lo
     if (ksplit <= 1 || elems <= 0) return hipSuccess;
     const long long n4 = elems / 2;
     const int grid = (int) ((n4 + 255) / 256);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4 *>(Y), ksplit, ks_stride / 2, n4);
+    const int pin = xcd_pin_for(grid);
+    static const bool fast = !(std::getenv("HCV_REDUCE_FAST") && std::atoi(std::getenv("HCV_REDUCE_FAST")) == 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid * (pin >= 0 ? 8 : 1)), dim3(256), 0, st, reinterpret_cast<float4 *>(Y), ksplit, ks_stride / 2, n4, pin,
+                       (int) fast);
     return hipGetLastError();
 }
 

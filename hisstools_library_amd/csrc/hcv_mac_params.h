@@ -20,6 +20,9 @@ struct MacParams
     int ksplit, kper;       // k-slices over blockIdx.x and their length
     int binblocks;
     long long ks_stride4;   // float4 stride between k-slices of Y
+    unsigned *tickets;      // fused split-K epilogue (spectral_mac_kernel<.., FUSE = true>): one arrival counter per (bin block, hop) group,
+                            // zero between launches; the workgroup that arrives last adds the slices up into slice 0
+    int pin;                // >= 0: grid.x is 8 x the workgroups and only blockIdx.x % 8 == pin work (hcv_kernels.h: xcd_pin_for)
 };
 
 // the software-pipelined hop-tiled kernel (hcv_mac_tiled.hip): (OT, TT) in {1, 4} x {2, 4, 8}

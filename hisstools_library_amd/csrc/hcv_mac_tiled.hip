@@ -35,8 +35,14 @@ namespace hcv
 template <int OT, int TT, bool NT>
 __global__ __launch_bounds__(256, 2) void spectral_mac_tiled_kernel(MacParams a)
 {
-    const int bb = blockIdx.x % a.binblocks;
-    const int ks = blockIdx.x / a.binblocks;
+    int bx = blockIdx.x;
+    if (a.pin >= 0)
+    {
+        if ((bx & 7) != a.pin) return;
+        bx >>= 3;
+    }
+    const int bb = bx % a.binblocks;
+    const int ks = bx / a.binblocks;
     const int o0 = blockIdx.y * OT;
     const int tile = blockIdx.z * blockDim.y + threadIdx.y;
     const bool tile_live = tile * TT < a.T;

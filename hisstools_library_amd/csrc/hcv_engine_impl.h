@@ -97,7 +97,9 @@ struct Engine::Stage
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
-    unsigned *tickets = nullptr;        // kMacTickets arrival counters of the fused split-K epilogue (zero between launches)
+    unsigned *tickets = nullptr;        // kMacTickets arrival counters of the fused split-K epilogue (zero between launches) + the two
+                                        // monotonic hand-over counters of the fused 1 x 1 block
+    unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
     // exact per-pair restart: device table of the live ghost entries of this stage, grouped by output
     int *gh_start = nullptr;            // [nout + 1]
     GhostEntry *gh_ent = nullptr;       // [pairs]

@@ -144,8 +144,34 @@ namespace
         for (int e = tid; e < V; e += TG) dst[e] = src[e];
     }
 
+    // AGENT = the value is handed to other workgroups of the SAME launch (the fused block kernel): written through with
+    // agent-scope relaxed atomics instead of plain stores (MI355X_MICROARCH.md: 8-byte agent atomics on both sides)
+    template <bool AGENT> __device__ __forceinline__ void put2(float2 *p, float2 v)
+    {
+        if constexpr (AGENT)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long) __float_as_uint(v.y) << 32) | __float_as_uint(v.x),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            *p = v;
+    }
+    template <bool AGENT> __device__ __forceinline__ void put1(float *p, float v)
+    {
+        if constexpr (AGENT) __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    }
+    template <bool AGENT> __device__ __forceinline__ float2 get2(const float2 *p)
+    {
+        if constexpr (AGENT)
+        {
+            const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return make_float2(__uint_as_float((unsigned) a), __uint_as_float((unsigned) (a >> 32)));
+        }
+        else
+            return *p;
+    }
+
     // forward: bin R k + r (and its mirror) of the packed half spectrum
-    template <int LOG2S, int LOG2R> struct SplitSpectrumStore
+    template <int LOG2S, int LOG2R, bool AGENT = false> struct SplitSpectrumStore
     {
         static constexpr bool is_lds = false;
         float2 *dst;
@@ -157,14 +183,14 @@ namespace
             v.y += v.y;
             if (r == 0)
             {
-                if (k == 0) dst[0].x = v.x;                          // 2 X[0]
-                else if (k == HALF) dst[0].y = v.x;                  // 2 X[N/2]
-                else if (k < HALF) dst[R * k] = v;
+                if (k == 0) put1<AGENT>(&dst[0].x, v.x);             // 2 X[0]
+                else if (k == HALF) put1<AGENT>(&dst[0].y, v.x);     // 2 X[N/2]
+                else if (k < HALF) put2<AGENT>(dst + R * k, v);
             }
             else if (k < HALF)
-                dst[R * k + r] = v;
+                put2<AGENT>(dst + R * k + r, v);
             else if (r != R / 2)
-                dst[R * (S - 1 - k) + (R - r)] = make_float2(v.x, -v.y);
+                put2<AGENT>(dst + R * (S - 1 - k) + (R - r), make_float2(v.x, -v.y));
         }
     };
 
@@ -184,27 +210,14 @@ namespace
     };
 }
 
-// One workgroup = (transform q = (t, i), residue r).  DIRECT: the new hop of the frame comes from the caller's block (positions
-// >= n0) and the workgroup of residue 0 files it in the history ring, as rfft_frames_direct_kernel does.
-template <int LOG2N, int LOG2R, bool DIRECT>
-__global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ hist, long long hist_stride, long long hist_mask, const float *__restrict__ in,
-                                                          long long in_stride, long long n0, long long h_first, int nin, float2 *__restrict__ X, int Rring,
-                                                          const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
+// Residue r of one frame's spectrum, by the 256 threads of a workgroup.  lds / tl / wr = the workgroup's LDS (lds_padded(S), S and R
+// float2).  DIRECT: the new hop of the frame comes from the caller's block (positions >= n0) and the workgroup of residue 0 files
+// it in the history ring, as rfft_frames_direct_kernel does.  AGENT: see put2.
+template <int LOG2N, int LOG2R, bool DIRECT, bool AGENT, int TG = 256>
+__device__ __forceinline__ void rfft_split_body(float2 *lds, float2 *tl, float2 *wr, int tid, int r, float *hrow, const float *irow, long long base, long long n0,
+                                                long long hist_mask, float2 *dstX, const float2 *__restrict__ tw, const float2 *__restrict__ tws)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S, NW = R / 2 + 1, TG = 256;
-    __shared__ __attribute__((aligned(16))) float2 lds[lds_padded(S)];
-    __shared__ __attribute__((aligned(16))) float2 tl[S];
-    __shared__ float2 wr[R];
-    const int tid = threadIdx.x;
-    int bx = blockIdx.x;
-    if (pin >= 0)
-    {
-        if ((bx & 7) != pin) return;
-        bx >>= 3;
-    }
-    const int r = bx % NW, q = bx / NW;
-    const int t = q / nin, i = q % nin;
-    const long long h = h_first + t;
+    constexpr int R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S;
     const LdsBuf<float2> s = { lds };
     stage_table<LOG2S, TG>(tl, tws, tid);
     if (tid < R)
@@ -215,9 +228,6 @@ __global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ his
     }
     __syncthreads();
 
-    float *hrow = hist + (long long) i * hist_stride;
-    const float *irow = in + (long long) i * in_stride;
-    const long long base = (h - 1) * (long long) M;
     for (int v = tid; v < S / 4; v += TG)
     {
         float4 f[R];
@@ -253,32 +263,45 @@ __global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ his
         }
     }
     __syncthreads();
-    const int slot = (int) (h % Rring);
-    const SplitSpectrumStore<LOG2S, LOG2R> st = { X + ((long long) i * Rring + slot) * M, r };
+    const SplitSpectrumStore<LOG2S, LOG2R, AGENT> st = { dstX, r };
     sub_fft<LOG2S, TG>(s, st, tid, tl);
 }
 
-// One workgroup = (transform q = (t, o), sample classes n2 = 2 j, 2 j + 1).  Y: [ksplit][T][nout][M] partial sums (added up while
-// the spectrum is staged into LDS).
-template <int LOG2N, int LOG2R>
-__global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, int nout, float *__restrict__ out,
-                                                                long long out_stride, const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
+// One workgroup = (transform q = (t, i), residue r).
+template <int LOG2N, int LOG2R, bool DIRECT>
+__global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ hist, long long hist_stride, long long hist_mask, const float *__restrict__ in,
+                                                          long long in_stride, long long n0, long long h_first, int nin, float2 *__restrict__ X, int Rring,
+                                                          const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S, NW = R / 2, TG = 256;
-    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
-    float2 *spec = dyn;                                  // [M] the packed half spectrum
-    const LdsBuf<float2> s = { dyn + M };                // [lds_padded(S)] the class pair's transform
-    float2 *tl = dyn + M + lds_padded(S);                // [S] the sub-transform's twiddles
-    float2 *wr = tl + S;                                 // [R] W_R^j
-    const int tid = threadIdx.x;
+    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S, NW = R / 2 + 1;
+    __shared__ __attribute__((aligned(16))) float2 lds[lds_padded(S)];
+    __shared__ __attribute__((aligned(16))) float2 tl[S];
+    __shared__ float2 wr[R];
     int bx = blockIdx.x;
     if (pin >= 0)
     {
         if ((bx & 7) != pin) return;
         bx >>= 3;
     }
-    const int j = bx % NW, q = bx / NW;
-    const int t = q / nout, o = q % nout;
+    const int r = bx % NW, q = bx / NW;
+    const int t = q / nin, i = q % nin;
+    const long long h = h_first + t;
+    rfft_split_body<LOG2N, LOG2R, DIRECT, false>(lds, tl, wr, threadIdx.x, r, hist + (long long) i * hist_stride, in + (long long) i * in_stride,
+                                                 (h - 1) * (long long) M, n0, hist_mask, X + ((long long) i * Rring + (int) (h % Rring)) * M, tw, tws);
+}
+
+// Sample classes n2 = 2 j, 2 j + 1 of one frame, by the 256 threads of a workgroup.  dyn = the workgroup's LDS: M (spectrum) +
+// lds_padded(S) + S + R float2.  Ysrc: the spectrum, or the first of `ksplit` partial sums `ks_stride` float2 apart (added up while
+// staged).  AGENT: the spectrum was written by other workgroups of this launch (see put2).  `row`: sample e of the frame lands at row[e].
+template <int LOG2N, int LOG2R, bool AGENT, int TG = 256>
+__device__ __forceinline__ void rifft_split_body(float2 *dyn, int tid, int j, const float2 *__restrict__ Ysrc, int ksplit, long long ks_stride, float *row,
+                                                 const float2 *__restrict__ tw, const float2 *__restrict__ tws)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, LOG2S = LOG2N - LOG2R, S = 1 << LOG2S;
+    float2 *spec = dyn;                                  // [M] the packed half spectrum
+    const LdsBuf<float2> s = { dyn + M };                // [lds_padded(S)] the class pair's transform
+    float2 *tl = dyn + M + lds_padded(S);                // [S] the sub-transform's twiddles
+    float2 *wr = tl + S;                                 // [R] W_R^j
     if (tid < R)
     {
         float sn, cs;
@@ -286,9 +309,19 @@ __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__r
         wr[tid] = make_float2(cs, sn);
     }
     stage_table<LOG2S, TG>(tl, tws, tid);
+    if constexpr (AGENT)
+    {
+        constexpr int V = M / TG;                        // float2 per thread, all in flight
+        float2 acc[V];
+#pragma unroll
+        for (int e = 0; e < V; e++) acc[e] = get2<true>(Ysrc + tid + e * TG);
+#pragma unroll
+        for (int e = 0; e < V; e++) spec[tid + e * TG] = acc[e];
+    }
+    else
     {
         // stage (and add up) the spectrum: 16-byte loads, every load of a slice in flight before the adds
-        const float4 *src = reinterpret_cast<const float4 *>(Y + ((long long) t * nout + o) * M);
+        const float4 *src = reinterpret_cast<const float4 *>(Ysrc);
         float4 *dst4 = reinterpret_cast<float4 *>(spec);
         constexpr int V = M / 2 / TG;                    // float4 per thread
         float4 acc[V];
@@ -350,8 +383,150 @@ __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__r
         s[b1] = make_float2(ga.y + gb.x, ga.x - gb.y);
     }
     __syncthreads();
-    const SplitSampleStore<LOG2S, LOG2R> st = { out + (long long) o * out_stride + (long long) t * M - M, 1.f / (float) (8 * M), j };
+    const SplitSampleStore<LOG2S, LOG2R> st = { row, 1.f / (float) (8 * M), j };
     sub_fft<LOG2S, TG>(s, st, tid, tl);
+}
+
+// One workgroup = (transform q = (t, o), sample classes n2 = 2 j, 2 j + 1).  Y: [ksplit][T][nout][M] partial sums.
+template <int LOG2N, int LOG2R>
+__global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, int nout, float *__restrict__ out,
+                                                                long long out_stride, const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, NW = R / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    int bx = blockIdx.x;
+    if (pin >= 0)
+    {
+        if ((bx & 7) != pin) return;
+        bx >>= 3;
+    }
+    const int j = bx % NW, q = bx / NW;
+    const int t = q / nout, o = q % nout;
+    rifft_split_body<LOG2N, LOG2R, false>(dyn, threadIdx.x, j, Y + ((long long) t * nout + o) * M, ksplit, ks_stride,
+                                          out + (long long) o * out_stride + (long long) t * M - M, tw, tws);
+}
+
+// ------------------------------------------------------------------------------------------------ the fused 1 x 1 block
+//
+// One whole-hop block of a 1 x 1 engine — forward transform, multiply-accumulate over the P live partitions, inverse transform,
+// PartitionedConvolve::process for one hop (PartitionedConvolve.cpp:243-385) — as ONE launch of R + R/2 + 1 workgroups with
+// in-launch hand-overs in place of two kernel boundaries.  What crosses workgroups inside the launch (X[h], then Y) is written
+// and read with agent-scope 8-byte atomics; every thread drains its stores before its workgroup is counted in, and the consumers
+// poll the counter from one lane with relaxed agent loads (`bar[k]` counts arrivals over all launches and the host keeps
+// the running totals: no reset).  The consumers must not be scheduled WITHOUT the producers (they spin): 25 workgroups of 256 CUs, and the
+// producers' workgroups never wait for anything.
+struct FusedBlockParams
+{
+    float *hist;
+    const float *in;
+    float *out;                 // the hop's output samples
+    float2 *X;                  // [Rring][M] the input's spectrum ring
+    const float2 *H;            // [P][M] the pair's partition spectra (lead slot first where the stage has one)
+    float2 *Y;                  // [M] scratch
+    const float2 *tw, *tws;
+    unsigned *bar;              // [2] arrival counters
+    long long hist_mask, n0, h;
+    int Rring, P, hmac_mod;     // hmac_mod = (hop the MAC's partition 0 reads) mod Rring
+    unsigned targetA, targetB;  // what the two counters read when this launch's producers have all arrived
+    int pin;
+};
+
+// arrive: every thread's agent-scope stores have been written through, then one lane counts the workgroup in
+__device__ __forceinline__ void grid_arrive(unsigned *counter)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void grid_wait(unsigned *counter, unsigned target)
+{
+    if (threadIdx.x == 0)
+        while ((int) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+}
+
+// Workgroups 0 .. R-1: multiply-accumulate (512 bins each), then 0 .. R/2-1 the inverse; workgroups R .. R + R/2: the forward
+// transform's residue classes.  A lone stage (`lone`: its partitions read X[h-1] and older, PartitionedConvolve's one hop of
+// latency) needs no hand-over from the forward transform at all — it runs BESIDE the multiply-accumulate and the inverse instead
+// of in front of them; a lead-slot stage (partition 0 reads X[h]) makes the multiply-accumulate wait for the nine residue classes.
+template <int LOG2N, int LOG2R>
+__global__ __launch_bounds__(256) void fused_block_1x1_kernel(FusedBlockParams a)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, S = N >> LOG2R;
+    static_assert(M / 2 == R * 256, "one float4 (two bins) per thread in the multiply-accumulate phase");
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    const int tid = threadIdx.x;
+    int w = blockIdx.x;
+    if (a.pin >= 0)
+    {
+        if ((w & 7) != a.pin) return;
+        w >>= 3;
+    }
+    const int slot = (int) (a.h % a.Rring);
+    const bool lone = a.hmac_mod != slot;
+
+    if (w >= R)
+    {
+        // ---- the new frame's spectrum X[h]
+        rfft_split_body<LOG2N, LOG2R, true, true>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, w - R, a.hist, a.in, (a.h - 1) * (long long) M, a.n0,
+                                                  a.hist_mask, a.X + (long long) slot * M, a.tw, a.tws);
+        grid_arrive(a.bar);
+        return;
+    }
+
+    // ---- Y[b] = sum_p X[hmac - p][b] H[p][b] for this workgroup's 512 bins; bin 0 = (DC, Nyquist): two real products
+    if (!lone) grid_wait(a.bar, a.targetA);
+    {
+        const int b4 = w * 256 + tid;
+        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ny = 0.f;
+        for (int p0 = 0; p0 < a.P; p0 += 8)
+        {
+            float4 x[8], hh[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                const int p = min(p0 + k, a.P - 1);
+                int sl = a.hmac_mod - p;
+                if (sl < 0) sl += a.Rring;
+                const float4 *xp = X4 + (long long) sl * (M / 2) + b4;
+                if (sl == slot)
+                {
+                    // written a moment ago by other workgroups of this launch
+                    const float2 lo = get2<true>(reinterpret_cast<const float2 *>(xp)), hi = get2<true>(reinterpret_cast<const float2 *>(xp) + 1);
+                    x[k] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
+                else
+                    x[k] = *xp;
+                hh[k] = H4[(long long) p * (M / 2) + b4];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (p0 + k < a.P)
+                {
+                    acc.x += x[k].x * hh[k].x - x[k].y * hh[k].y;
+                    acc.y += x[k].x * hh[k].y + x[k].y * hh[k].x;
+                    acc.z += x[k].z * hh[k].z - x[k].w * hh[k].w;
+                    acc.w += x[k].z * hh[k].w + x[k].w * hh[k].z;
+                    ny += x[k].y * hh[k].y;
+                }
+        }
+        if (b4 == 0)
+        {
+            acc.x += ny;
+            acc.y = ny;
+        }
+        float2 *y = a.Y + 2 * (long long) b4;
+        put2<true>(y, make_float2(acc.x, acc.y));
+        put2<true>(y + 1, make_float2(acc.z, acc.w));
+    }
+    grid_arrive(a.bar + 1);
+    if (w >= R / 2) return;
+
+    // ---- the hop's samples
+    grid_wait(a.bar + 1, a.targetB);
+    rifft_split_body<LOG2N, LOG2R, true>(dyn, tid, w, a.Y, 1, 0, a.out - M, a.tw, a.tws);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -453,6 +628,194 @@ hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long 
     HCV_SPLIT_I(14, 3); HCV_SPLIT_I(14, 4); HCV_SPLIT_I(14, 5); HCV_SPLIT_I(12, 2); HCV_SPLIT_I(12, 3); HCV_SPLIT_I(12, 4);
 #undef HCV_SPLIT_I
     return hipErrorInvalidValue;
+}
+
+// The same for nin inputs and ONE output (NToMonoConvolve::process, NToMonoConvolve.cpp:35-43, for one hop) and for 1 x 1 engines
+// with long impulse responses: the reduction over (input, partition) — K = nin P terms — is split over the 16 waves of 1024-thread
+// workgroups (64 lanes = 128 bins each) and added up in LDS, as spectral_mac_kernel's INWG form does.  Workgroups 0 .. M/128 - 1:
+// multiply-accumulate, then 0 .. R/2 - 1 the inverse; the rest: residue class r of input i's forward transform.
+struct FusedNx1Params
+{
+    float *hist;
+    const float *in;
+    float *out;
+    float2 *X;                  // [nin][Rring][M]
+    const float2 *H;            // [nin rows of hstride float2][P][M]: output 0's pairs
+    float2 *Y;
+    const float2 *tw, *tws;
+    unsigned *bar;
+    long long hist_stride, in_stride, hist_mask, n0, h, hstride;
+    int Rring, P, hmac_mod, nin, kper;
+    unsigned targetA, targetB;
+};
+
+template <int LOG2N, int LOG2R>
+__global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, M2 = M / 2, R = 1 << LOG2R, S = N >> LOG2R, NF = R / 2 + 1, TG = 1024, MACW = M2 / 64;
+    static_assert(NF > 0, "");
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    const int tid = threadIdx.x, w = blockIdx.x;
+    const int slot = (int) (a.h % a.Rring);
+    const bool lone = a.hmac_mod != slot;
+
+    if (w >= MACW)
+    {
+        const int i = (w - MACW) / NF, r = (w - MACW) % NF;
+        rfft_split_body<LOG2N, LOG2R, true, true, TG>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, r, a.hist + (long long) i * a.hist_stride,
+                                                      a.in + (long long) i * a.in_stride, (a.h - 1) * (long long) M, a.n0, a.hist_mask,
+                                                      a.X + ((long long) i * a.Rring + slot) * M, a.tw, a.tws);
+        grid_arrive(a.bar);
+        return;
+    }
+
+    {
+        const int lane = tid & 63, ks = tid >> 6;
+        const int b4 = w * 64 + lane;
+        // with a lead slot (partition 0 reads the NEW spectra X[h]) the terms of partitions >= 1 — all but nin of the nin P — are
+        // accumulated first, beside the forward transforms; the nin lead terms follow once those have arrived
+        const int P1 = lone ? a.P : a.P - 1, pofs = lone ? 0 : 1;
+        const int K = a.nin * P1;
+        const int kper = (K + 15) / 16;
+        const int k0 = ks * kper, k1 = min(K, k0 + kper);
+        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ny = 0.f;
+        for (int kb = k0; kb < k1; kb += 8)
+        {
+            float4 x[8], hh[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int k = min(kb + u, k1 - 1);
+                const int i = k / P1, p = k - i * P1 + pofs;
+                int sl = a.hmac_mod - p;
+                if (sl < 0) sl += a.Rring;
+                x[u] = X4[((long long) i * a.Rring + sl) * M2 + b4];
+                hh[u] = H4[(long long) i * (a.hstride / 2) + (long long) p * M2 + b4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (kb + u < k1)
+                {
+                    acc.x += x[u].x * hh[u].x - x[u].y * hh[u].y;
+                    acc.y += x[u].x * hh[u].y + x[u].y * hh[u].x;
+                    acc.z += x[u].z * hh[u].z - x[u].w * hh[u].w;
+                    acc.w += x[u].z * hh[u].w + x[u].w * hh[u].z;
+                    ny += x[u].y * hh[u].y;
+                }
+        }
+        if (!lone)
+        {
+            grid_wait(a.bar, a.targetA);
+            // the lead terms: input i by wave i, i + 16, ... (X[h] was written a moment ago by other workgroups of this launch)
+            for (int i = ks; i < a.nin; i += 16)
+            {
+                const float2 *xp = reinterpret_cast<const float2 *>(X4 + ((long long) i * a.Rring + slot) * M2 + b4);
+                const float2 lo = get2<true>(xp), hi = get2<true>(xp + 1);
+                const float4 hv = H4[(long long) i * (a.hstride / 2) + b4];
+                acc.x += lo.x * hv.x - lo.y * hv.y;
+                acc.y += lo.x * hv.y + lo.y * hv.x;
+                acc.z += hi.x * hv.z - hi.y * hv.w;
+                acc.w += hi.x * hv.w + hi.y * hv.z;
+                ny += lo.y * hv.y;
+            }
+        }
+        if (b4 == 0)
+        {
+            acc.x += ny;                                    // (DC and Nyquist products are sums too: repaired per slice, added up below)
+            acc.y = ny;
+        }
+        float4 *red = reinterpret_cast<float4 *>(dyn);      // [16][64]
+        red[ks * 64 + lane] = acc;
+        __syncthreads();
+        if (ks == 0)
+        {
+            float4 sum = acc;
+#pragma unroll
+            for (int k = 1; k < 16; k++)
+            {
+                const float4 p = red[k * 64 + lane];
+                sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w;
+            }
+            float2 *y = a.Y + 2 * (long long) b4;
+            put2<true>(y, make_float2(sum.x, sum.y));
+            put2<true>(y + 1, make_float2(sum.z, sum.w));
+        }
+    }
+    grid_arrive(a.bar + 1);
+    if (w >= R / 2) return;
+
+    grid_wait(a.bar + 1, a.targetB);
+    rifft_split_body<LOG2N, LOG2R, true, TG>(dyn, tid, w, a.Y, 1, 0, a.out - M, a.tw, a.tws);
+}
+
+bool fused_block_1x1_applies(int log2n)
+{
+    static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0);
+    return on && log2n == 14;
+}
+
+hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0, long long h,
+                                  int nin, float2 *X, int Rring, const float2 *H, long long hstride, int P, long long h_mac, float2 *Y, float *out, const float2 *tw,
+                                  unsigned *bar, unsigned *arrived, hipStream_t st)
+{
+    if (log2n != 14 || nin < 1) return hipErrorInvalidValue;
+    constexpr int LOG2N = 14, LOG2R = 4, M = 1 << (LOG2N - 1), S = 1 << (LOG2N - LOG2R), R = 1 << LOG2R;
+    const float2 *tws = sub_table(LOG2N - LOG2R);
+    if (!tws) return hipErrorInvalidValue;
+    constexpr size_t lds = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R);
+    static bool allowed[64] = {};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !allowed[dev])
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_block_nx1_kernel<LOG2N, LOG2R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int) lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) allowed[dev] = true;
+    }
+    FusedNx1Params a;
+    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
+    a.hist_stride = hist_stride; a.in_stride = in_stride; a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.hstride = hstride;
+    a.Rring = Rring; a.P = P; a.nin = nin;
+    a.hmac_mod = (int) (h_mac % Rring);
+    a.kper = (nin * P + 15) / 16;
+    constexpr int G = M / 128 + 0;
+    a.targetA = (arrived[0] += (unsigned) (nin * (R / 2 + 1)));
+    a.targetB = (arrived[1] += (unsigned) G);
+    hipLaunchKernelGGL((fused_block_nx1_kernel<LOG2N, LOG2R>), dim3(G + nin * (R / 2 + 1)), dim3(1024), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, float2 *X, int Rring, const float2 *H,
+                                  int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived, hipStream_t st)
+{
+    if (log2n != 14) return hipErrorInvalidValue;
+    constexpr int LOG2N = 14, LOG2R = 4, M = 1 << (LOG2N - 1), S = 1 << (LOG2N - LOG2R), R = 1 << LOG2R;
+    const float2 *tws = sub_table(LOG2N - LOG2R);
+    if (!tws) return hipErrorInvalidValue;
+    constexpr size_t lds = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R);
+    static bool allowed[64] = {};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !allowed[dev])
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_block_1x1_kernel<LOG2N, LOG2R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int) lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) allowed[dev] = true;
+    }
+    FusedBlockParams a;
+    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
+    a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.Rring = Rring; a.P = P;
+    a.hmac_mod = (int) (h_mac % Rring);
+    a.targetA = (arrived[0] += (unsigned) (R / 2 + 1));
+    a.targetB = (arrived[1] += (unsigned) R);
+    constexpr int G = R + R / 2 + 1;
+    a.pin = xcd_pin_for(G);
+    hipLaunchKernelGGL((fused_block_1x1_kernel<LOG2N, LOG2R>), dim3(G * (a.pin >= 0 ? 8 : 1)), dim3(256), lds, st, a);
+    return hipGetLastError();
 }
 
 } // namespace hcv

@@ -56,6 +56,20 @@ namespace hcv
     hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
                                        const float2 *tw, hipStream_t st);
 
+    // ---- the fused 1 x 1 block (hcv_fft_split.hip): one hop of a one-input, one-output engine in ONE launch.  h = the hop, h_mac =
+    //      the hop partition 0 reads (h with a lead slot, h - 1 for a lone stage), H = the pair's P live partitions, bar = two
+    //      zero-initialised counters that only these launches touch, arrived = the host's running totals of what they will read
+    bool fused_block_1x1_applies(int log2n);
+    hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, float2 *X, int Rring,
+                                      const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
+                                      hipStream_t st);
+
+    // nin inputs -> one output, or 1 x 1 with a long reduction (K = nin P split over the waves of 1024-thread workgroups); H = output 0's
+    // pairs, `hstride` float2 between two inputs' spectra
+    hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0,
+                                      long long h, int nin, float2 *X, int Rring, const float2 *H, long long hstride, int P, long long h_mac, float2 *Y,
+                                      float *out, const float2 *tw, unsigned *bar, unsigned *arrived, hipStream_t st);
+
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,
                                int R, const float2 *tw, const BigFFTWork &w, hipStream_t st);
     hipError_t big_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork &w, hipStream_t st);

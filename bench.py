@@ -630,13 +630,14 @@ def bench_line(args, ctx):
     # instantiation) — and the CPU leg's output rows are compared sample by sample.  On N > 1 ranks every rank streams its own
     # block of the matrix (its share of the CPU leg's inputs; on the reduce path the all-reduce of every step included) and
     # rank 0 compares the rows it holds.
-    self_check = None
     have_ref = cpu is not None and cpu.get("_outs") is not None
     if world > 1 and check_all_ranks:
         flag = torch.tensor([1.0 if have_ref else 0.0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         have_ref = bool(flag.item() > 0.5)
-    if have_ref and not args.no_self_check and not args.tail_ratio:
+
+    def check_against_cpu_leg(conv):
+        """reset `conv`, stream the CPU leg's inputs in B-sample steps, compare with the CPU leg's rows"""
         try:
             sub_in, sub_out, S_chk = cpu["_sub"]
             ref = cpu["_outs"]
@@ -666,16 +667,19 @@ def bench_line(args, ctx):
             n_hops_ref = 16 if check_all_ranks else 64
             tail_span = slice(S_chk - n_hops_ref * (stages[-1][0] // 2), S_chk)       # the span the CPU leg timed: every partition live
             err_tail = max([float(np.abs(got[k][tail_span] - ref[o][tail_span]).max() / np.abs(ref[o]).max()) for k, o in enumerate(rows)] or [float("nan")])
-            self_check = {"max_rel_err": float(f"{max(errs):.3e}"), "max_rel_err_steady_span": float(f"{err_tail:.3e}"),
-                          "against": f"{cpu['kind']} CPU leg: output rows {rows[0] if rows else '-'}..{rows[-1] if rows else '-'} from inputs 0..{sub_in - 1} (the other "
-                                     f"inputs silent), {S_chk} samples in {B}-sample steps after a reset, on the timed engine(s) and spectra"
-                                     + (f"; every one of the {world} ranks streamed its block" + (", all-reduce per step included" if reduce_path else "")
-                                        if world > 1 else ""),
-                          "tolerance": 1e-5, "ok": bool(max(errs) <= 1e-5),
-                          "mac_launches": int(st_chk["mac_launches"]), "mac_steady_launches": int(st_chk["mac_steady_launches"])}
-            del xc, yc
+            return {"max_rel_err": float(f"{max(errs):.3e}"), "max_rel_err_steady_span": float(f"{err_tail:.3e}"),
+                    "against": f"{cpu['kind']} CPU leg: output rows {rows[0] if rows else '-'}..{rows[-1] if rows else '-'} from inputs 0..{sub_in - 1} (the other "
+                               f"inputs silent), {S_chk} samples in {B}-sample steps after a reset, on the timed engine(s) and spectra"
+                               + (f"; every one of the {world} ranks streamed its block" + (", all-reduce per step included" if reduce_path else "")
+                                  if world > 1 else ""),
+                    "tolerance": 1e-5, "ok": bool(max(errs) <= 1e-5),
+                    "mac_launches": int(st_chk["mac_launches"]), "mac_steady_launches": int(st_chk["mac_steady_launches"])}
         except Exception as e:
-            self_check = {"max_rel_err": None, "error": str(e)}
+            return {"max_rel_err": None, "error": str(e)}
+
+    self_check = None
+    if have_ref and not args.no_self_check and not args.tail_ratio:
+        self_check = check_against_cpu_leg(conv)
 
     # ---- paced real-time calls (what a plug-in host does): `realtime-block` samples per call at the workload's sample rate,
     # through the host-pointer entry point (hcv_convolver_process_f32: what the C++ drop-in calls) and the device-pointer one
@@ -699,10 +703,19 @@ def bench_line(args, ctx):
     extended = None
     if args.extended_ratio and not args.tail_ratio and not reduce_path:
         try:
-            e_el, e_stats, e_fin, _, _, _ = run(args.extended_ratio, args.steps, args.warmup, 0)
+            e_el, e_stats, e_fin, _, _, e_conv = run(args.extended_ratio, args.steps, args.warmup, 0, keep=True)
             extended = {"tail_ratio": args.extended_ratio, "stages": [(s_["fft_size"], s_["partitions"]) for s_ in e_stats],
                         "msamples_per_s": round(nout_total * B * args.steps / e_el / 1e6, 2), "ms_per_step": round(1e3 * e_el / args.steps, 4),
                         "finite_output": e_fin}
+            # the same self-check the headline has: the ladder's engine, reset, against the reference CPU leg's rows (the SAME
+            # convolution on a different partitioning).  Its steps are not an HBM test — its spectra are read 8 x less often per rung
+            # — so no roofline fraction is quoted for it: the per-stage multiply-accumulate times say where its step goes
+            if have_ref and not args.no_self_check and world == 1:
+                extended["self_check"] = check_against_cpu_leg(e_conv)
+            extended["all_stage_mac_ms_per_step"] = {str(s_["fft_size"]): round(s_["mac_ms"] / args.steps, 4) for s_ in e_stats}
+            extended["note"] = ("MI355X extension, not the reference's partitioning: reported beside the headline, never as it; parity at this scale: "
+                                "tests/test_steady_state_gpu.py::test_config5_extended_ladder_full_depth")
+            del e_conv
         except Exception as e:      # never let the side measurement take the headline down
             extended = {"error": str(e)}
 

@@ -32,7 +32,7 @@ def torch():
     return torch
 
 
-def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=8192, spread=None):
+def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=8192, spread=None, tail_ratio=0):
     """Impulse IRs built in HBM (a few scaled taps per pair, spread over the WHOLE IR), audio resident in HBM, streamed in
     whole tail hops.  The exact answer is a gain-weighted sum of delayed inputs, computed in float64 (torch on the GPU: plain
     shifted adds, nothing of this library).  Returns the tail stage's statistics."""
@@ -49,7 +49,7 @@ def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=819
     if spread is not None:
         delays[:, :, -1] = rng.randint(spread[0], spread[1], size=(nout, nin))
     gains = rng.uniform(-1, 1, size=(nout, nin, taps_per_pair))
-    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B, tailRatio=tail_ratio)
     h = torch.zeros(L, dtype=torch.float32, device=dev)
     for o in range(nout):
         for i in range(nin):
@@ -82,6 +82,8 @@ def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=819
         worst = max(worst, err, err_end)
         assert err < TOL_SUM and err_end < TOL_SUM, (o, err, err_end)
     st = c.stage_stats()
+    if tail_ratio:
+        return st, worst
     return st[-1], worst
 
 
@@ -94,6 +96,19 @@ def test_config5_full_depth_steady_state(H, torch):
     assert tail["mac_launches"] == hops
     # every hop from the 703rd on runs the unchecked instantiation with nontemporal loads
     assert tail["mac_steady_launches"] >= hops - 704, tail
+
+
+def test_config5_extended_ladder_full_depth(H, torch):
+    """The extended far-tail ladder (MI355X extension, tailRatio = 8: 16384 -> 131072 -> 2^20-point rungs past the reference's
+    largest FFT) at config-5 scale — the shape bench.py's `extended_layout` leg times: 16x16, 5.76 M-sample IRs, three taps per
+    pair over the WHOLE IR (every rung, every partition index of the 16384-point rung), 712 hops, so that the far rungs — their
+    four-step transforms, their deferred slices, their first emission 2^19 samples in — all contribute; <= 1e-5 of the float64
+    answer.  It must be the same convolution as the reference partitioning gives (same test above)."""
+    L, hops = 5760000, 712
+    stats, worst = _sparse_device_case(H, torch, 16, 16, L, hops, 3, seed=58, spread=(L - 3 * 8192, L), tail_ratio=8)
+    assert [s["fft_size"] for s in stats] == [256, 1024, 4096, 16384, 131072, 1 << 20]
+    assert stats[-1]["partitions"] == 10 and stats[-2]["partitions"] == 7 and stats[-3]["partitions"] == 7
+    assert worst < TOL_SUM
 
 
 def test_config4_full_depth_steady_state(H, torch):

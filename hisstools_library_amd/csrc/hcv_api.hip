@@ -1353,13 +1353,14 @@ extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
 extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
 {
     if (!out) return -1;
-    out->lock_contended = out->lock_wait_ns_max = out->blocks_muted = 0;
+    out->lock_contended = out->lock_wait_ns_max = out->blocks_muted = out->mailbox_runs = 0;
     auto add = [&](Engine &e)
     {
         const Engine::RtStats r = e.rt_stats();
         out->lock_contended += r.lock_contended;
         out->lock_wait_ns_max = std::max<uint64_t>(out->lock_wait_ns_max, r.lock_wait_ns_max);
         out->blocks_muted += r.blocks_muted;
+        out->mailbox_runs += r.mailbox_runs;
     };
     if (h->sh)
         for (hcv_shard &x : h->sh->s) add(*x.m->engine);

@@ -32,6 +32,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -135,8 +136,8 @@ namespace hcv
         // upload, allocation or device work — only, at most, for the short host-only section in which a control call swaps
         // its staged result in.  These count what that cost: calls that found the engine lock taken, the longest such wait,
         // and blocks given up as silence after kAudioLockBudgetNs (never observed; the reference mutes the pair instead).
-        struct RtStats { uint64_t lock_contended, lock_wait_ns_max, blocks_muted; };
-        RtStats rt_stats() const { return { mLockContended.load(), mLockWaitNsMax.load(), mBlocksMuted.load() }; }
+        struct RtStats { uint64_t lock_contended, lock_wait_ns_max, blocks_muted, mailbox_runs; };
+        RtStats rt_stats() const { return { mLockContended.load(), mLockWaitNsMax.load(), mBlocksMuted.load(), mMailboxRuns.load() }; }
         void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; }
 
         void set_profiling(bool on);
@@ -164,6 +165,25 @@ namespace hcv
         hipError_t ctl_alloc(void **p, size_t bytes);
         void ctl_free(void *p);
         bool lock_for_audio(std::unique_lock<std::mutex> &lk);
+        // The control mailbox.  A control call's swap section (set_ir phase B, the pointer swap of a regrow) must run between
+        // two blocks, exclusive of the audio thread's enqueue.  While a stream is running (a process call within the last
+        // kStreamingWindowNs) the control thread never takes the engine lock for it: it POSTS the section and the audio thread runs
+        // it at the start of its next call, inside the lock it holds anyway — so no process call of a running stream can find the
+        // lock taken by a set / resize / reset (MemorySwap::attempt never waits either, MemorySwap.h:182-185; the reference mutes
+        // the pair meanwhile, here the pair plays its previous IR until the swap).  With no stream running the control thread takes
+        // the lock itself.  Control calls are serialised by mSetMutex, so one slot suffices.
+        struct CtlJob
+        {
+            std::function<bool()> fn;
+            std::atomic<bool> done { false };
+            bool ok = false;
+        };
+        bool run_exclusive(std::function<bool()> fn);       // control threads
+        void audio_enter();                                 // audio thread, engine lock held: timestamp + run a posted section
+        std::atomic<CtlJob *> mMailbox { nullptr };
+        std::atomic<long long> mLastAudioNs { 0 };
+        std::atomic<size_t> mAudioThread { 0 };             // (hash of) the thread that made the last process call
+        std::atomic<uint64_t> mMailboxRuns { 0 };           // sections the audio thread ran for control threads
         bool apply_pending_resets();
         bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
         struct Block;

@@ -3,7 +3,9 @@
 
 #include "hcv_engine_impl.h"
 
+#include <chrono>
 #include <map>
+#include <thread>
 
 namespace hcv
 {
@@ -550,13 +552,14 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     }
     long long h_snap = 0;
     uint32_t live_P = 0;
+    // a snapshot of the hop clock; everything the blocks so far have enqueued is ordered before the copies below
+    (void) run_exclusive([&]()
     {
-        // a snapshot of the hop clock; everything the blocks so far have enqueued is ordered before the copies below
-        std::lock_guard<std::mutex> g(mMutex);
         h_snap = mN / st.M;
         live_P = st.P;
         if (hipEventRecord(mEvSnap, mStream) != hipSuccess) { (void) hipGetLastError(); }
-    }
+        return true;
+    });
     bool ok = hipStreamWaitEvent(mCtlStream, mEvSnap, 0) == hipSuccess && hipStreamWaitEvent(mCtlStream, mEvSwapDone, 0) == hipSuccess;
     ok = ok && hipMemsetAsync(nHs, 0, hs_bytes, mCtlStream) == hipSuccess && hipMemsetAsync(nX, 0, x_bytes, mCtlStream) == hipSuccess;
     if (ok && (live_P > 0 || st.lead))
@@ -580,8 +583,8 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     // ---- under the engine lock: the hops that arrived since the snapshot, then the pointer swap (no allocation, no wait)
     float2 *oHs = nullptr, *oX = nullptr;
     const bool old_ctl = st.hs_ctl;
+    (void) run_exclusive([&]()
     {
-        std::lock_guard<std::mutex> g(mMutex);
         if (!fence_background()) ok = false;
         const long long h_now = mN / st.M;
         if (ok && st.P > 0 && h_now < h_snap)
@@ -606,7 +609,8 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
             mCtlDirty = true;
             ok = hipEventRecord(mEvSnap, mStream) == hipSuccess;       // the old buffers' last readers are behind this
         }
-    }
+        return true;
+    });
     if (!ok)
     {
         (void) hipGetLastError();
@@ -776,9 +780,9 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
     }
     HCV_TRY(hipStreamSynchronize(mCtlStream));          // the device has consumed `ir`; the staging buffers are complete
 
-    // ---- phase B
+    // ---- phase B: between two blocks — run by the audio thread itself while a stream is running (run_exclusive)
+    return run_exclusive([&]() -> bool
     {
-        std::lock_guard<std::mutex> g(mMutex);
         if (!fence_background(exact_restart())) return false;
         // what the pair still has to deliver belongs to the spectra about to be replaced: take it out of the timelines now
         if (mLoaded[pair] && !mRetired[pair] && !retire_pair(pair)) return false;
@@ -811,24 +815,88 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             HCV_TRY(hipMemcpyAsync(mStages.back()->Hs + pair * mStages.back()->hstride(), mStageTailHead, sizeof(float2) * mStages.back()->M,
                                    hipMemcpyDeviceToDevice, mStream));
         mLoaded[pair] = any ? 1 : 0;
-        mPending[pair] = 1;                                                         // set() always ends in reset()
+        __atomic_store_n(&mPending[pair], (uint8_t) 1, __ATOMIC_RELEASE);           // set() always ends in reset()
         mCtlDirty = true;
         HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
-    }
-    return true;
+        return true;
+    });
 }
 
+// A section that must run between two blocks, exclusive of the audio thread's enqueue (see CtlJob in hcv_engine.h).
+constexpr long long kStreamingWindowNs = 20000000;      // "a stream is running": a process call within the last 20 ms
+
+static inline long long steady_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static inline size_t this_thread_hash() { return std::hash<std::thread::id>()(std::this_thread::get_id()) | 1; }
+
+bool Engine::run_exclusive(std::function<bool()> fn)
+{
+    // a caller that IS the audio thread (one thread making both kinds of call: offline use, most tests) cannot be inside a
+    // process call: it takes the lock directly
+    const bool same_thread = mAudioThread.load(std::memory_order_acquire) == this_thread_hash();
+    for (;;)
+    {
+        if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_acquire) < kStreamingWindowNs)
+        {
+            // a stream is running: hand the section to the audio thread's next call and wait for it (this is the control thread)
+            CtlJob job;
+            job.fn = fn;
+            mMailbox.store(&job, std::memory_order_release);
+            const long long t0 = steady_ns();
+            while (!job.done.load(std::memory_order_acquire))
+            {
+                if (steady_ns() - t0 > 2 * kStreamingWindowNs)
+                {
+                    // no call came: the stream has stopped.  Take the section back — unless the audio thread picked it up just now
+                    CtlJob *expect = &job;
+                    if (mMailbox.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel)) break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+            if (job.done.load(std::memory_order_acquire)) return job.ok;
+            continue;                                       // withdrawn: look at the clock again
+        }
+        // no stream: the control thread takes the lock itself (a process call that starts right now polls for this short,
+        // host-only section — lock_for_audio — the one case left in which the audio thread can find the lock taken by a control call)
+        std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
+        if (lk.owns_lock())
+        {
+            if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_acquire) < kStreamingWindowNs) continue;   // a stream started meanwhile: post it
+            return fn();
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
+// audio thread, engine lock held, before it looks at the engine's state
+void Engine::audio_enter()
+{
+    mLastAudioNs.store(steady_ns(), std::memory_order_release);
+    mAudioThread.store(this_thread_hash(), std::memory_order_release);
+    if (mMailbox.load(std::memory_order_acquire))
+    {
+        if (CtlJob *job = mMailbox.exchange(nullptr, std::memory_order_acq_rel))
+        {
+            job->ok = job->fn();
+            mMailboxRuns++;
+            job->done.store(true, std::memory_order_release);
+        }
+    }
+}
+
+// (flag writes, no lock: consumed — exchanged — by the next block's apply_pending_resets)
 void Engine::reset_pair(uint32_t in, uint32_t out)
 {
     if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return;
-    std::lock_guard<std::mutex> g(mMutex);
-    mPending[pair_index(in, out)] = 1;
+    __atomic_store_n(&mPending[pair_index(in, out)], (uint8_t) 1, __ATOMIC_RELEASE);
 }
 
 void Engine::reset_all()
 {
-    std::lock_guard<std::mutex> g(mMutex);
-    std::fill(mPending.begin(), mPending.end(), 1);
+    for (size_t p = 0; p < mPending.size(); p++) __atomic_store_n(&mPending[p], (uint8_t) 1, __ATOMIC_RELEASE);
 }
 
 // Every loaded pair restarts: clear the rings and restart the hop clock.  The input-spectrum rings are not

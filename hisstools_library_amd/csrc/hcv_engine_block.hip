@@ -722,6 +722,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         mHostMuted = true;
         return true;
     }
+    audio_enter();
     if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
     static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
     const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
@@ -744,6 +745,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
     }
     HCV_TRY(hipEventRecord(mEvHostDone, mStream));
+    audio_enter();                      // (stamp the clock at the end of the enqueue too, and serve a section posted meanwhile)
     return true;
 }
 
@@ -810,6 +812,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
             for (uint32_t o = 0; o < nout_act; o++) std::memset(outs_host + (size_t) o * out_stride + pos, 0, sizeof(float) * B);
             continue;
         }
+        audio_enter();
         if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
         if (rows_in)
         {
@@ -852,6 +855,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             if (sync) HCV_TRY(hipStreamSynchronize(mStream));
             return true;
         }
+        audio_enter();
         if (!update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
         if (after)
         {
@@ -866,6 +870,8 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
             if (!enqueue_chunk(ins + pos, in_stride, outs + pos, out_stride, nin_act, nout_act, B)) return false;
         }
+        mLastAudioNs.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                           std::memory_order_release);
     }
     if (sync) return synchronize();
     return true;

@@ -294,12 +294,12 @@ bool Engine::update_active_matrix(uint32_t rows_in, uint32_t nout_act)
             const uint32_t row = mCfg.diag ? o : c;
             const bool was = o < mLastNout && row < mLastNin, now = o < nout_act && row < rows_in;
             if (!mLoaded[p] || was == now) continue;
-            if (was && !mPending[p] && !mRetired[p])
+            if (was && !__atomic_load_n(&mPending[p], __ATOMIC_ACQUIRE) && !mRetired[p])
             {
                 if (!retire_pair(p)) return false;
                 mRetired[p] = 1;
             }
-            if (now) mPending[p] = 1;
+            if (now) __atomic_store_n(&mPending[p], (uint8_t) 1, __ATOMIC_RELEASE);
         }
     for (uint32_t o = mLastNout; o < nout_act && o < mCfg.nout; o++)
         for (Stage *st : mStages) HCV_TRY(hipMemsetAsync(st->timeline + (size_t) o * st->tl_len, 0, sizeof(float) * st->tl_len, mStream));
@@ -309,13 +309,18 @@ bool Engine::update_active_matrix(uint32_t rows_in, uint32_t nout_act)
 
 bool Engine::apply_pending_resets()
 {
-    bool any = false, all = true;
+    // (reset_pair / reset_all write the flags from other threads without the lock: a cheap look first, then every flag is TAKEN —
+    // exchanged with 0 — so that one raised after this point waits for the next block instead of being wiped)
+    bool any = false;
+    for (size_t p = 0; p < mPending.size() && !any; p++) any = __atomic_load_n(&mPending[p], __ATOMIC_ACQUIRE) != 0;
+    if (!any) return true;
+    std::vector<uint8_t> taken(mPending.size());
+    bool all = true;
     for (size_t p = 0; p < mPending.size(); p++)
     {
-        any = any || mPending[p];
-        if (mLoaded[p] && !mPending[p]) all = false;
+        taken[p] = __atomic_exchange_n(&mPending[p], (uint8_t) 0, __ATOMIC_ACQ_REL);
+        if (mLoaded[p] && !taken[p]) all = false;
     }
-    if (!any) return true;
     if (!fence_background(!all && exact_restart())) return false;
     if (all)
     {
@@ -328,9 +333,9 @@ bool Engine::apply_pending_resets()
         // sample (hcv_ghost.hip).  The time-domain head is fenced per sample directly.
         mCtlDirty = true;
         std::vector<size_t> restart;
-        for (size_t p = 0; p < mPending.size(); p++)
+        for (size_t p = 0; p < taken.size(); p++)
         {
-            if (!mPending[p]) continue;
+            if (!taken[p]) continue;
             if (!mRetired[p] && !retire_pair(p)) return false;
             if (mLoaded[p]) restart.push_back(p);
             else release_ghost(p);
@@ -350,7 +355,6 @@ bool Engine::apply_pending_resets()
         if (!rebuild_ghost_tables()) return false;
     }
     std::fill(mRetired.begin(), mRetired.end(), 0);
-    std::fill(mPending.begin(), mPending.end(), 0);
     return true;
 }
 

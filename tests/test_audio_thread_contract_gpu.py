@@ -1,8 +1,11 @@
 """The audio-thread contract of the reference (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:118-140,181-183):
 `process` never waits for a control thread's `set` / `resize` — not for the IR upload, not for an allocation, not for the
 device.  The reference mutes the pair being replaced for the blocks processed meanwhile; here the pair keeps playing its
-previous IR until the staged spectra are swapped in (engine.h: set_ir phases A / B), and what the audio thread can wait for is
-one short host-only section.
+previous IR until the staged spectra are swapped in (engine.h: set_ir phases A / B).  STRUCTURALLY: while a stream is running
+(a process call within the last 20 ms) no control call takes the engine lock at all — its swap section is posted to the
+engine's mailbox and the audio thread runs it itself at the start of its next call (hcv_engine.h: CtlJob) — so a process call of
+a running stream cannot find the lock taken by a set / resize / reset: `lock_contended` and `lock_wait_ns_max` are exactly 0, not
+small, and `mailbox_runs` counts the sections the audio thread ran.
 
 A control thread loops set(resize=True) with GROWING 10 s-class IRs on a 16x16 zero-latency engine — every growth re-strides the
 tail stage's whole spectrum store — while the audio thread issues paced 128-sample calls.  Asserted: the calls stay inside the
@@ -41,28 +44,9 @@ def _paced(call, ncalls, period):
     return ts * 1e3
 
 
-class _HostTimingNoise(AssertionError):
-    """A wall-clock criterion missed: the two threads of this test are Python threads on a shared host, and a preempted one —
-    the control thread inside its microsecond swap section, or the caller inside a call — shows up as a long lock wait, a muted
-    block or a slow call.  The scenario is repeated (at most twice) when that happens; the engine-exact criteria (parity of the
-    steady rows, no error, finite output, the stream after the swaps) are never retried."""
-
-
 @pytest.mark.parametrize("entry", ["host_pointers", "device_pointers", "sharded_host_pointers"])
 def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
-    for attempt in range(3):
-        try:
-            _scenario(H, oracle, entry)
-            return
-        except _HostTimingNoise as e:
-            print(f"[{entry}] attempt {attempt + 1}: {e}")
-            if attempt == 2:
-                raise
-
-
-def _timing(ok, msg):
-    if not ok:
-        raise _HostTimingNoise(msg)
+    _scenario(H, oracle, entry)         # (one run, no retry: the lock criteria are structural now, the wall-clock ones generous)
 
 
 def _scenario(H, oracle, entry):
@@ -134,19 +118,18 @@ def _scenario(H, oracle, entry):
     budget = 1e3 * RB / fs
     print(f"[{entry}] {sets['n']} set(resize) calls (worst {sets['worst_ms']:.1f} ms each) beside {ncalls} paced calls: p50 {np.percentile(ts, 50):.3f} "
           f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); lock contended {rt['lock_contended']}x, longest wait "
-          f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}")
+          f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}, sections run by the audio thread {rt['mailbox_runs']}")
     assert not sets["errors"] and sets["n"] >= 8                         # every length was loaded at least once: the stage regrew
-    # no block given up; the swap sections are host-only and take microseconds, so the longest wait for the lock stays far
-    # below the 2 ms after which a block would be muted (typical: 0 - 150 us)
-    _timing(rt["blocks_muted"] == 0, f"{rt['blocks_muted']} blocks muted")
-    _timing(rt["lock_wait_ns_max"] < 1.0e6, f"longest wait for the engine lock {rt['lock_wait_ns_max'] / 1e3:.0f} us")
-    # The engine-side guarantees are exact (no block given up, the lock never held across anything that waits); the wall-clock
-    # side is measured from a Python thread on a shared host, where a preempted caller shows up as one slow call: all but at
-    # most two of the 1400 calls must be inside the budget (typical maximum 0.4-1.1 ms), and none may look like a stall behind
-    # an upload or a regrow (tens to hundreds of milliseconds in round 1).
+    # STRUCTURAL: the stream never stopped, so every swap section went through the mailbox — the audio thread never found the
+    # engine lock taken, never waited for it, never gave a block up; and it ran at least one section per set()
+    assert rt["lock_contended"] == 0 and rt["lock_wait_ns_max"] == 0 and rt["blocks_muted"] == 0, rt
+    assert rt["mailbox_runs"] >= sets["n"] - 1, (rt, sets["n"])
+    # The wall-clock side is measured from a Python thread on a shared host, where a preempted caller shows up as one slow call:
+    # all but a handful of the 1400 calls inside the budget, none that looks like a stall behind an upload or a regrow (tens to
+    # hundreds of milliseconds in round 1), p99 well inside it
     over = int((ts > budget).sum())
-    _timing(over <= 2 and ts.max() < 40.0, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms")
-    _timing(np.percentile(ts, 99) < 0.5 * budget, f"p99 {np.percentile(ts, 99):.3f} ms")
+    assert over <= 4 and ts.max() < 40.0, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
+    assert np.percentile(ts, 99) < 0.75 * budget, f"p99 {np.percentile(ts, 99):.3f} ms"
     assert np.isfinite(ys).all()
     y_ref = ref.run(xs, len(steady), 2048)
     for k, o in enumerate(steady):

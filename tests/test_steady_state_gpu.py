@@ -32,7 +32,7 @@ def torch():
     return torch
 
 
-def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=8192, spread=None, tail_ratio=0):
+def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=8192, spread=None, tail_ratio=0, call_hops=1):
     """Impulse IRs built in HBM (a few scaled taps per pair, spread over the WHOLE IR), audio resident in HBM, streamed in
     whole tail hops.  The exact answer is a gain-weighted sum of delayed inputs, computed in float64 (torch on the GPU: plain
     shifted adds, nothing of this library).  Returns the tail stage's statistics."""
@@ -49,7 +49,7 @@ def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=819
     if spread is not None:
         delays[:, :, -1] = rng.randint(spread[0], spread[1], size=(nout, nin))
     gains = rng.uniform(-1, 1, size=(nout, nin, taps_per_pair))
-    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B, tailRatio=tail_ratio)
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B * call_hops, tailRatio=tail_ratio)
     h = torch.zeros(L, dtype=torch.float32, device=dev)
     for o in range(nout):
         for i in range(nin):
@@ -63,8 +63,8 @@ def _sparse_device_case(H, torch, nin, nout, L, hops, taps_per_pair, seed, B=819
     ys = torch.zeros((nout, S), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     c.clear_stats()
-    for pos in range(0, S, B):
-        c.process_dev(xs.data_ptr() + 4 * pos, S, ys.data_ptr() + 4 * pos, S, nin, nout, B)
+    for pos in range(0, S, B * call_hops):
+        c.process_dev(xs.data_ptr() + 4 * pos, S, ys.data_ptr() + 4 * pos, S, nin, nout, min(B * call_hops, S - pos))
     c.synchronize()
     x64 = xs.to(torch.float64)
     worst = 0.0
@@ -108,6 +108,18 @@ def test_config5_extended_ladder_full_depth(H, torch):
     stats, worst = _sparse_device_case(H, torch, 16, 16, L, hops, 3, seed=58, spread=(L - 3 * 8192, L), tail_ratio=8)
     assert [s["fft_size"] for s in stats] == [256, 1024, 4096, 16384, 131072, 1 << 20]
     assert stats[-1]["partitions"] == 10 and stats[-2]["partitions"] == 7 and stats[-3]["partitions"] == 7
+    assert worst < TOL_SUM
+
+
+@pytest.mark.parametrize("nin,nout,L,hops", [(16, 16, 8192 * 201 - 77, 232), (8, 24, 8192 * 130, 160), (16, 9, 8192 * 140 + 5, 168)])
+def test_batched_calls_long_rows_full_depth(H, torch, nin, nout, L, hops):
+    """65536-sample calls (8 tail hops per launch: the software-pipelined 4 x 8 tile, hcv_mac_tiled.hip) on LONG rows — 130 to 200
+    partitions, the batched leg of bench.py runs 703 — against float64 truth: taps over the whole IR, streamed past its length so
+    that the unchecked instantiation runs with every partition live, every k-slice and the ring wrap included; output counts that
+    are not a multiple of the tile (9 = two full tiles + one clamped tile).  <= 1e-5 of the peak."""
+    tail, worst = _sparse_device_case(H, torch, nin, nout, L, hops, 3, seed=91 + nout, spread=(L - 2 * 8192, L), call_hops=8)
+    assert tail["fft_size"] == 16384 and tail["hop_tile"] == 8 and tail["out_tile"] == 4, tail
+    assert tail["mac_steady_launches"] >= 2, tail
     assert worst < TOL_SUM
 
 

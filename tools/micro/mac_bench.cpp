@@ -9,6 +9,18 @@
 #include <cstdlib>
 #include <vector>
 
+// MAC_RANDOM=1: operands uniform in (-1, 1) instead of one constant (the chip clocks to its power budget: toggling operands cost the
+// hop-tiled launch several per cent)
+__global__ void fill_random(float *p, size_t n, unsigned seed)
+{
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+    {
+        unsigned h = (unsigned) i * 2654435761u ^ (unsigned) (i >> 32) * 40503u ^ seed;
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        p[i] = (float) (h >> 8) * (2.0f / 16777216.0f) - 1.0f;
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char **argv)
@@ -30,6 +42,12 @@ int main(int argc, char **argv)
     CK(hipMemset(H, 0x3c, hs * sizeof(float2)));       // small finite floats
     CK(hipMemset(X, 0x3c, xs * sizeof(float2)));
     CK(hipMemset(hv, 0, sizeof(long long) * nout * nin));
+    if (std::getenv("MAC_RANDOM") && std::atoi(std::getenv("MAC_RANDOM")))
+    {
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (float *) H, hs * 2, 1u);
+        hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (float *) X, xs * 2, 2u);
+        CK(hipDeviceSynchronize());
+    }
     hipStream_t st;
     CK(hipStreamCreate(&st));
     hipEvent_t a, b;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__((FourStepTile<(1 << L1), 8>::THREADS)) void big_col
     constexpr int TG = Tile::TG, G = Tile::G, BIG_COLS = Tile::TILE, NT = Tile::THREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [BIG_COLS][M1]
 
-    const int col0 = blockIdx.x * BIG_COLS;
+    const int col0 = fourstep_tile_of(blockIdx.x, gridDim.x) * BIG_COLS;
     const float2 *zin = Zin + (long long) blockIdx.y * M;
     float2 *tout = Tout + (long long) blockIdx.y * M;
 
@@ -132,7 +132,7 @@ __global__ __launch_bounds__((FourStepTile<(1 << L2), 8>::THREADS)) void big_row
     constexpr int TG = Tile::TG, G = Tile::G, BIG_ROWS = Tile::TILE, NT = Tile::THREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];   // [BIG_ROWS][M2]
 
-    const int row0 = blockIdx.x * BIG_ROWS;
+    const int row0 = fourstep_tile_of(blockIdx.x, gridDim.x) * BIG_ROWS;
     const float2 *tin = Tin + (long long) blockIdx.y * M + (long long) row0 * M2;
     float2 *zout = Zout + (long long) blockIdx.y * M;
 

@@ -648,13 +648,20 @@ template <int LOG2M, int WG = 256> struct FFTGeom
 #ifndef HCV_FX_TILE_BYTES
 #define HCV_FX_TILE_BYTES 256
 #endif
+#ifndef HCV_FX_TILE_MINRUN
+#define HCV_FX_TILE_MINRUN 64       // bytes of complex elements per tile line below which a 64 KiB tile is not worth its second workgroup
+#endif
+#ifndef HCV_FX_XCD_ORDER
+#define HCV_FX_XCD_ORDER 1          // workgroup b of a pass takes tile (b % 8) * (tiles / 8) + b / 8: the tiles an XCD holds at one time
+                                    // are NEIGHBOURS, so the partial cache lines of their strided runs meet in that XCD's L2
+#endif
 template <int P, int ELEM_BYTES> struct FourStepTile
 {
     static constexpr int TG = P / 16 < 256 ? P / 16 : 256;
     static constexpr int WANT = HCV_FX_TILE_BYTES / ELEM_BYTES;         // complex elements: 128 bytes per split array
     // LDS budget per tile: 64 KiB (two workgroups per CU) while that still leaves 64-byte runs, else 128 KiB (one)
     static constexpr int CAP64 = 64 * 1024 / (P * ELEM_BYTES), CAP128 = 128 * 1024 / (P * ELEM_BYTES);
-    static constexpr int CAP = (HCV_FX_TILE_CAP64 && CAP64 * ELEM_BYTES >= 128) ? CAP64 : CAP128;
+    static constexpr int CAP = (HCV_FX_TILE_CAP64 && CAP64 * ELEM_BYTES >= HCV_FX_TILE_MINRUN) ? CAP64 : CAP128;
     static constexpr int TILE = CAP < WANT ? CAP : WANT;
     static constexpr int THREADS = TILE * TG < 1024 ? TILE * TG : 1024;
     static constexpr int G = THREADS / TG;                              // sub-transforms in flight
@@ -666,5 +673,15 @@ template <int P, int ELEM_BYTES> struct FourStepTile
     static constexpr int WAVES_PER_SIMD = PER_CU * THREADS / 256 < 1 ? 1 : PER_CU * THREADS / 256;   // (second launch bound, HIP semantics)
 };
 
+// Workgroups are handed to the eight XCDs round robin (linear workgroup id mod 8).  With the plain order the tiles that run at one
+// time on ONE XCD are eight apart, and each 32- or 64-byte run of a strided tile line is a partial cache line in that XCD's L2
+// whose other parts are fetched (and written back) by other XCDs.
+__device__ __forceinline__ int fourstep_tile_of(int b, int tiles)
+{
+#if HCV_FX_XCD_ORDER
+    if ((tiles & 7) == 0) return (b & 7) * (tiles >> 3) + (b >> 3);
+#endif
+    return b;
+}
 
 } // namespace hcv

@@ -487,6 +487,19 @@ namespace
     }
 
 
+#ifdef HCV_FX_PHASE_TIMING
+    // diagnostic builds (tools/micro/fx_phases.py): time from a workgroup's start to the end of its load / transform / store phase,
+    // summed over workgroups, in 10 ns ticks of the constant-rate counter; [0..3] column pass, [4..7] row pass, last = workgroups
+    __device__ unsigned long long g_fx_phase[8];
+#define FX_T0 const unsigned long long fx_t0 = wall_clock64();
+#define FX_MARK(i) do { __syncthreads(); if (threadIdx.x == 0) atomicAdd(&g_fx_phase[i], wall_clock64() - fx_t0); } while (0)
+#define FX_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_fx_phase[i], 1ull); } while (0)
+#else
+#define FX_T0
+#define FX_MARK(i)
+#define FX_COUNT(i)
+#endif
+
     // M = M1 * M2, n = M2*n1 + n2, k = k1 + M1*k2.   cols: for every n2 an M1-point transform over n1, times W_M^(n2 k1)
     template <class T, int L1>
     __global__ __launch_bounds__((FxTile<(1 << L1), (int) sizeof(typename Cx<T>::type)>::THREADS)) void fx_cols_kernel(FxK<T> a0, typename Cx<T>::type *__restrict__ work, int M2, int M, long long q0,
@@ -499,7 +512,8 @@ namespace
         extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
         C *lds = reinterpret_cast<C *>(fx_raw);                                // [COLS][M1]
 
-        const int col0 = blockIdx.x * COLS;
+        FX_T0
+        const int col0 = fourstep_tile_of(blockIdx.x, gridDim.x) * COLS;
         const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
         typedef typename FxVec<T>::type VT;
         constexpr int V = FxVec<T>::V;
@@ -524,8 +538,10 @@ namespace
             }
         }
         __syncthreads();
+        FX_MARK(0);
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
         for (int c0 = 0; c0 < COLS; c0 += G) LdsFFT<L1, TG, C>::run(LdsBuf<C>{ lds + (c0 + g) * fourstep_pitch(M1) }, t, tw1);
+        FX_MARK(1);
         C *out = work + (long long) blockIdx.y * M;
         constexpr int CV = 16 / (int) sizeof(C) > 0 ? 16 / (int) sizeof(C) : 1;       // complex values per 16-byte store: 2 (float), 1 (double)
         constexpr int NI = ((COLS / CV) * M1) / NT, DK = NT / (COLS / CV);      // a thread's elements: its column pair at k1 = k10 + i DK
@@ -577,6 +593,8 @@ namespace
                 else d[0] = v[0];
             }
         }
+        FX_MARK(2);
+        FX_COUNT(3);
     }
 
     // rows: for every k1 an M2-point transform over n2; element k2 of row k1 is bin k1 + M1*k2
@@ -591,7 +609,8 @@ namespace
         extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
         C *lds = reinterpret_cast<C *>(fx_raw);                                // [ROWS][M2]
 
-        const int row0 = blockIdx.x * ROWS;
+        FX_T0
+        const int row0 = fourstep_tile_of(blockIdx.x, gridDim.x) * ROWS;
         const C *in = work + (long long) blockIdx.y * M + (long long) row0 * M2;
         constexpr int CV = 16 / (int) sizeof(C) > 0 ? 16 / (int) sizeof(C) : 1;
         if (CV == 2)
@@ -609,8 +628,10 @@ namespace
         else
             for (int e = threadIdx.x; e < ROWS * M2; e += NT) LdsBuf<C>{ lds + (e / M2) * fourstep_pitch(M2) }[e % M2] = in[e];
         __syncthreads();
+        FX_MARK(4);
         const int g = threadIdx.x / TG, t = threadIdx.x % TG;
         for (int r0 = 0; r0 < ROWS; r0 += G) LdsFFT<L2, TG, C>::run(LdsBuf<C>{ lds + (r0 + g) * fourstep_pitch(M2) }, t, tw2);
+        FX_MARK(5);
         const FxK<T> a = fx_at(a0, q0 + blockIdx.y);
         typedef typename FxVec<T>::type VT;
         constexpr int V = FxVec<T>::V;
@@ -643,6 +664,8 @@ namespace
                 else fx_store<T, C>(a, 0, k, v);
             }
         }
+        FX_MARK(6);
+        FX_COUNT(7);
     }
 
     template <class T>
@@ -985,3 +1008,13 @@ hipError_t fftx_exec(int device, const FxCall &c, hipStream_t stream, std::strin
 }
 
 } // namespace hcv
+
+#ifdef HCV_FX_PHASE_TIMING
+// diagnostic builds only (not declared in include/): reads and clears the phase counters of the four-step passes
+extern "C" int hcv_debug_fx_phases(unsigned long long *out8)
+{
+    unsigned long long zero[8] = { 0 };
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hcv::g_fx_phase), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(hcv::g_fx_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

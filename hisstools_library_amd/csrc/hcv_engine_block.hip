@@ -138,26 +138,31 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     // transforms, multiply-accumulate and inverse of a steady-state one-hop block of an engine with ONE output as ONE launch with
     // in-launch hand-overs instead of two or three kernel boundaries (c1: 0.0166 -> 0.0101 ms per block).  With the MAC's HIP events
     // on (profiling) the block takes the separate launches, so that the statistics keep their meaning.
-    if (tail_head_here && direct_in && blk.direct_out && !blk.pipe2 && serial && T == 1 && rows_in >= 1 && nout_act == 1 && !mCfg.diag && !mProfiling &&
-        !st.gh_count && fused_block_1x1_applies(st.log2n))
+    const bool fuse_one = T == 1 && fused_block_1x1_applies(st.log2n);
+    const bool fuse_hops = T > 1 && rows_in == 1 && fused_block_hops_applies(st.log2n, T);       // (several hops of a short stage: config 2)
+    if (tail_head_here && direct_in && blk.direct_out && !blk.pipe2 && serial && rows_in >= 1 && nout_act == 1 && !mCfg.diag && !mProfiling &&
+        !st.gh_count && (fuse_one || fuse_hops))
     {
         const int Pw = (int) (st.P + st.lead);
         const long long h_mac = h_first - (long long) (1 - st.lead);
         const long long p_live = std::max<long long>(0, std::min<long long>(Pw, h_mac + T));
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
-        if (!wcheck && p_live >= 1 && (long long) rows_in * p_live <= 2048)
+        if (!wcheck && p_live >= 1 && (long long) rows_in * p_live <= 2048 && (!fuse_hops || (p_live == Pw && st.y_elems >= (size_t) T * st.M)))
         {
-            if (rows_in == 1 && p_live <= 16)
+            if (fuse_hops)
+                HCV_TRY(launch_fused_block_hops(st.log2n, mHist, hmask, blk.din, n0, h_first, T, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
+                                                st.tickets + kMacTickets, st.coop_arrived, sS));
+            else if (rows_in == 1 && p_live <= 16)
                 HCV_TRY(launch_fused_block_1x1(st.log2n, mHist, hmask, blk.din, n0, h_first, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
                                                st.tickets + kMacTickets, st.coop_arrived, sS));
             else
                 HCV_TRY(launch_fused_block_nx1(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, st.X, (int) st.R, st.Hs,
                                                (long long) st.hstride(), (int) p_live, h_mac, st.Y, blk.dout, st.tw, st.tickets + kMacTickets, st.coop_arrived, sS));
             st.launches++;
-            st.hops += 1;
+            st.hops += (uint64_t) T;
             st.last_ksplit = 1;
             st.last_ot = 1;
-            st.last_tt = 1;
+            st.last_tt = (uint32_t) T;
             st.last_parts = (uint32_t) p_live;
             HCV_TRY(rec(mEvInput[q], sS));
             HCV_TRY(rec(mEvEmit[q], sS));

@@ -750,6 +750,164 @@ __global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
     rifft_split_body<LOG2N, LOG2R, true, TG>(dyn, tid, w, a.Y, 1, 0, a.out - M, a.tw, a.tws);
 }
 
+
+// The same for a 1 x 1 engine whose block is SEVERAL hops of a short stage (PartitionedConvolve with 4096-point partitions called
+// with 8192 samples: four hops per block, BASELINE config 2) — until now four launches: transforms, hop-tiled multiply-accumulate,
+// reduction, inverse.  Hop t of the block needs the spectra of hops h + t - (1 - lead) - p: all but a handful of its terms (those
+// with p < T) read spectra of EARLIER blocks, so the 16 waves of every multiply-accumulate workgroup first sum the partitions
+// p >= T over their slices — each IR spectrum loaded once for all T hops, the window of input spectra sliding as in the hop-tiled
+// kernel (hcv_mac_tiled.hip) — beside the T x (R/2 + 1) workgroups of the forward transforms, then wait for those and add the
+// T partitions p < T (one per wave).  Workgroups 0 .. M/128 - 1: multiply-accumulate (128 bins each), then 0 .. T R/2 - 1 the
+// inverse of hop t = w / (R/2); the rest: residue class r of hop t's forward transform.
+struct FusedHopsParams
+{
+    float *hist;
+    const float *in;
+    float *out;                 // the block's output samples (T hops)
+    float2 *X;                  // [Rring][M]
+    const float2 *H;            // [P][M]
+    float2 *Y;                  // [T][M] scratch
+    const float2 *tw, *tws;
+    unsigned *bar;
+    long long hist_mask, n0, h; // h = the block's first hop
+    int Rring, P, T, hmac_mod, new_from;   // hmac_mod = (hop that partition 0 of hop h reads) mod Rring; new_from = h - that hop (1 lone, 0 lead)
+    unsigned targetA, targetB;
+};
+
+template <int LOG2N, int LOG2R, int TMAX>
+__global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams a)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, M2 = M / 2, R = 1 << LOG2R, S = N >> LOG2R, NF = R / 2 + 1, TG = 1024, MACW = M2 / 64;
+    static_assert(TMAX * (R / 2) <= MACW, "the inverse's workgroups are the first of the multiply-accumulate's");
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    const int tid = threadIdx.x, w = blockIdx.x;
+    const int T = a.T;
+
+    if (w >= MACW)
+    {
+        const int t = (w - MACW) / NF, r = (w - MACW) % NF;
+        const long long h = a.h + t;
+        rfft_split_body<LOG2N, LOG2R, true, true, TG>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, r, a.hist, a.in, (h - 1) * (long long) M, a.n0,
+                                                      a.hist_mask, a.X + (long long) (h % a.Rring) * M, a.tw, a.tws);
+        grid_arrive(a.bar);
+        return;
+    }
+
+    {
+        const int lane = tid & 63, ks = tid >> 6;
+        const int b4 = w * 64 + lane;
+        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
+        float4 acc[TMAX];
+        float ny[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; t++)
+        {
+            acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ny[t] = 0.f;
+        }
+        auto slot_of = [&](int d) -> int                 // ring slot of hop (hmac + d), d in (-Rring, TMAX)
+        {
+            int sl = a.hmac_mod + d;
+            if (sl < 0) sl += a.Rring;
+            if (sl >= a.Rring) sl -= a.Rring;
+            return sl;
+        };
+        auto cmac = [&](float4 &c, float &n, const float4 &x, const float4 &hv)
+        {
+            c.x += x.x * hv.x - x.y * hv.y;
+            c.y += x.x * hv.y + x.y * hv.x;
+            c.z += x.z * hv.z - x.w * hv.w;
+            c.w += x.z * hv.w + x.w * hv.z;
+            n += x.y * hv.y;
+        };
+
+        // ---- partitions p >= T: every spectrum they read is older than this block
+        const int K = a.P - T;
+        if (K > 0)
+        {
+            const int kper = (K + 15) / 16;
+            const int p0 = T + ks * kper, p1 = min(a.P, p0 + kper);
+            if (p0 < p1)
+            {
+                float4 win[TMAX];                        // win[t] = X[hmac + t - p]
+#pragma unroll
+                for (int t = 0; t < TMAX; t++) win[t] = X4[(long long) slot_of(min(t, T - 1) - p0) * M2 + b4];
+                for (int pb = p0; pb < p1; pb += 8)
+                {
+                    float4 hh[8], xn[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                    {
+                        const int p = min(pb + u, p1 - 1);
+                        hh[u] = H4[(long long) p * M2 + b4];
+                        xn[u] = X4[(long long) slot_of(-p - 1) * M2 + b4];      // the hop the window gains at p + 1
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (pb + u < p1)
+                        {
+#pragma unroll
+                            for (int t = 0; t < TMAX; t++) cmac(acc[t], ny[t], win[t], hh[u]);
+#pragma unroll
+                            for (int t = TMAX - 1; t > 0; t--) win[t] = win[t - 1];
+                            win[0] = xn[u];
+                        }
+                }
+            }
+        }
+
+        // ---- partitions p < T, one per wave: hop t's term reads hop hmac + t - p, written by this launch when t - p >= new_from
+        grid_wait(a.bar, a.targetA);
+        if (ks < T && ks < a.P)
+        {
+            const int p = ks;
+            const float4 hv = H4[(long long) p * M2 + b4];
+#pragma unroll
+            for (int t = 0; t < TMAX; t++)
+                if (t < T)
+                {
+                    const float2 *xp = reinterpret_cast<const float2 *>(X4 + (long long) slot_of(t - p) * M2 + b4);
+                    const float2 lo = get2<true>(xp), hi = get2<true>(xp + 1);
+                    cmac(acc[t], ny[t], make_float4(lo.x, lo.y, hi.x, hi.y), hv);
+                }
+        }
+        float4 *red = reinterpret_cast<float4 *>(dyn);      // [16][TMAX][64]
+#pragma unroll
+        for (int t = 0; t < TMAX; t++)
+        {
+            if (b4 == 0)
+            {
+                acc[t].x += ny[t];
+                acc[t].y = ny[t];
+            }
+            red[(ks * TMAX + t) * 64 + lane] = acc[t];
+        }
+        __syncthreads();
+        // hop t's sums by wave t (the slices in wave order, as the one-hop kernel adds them)
+        if (ks < T)
+        {
+            float4 sum = red[ks * 64 + lane];
+#pragma unroll
+            for (int k = 1; k < 16; k++)
+            {
+                const float4 q = red[(k * TMAX + ks) * 64 + lane];
+                sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+            }
+            float2 *y = a.Y + (long long) ks * M + 2 * (long long) b4;
+            put2<true>(y, make_float2(sum.x, sum.y));
+            put2<true>(y + 1, make_float2(sum.z, sum.w));
+        }
+    }
+    grid_arrive(a.bar + 1);
+    if (w >= T * (R / 2)) return;
+
+    grid_wait(a.bar + 1, a.targetB);
+    {
+        const int t = w / (R / 2), j = w % (R / 2);
+        rifft_split_body<LOG2N, LOG2R, true, TG>(dyn, tid, j, a.Y + (long long) t * M, 1, 0, a.out + (long long) t * M - M, a.tw, a.tws);
+    }
+}
+
 bool fused_block_1x1_applies(int log2n)
 {
     static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0);
@@ -815,6 +973,45 @@ hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, c
     constexpr int G = R + R / 2 + 1;
     a.pin = xcd_pin_for(G);
     hipLaunchKernelGGL((fused_block_1x1_kernel<LOG2N, LOG2R>), dim3(G * (a.pin >= 0 ? 8 : 1)), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+
+bool fused_block_hops_applies(int log2n, int T)
+{
+    static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0) &&
+                           !(std::getenv("HCV_COOP_HOPS") && std::atoi(std::getenv("HCV_COOP_HOPS")) == 0);
+    return on && log2n == 12 && T >= 2 && T <= 4;
+}
+
+hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, int T, float2 *X, int Rring,
+                                   const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
+                                   hipStream_t st)
+{
+    if (log2n != 12 || T < 2 || T > 4 || P < 1) return hipErrorInvalidValue;
+    constexpr int LOG2N = 12, LOG2R = 3, TMAX = 4, M = 1 << (LOG2N - 1), S = 1 << (LOG2N - LOG2R), R = 1 << LOG2R, MACW = M / 128;
+    const float2 *tws = sub_table(LOG2N - LOG2R);
+    if (!tws) return hipErrorInvalidValue;
+    constexpr size_t lds_fft = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R), lds_red = sizeof(float4) * 16 * TMAX * 64;
+    constexpr size_t lds = lds_fft > lds_red ? lds_fft : lds_red;
+    static bool allowed[64] = {};
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !allowed[dev])
+    {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_block_hops_kernel<LOG2N, LOG2R, TMAX>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) allowed[dev] = true;
+    }
+    FusedHopsParams a;
+    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
+    a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.Rring = Rring; a.P = P; a.T = T;
+    a.hmac_mod = (int) (h_mac % Rring);
+    a.new_from = (int) (h - h_mac);
+    a.targetA = (arrived[0] += (unsigned) (T * (R / 2 + 1)));
+    a.targetB = (arrived[1] += (unsigned) MACW);
+    hipLaunchKernelGGL((fused_block_hops_kernel<LOG2N, LOG2R, TMAX>), dim3(MACW + T * (R / 2 + 1)), dim3(1024), lds, st, a);
     return hipGetLastError();
 }
 

@@ -64,6 +64,13 @@ namespace hcv
                                       const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
                                       hipStream_t st);
 
+    // several hops of a short stage per block (1 x 1, 4096-point partitions, T = 2 .. 4 hops: BASELINE config 2 at 8192-sample calls);
+    // h = the block's first hop, Y = room for T spectra, out = the block's T hops of output
+    bool fused_block_hops_applies(int log2n, int T);
+    hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, int T, float2 *X, int Rring,
+                                       const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
+                                       hipStream_t st);
+
     // nin inputs -> one output, or 1 x 1 with a long reduction (K = nin P split over the waves of 1024-thread workgroups); H = output 0's
     // pairs, `hstride` float2 between two inputs' spectra
     hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0,

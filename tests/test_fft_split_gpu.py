@@ -52,3 +52,44 @@ def test_split_off_matches_split_on_bitwise_in_neither_direction_but_to_rounding
     peak = np.abs(ys[0]).max()
     assert np.abs(ys[0] - ys[1]).max() <= 2e-6 * peak
     assert np.abs(ys[0] - ys[1]).max() > 0           # (they ARE different code paths)
+
+
+@pytest.mark.parametrize("block", [8192, 6144, 4096])
+def test_fused_multi_hop_block_of_a_4096_point_stage_vs_oracle(block):
+    """BASELINE config 2's shape at reduced length — PartitionedConvolve(4096) called with 4, 3 and 2 hops per block — through the
+    fused multi-hop block (hcv_fft_split.hip: fused_block_hops_kernel; forward transforms, multiply-accumulate over all partitions
+    and inverse of the block's hops in ONE launch) against the CPU oracle (bit-identical to the unmodified reference,
+    PartitionedConvolve.cpp:243-426) with a dense decaying-noise IR, streamed past the IR length so that every partition is live,
+    <= 2e-6 of the peak; the stage statistics must show the fused launch (one slice, hop tile = hops per block), and the same
+    stream with the fused block switched off (HCV_COOP_HOPS=0: transforms, hop-tiled MAC, reduction, inverse as four launches)
+    must agree to rounding."""
+    code = ("import sys, json, numpy as np, hisstools_library_amd as H\n"
+            "from oracle import oracle as O\n"
+            "B = int(sys.argv[2]); L, N = 60000 - 77, 4096; S = 40 * B\n"
+            "h = O.synth_ir(0, 0, L); x = O.synth_audio(3, S)\n"
+            "p = H.Convolver(1, 1, 0, custom=(L, False, N, 0, 0, 0), maxBlock=B); assert p.set(0, 0, h, True) == 0\n"
+            "y = p.run(x[None, :], 1, B)[0]\n"
+            "r = O.PartitionedConvolve(N, L, 0, 0); r.setResetOffset(0); assert r.set(h) == 0\n"
+            "yr = r.run(x, 2048)\n"
+            "st = p.stage_stats()[-1]\n"
+            "np.save(sys.argv[1], np.stack([y, yr]))\n"
+            "print(json.dumps({k: int(st[k]) for k in ('hop_tile', 'ksplit', 'partitions') if k in st}))\n")
+    import json
+    import numpy as np
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("1", "0"):
+            path = os.path.join(d, f"y{mode}.npy")
+            out = subprocess.run([sys.executable, "-c", code, path, str(block)], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                                 env=dict(os.environ, HCV_COOP_HOPS=mode))
+            assert out.returncode == 0, out.stderr[-2000:]
+            res[mode] = (np.load(path), json.loads(out.stdout.strip().splitlines()[-1]))
+    (y1, st1), (y0, st0) = res["1"], res["0"]
+    peak = np.abs(y1[1]).max()
+    assert np.abs(y1[0] - y1[1]).max() <= 2e-6 * peak, np.abs(y1[0] - y1[1]).max() / peak
+    assert np.abs(y0[0] - y0[1]).max() <= 2e-6 * peak
+    assert np.abs(y1[0] - y0[0]).max() <= 2e-6 * peak
+    if st1:
+        assert st1["hop_tile"] == block // 2048 and st1["ksplit"] == 1, st1         # the fused launch ran the steady state ...
+        assert st0["ksplit"] > 1, st0                                                # ... and the separate launches did without it

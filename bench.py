@@ -713,6 +713,14 @@ def bench_line(args, ctx):
             if have_ref and not args.no_self_check and world == 1:
                 extended["self_check"] = check_against_cpu_leg(e_conv)
             extended["all_stage_mac_ms_per_step"] = {str(s_["fft_size"]): round(s_["mac_ms"] / args.steps, 4) for s_ in e_stats}
+            # SURVEY 8d's per-sample-time figure summed over the ladder's stages (8 Nin (Nout + 1) sum P + 12 Nin stages + 4 Nout stages)
+            # against the WHOLE step: no single kernel dominates this leg (profiles/r03_c5_extended_kernel_summary.txt)
+            e_sum_p, e_ns = sum(s_["partitions"] for s_ in e_stats), len(e_stats)
+            e_bytes = (8.0 * nin * (nout + 1) * e_sum_p + 12.0 * nin * e_ns + 4.0 * nout * e_ns) * B
+            e_gbs = e_bytes / (e_el / args.steps) / 1e9
+            extended["roofline_step"] = {"bound": "hbm", "achieved": round(e_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(e_gbs / 8000.0, 4),
+                                         "alg_bytes_per_step": int(e_bytes), "sum_partitions": int(e_sum_p),
+                                         "note": "whole step (every stage's kernels, transforms included) against SURVEY 8d's bytes for this ladder"}
             extended["note"] = ("MI355X extension, not the reference's partitioning: reported beside the headline, never as it; parity at this scale: "
                                 "tests/test_steady_state_gpu.py::test_config5_extended_ladder_full_depth")
             del e_conv

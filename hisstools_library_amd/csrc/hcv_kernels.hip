@@ -572,6 +572,74 @@ __global__ __launch_bounds__(FIR_THREADS) void fir_head_kernel(const float *__re
     }
 }
 
+// The same sum for SMALL calls of a matrix with many inputs (the real-time sizes: 32 .. 256 samples per call, 64 x 64 channels).
+// The kernel above gives a workgroup 512 output samples of one output and walks the inputs one after the other — two barriers and
+// L taps of serial work per input: with 32 samples per call 8 of its 128 threads have anything to do and a 64-input row takes
+// 222 us, three quarters of a 32-sample call of the 64 x 64 engine.  Here a workgroup owns 32 samples of one output and its 256
+// threads split the TAPS eight ways (thread = sample n, tap slice ks); the windows and taps of a whole batch of inputs are staged
+// in LDS at once (every global load in flight before the one barrier), each thread runs nin x L / 8 multiply-adds out of LDS
+// (x reads conflict-free, tap reads broadcast), and the eight slices are added up in LDS.  TimeDomainConvolve.cpp:100-163.
+constexpr int FIRS_THREADS = 256, FIRS_SAMPLES = 32, FIRS_SLICES = FIRS_THREADS / FIRS_SAMPLES;
+
+template <bool CHECK>
+__global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
+                                                                      const float *__restrict__ taps, int Lpad, int tap_stride, int nin, int nin_alloc,
+                                                                      long long n0, int B, const long long *__restrict__ valid_from,
+                                                                      float *__restrict__ out, long long out_stride, int ib)
+{
+    extern __shared__ __attribute__((aligned(16))) float firs_lds[];
+    const int W = FIRS_SAMPLES + Lpad;                     // x[nblk - Lpad .. nblk + 32) of one input
+    float *xs = firs_lds;                                  // [ib][W]
+    float *hs = firs_lds + (size_t) ib * W;                // [ib][Lpad]
+    float *red = hs + (size_t) ib * Lpad;                  // [slices][32]
+
+    const int tid = threadIdx.x, n = tid & (FIRS_SAMPLES - 1), ks = tid / FIRS_SAMPLES;
+    const int nb = blockIdx.x * FIRS_SAMPLES, o = blockIdx.y;
+    const long long nabs = n0 + nb;
+    const int kper = Lpad / FIRS_SLICES, k0 = ks * kper;   // (Lpad is a multiple of 16)
+    const int L4 = Lpad / 4;
+
+    float acc = 0.f;
+    for (int i0 = 0; i0 < nin; i0 += ib)
+    {
+        const int nbi = min(ib, nin - i0);
+        __syncthreads();
+        for (int e = tid; e < nbi * W; e += FIRS_THREADS)
+        {
+            const int i = e / W, j = e - i * W;
+            const long long pos = nabs - Lpad + j;
+            float v = hist[(long long) (i0 + i) * hist_stride + (pos & hist_mask)];
+            if (CHECK)
+            {
+                if (pos < valid_from[(long long) o * nin_alloc + (i0 + i)]) v = 0.f;
+            }
+            xs[e] = v;
+        }
+        for (int e = tid; e < nbi * L4; e += FIRS_THREADS)
+        {
+            const int i = e / L4, k4 = e - i * L4;
+            reinterpret_cast<float4 *>(hs)[e] = *reinterpret_cast<const float4 *>(taps + ((long long) o * nin_alloc + (i0 + i)) * tap_stride + 4 * k4);
+        }
+        __syncthreads();
+        for (int i = 0; i < nbi; i++)
+        {
+            const float *x = xs + i * W + Lpad + n - k0;   // x[n - k] = x[-(k - k0)]
+            const float *h = hs + i * Lpad + k0;
+#pragma unroll 8
+            for (int k = 0; k < kper; k++) acc += h[k] * x[-k];
+        }
+    }
+    red[ks * FIRS_SAMPLES + n] = acc;
+    __syncthreads();
+    if (ks == 0 && nb + n < B)
+    {
+        float s = acc;
+#pragma unroll
+        for (int q = 1; q < FIRS_SLICES; q++) s += red[q * FIRS_SAMPLES + n];
+        out[(long long) o * out_stride + nb + n] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K7: ring bookkeeping
 // ------------------------------------------------------------------------------------------------
@@ -891,6 +959,25 @@ hipError_t launch_fir_head(const float *hist, long long hist_stride, long long h
                            long long out_stride, hipStream_t st)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
+    // small calls of matrices with several inputs: taps split over the threads, a batch of inputs staged at once (HCV_FIR_SMALL = 0:
+    // the general kernel everywhere)
+    static const bool small_on = !(std::getenv("HCV_FIR_SMALL") && std::atoi(std::getenv("HCV_FIR_SMALL")) == 0);
+    if (small_on && !diag && B <= 256 && nin >= 1 && Lpad >= 16 && Lpad <= 1024)
+    {
+        const int per_input = FIRS_SAMPLES + 2 * Lpad;                             // floats of LDS per staged input
+        const int ibmax = std::max(1, (60 * 1024 / 4 - FIRS_THREADS) / per_input);
+        const int batches = (nin + ibmax - 1) / ibmax;
+        const int ib = (nin + batches - 1) / batches;
+        const size_t lds = sizeof(float) * ((size_t) ib * per_input + FIRS_THREADS);
+        const dim3 grid((B + FIRS_SAMPLES - 1) / FIRS_SAMPLES, nout);
+        if (check)
+            hipLaunchKernelGGL((fir_head_small_kernel<true>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
+                               nin_alloc, n0, B, valid_from, out, out_stride, ib);
+        else
+            hipLaunchKernelGGL((fir_head_small_kernel<false>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
+                               nin_alloc, n0, B, valid_from, out, out_stride, ib);
+        return hipGetLastError();
+    }
     // widest output tile that still leaves >= 2 workgroups per CU
     const long long sblocks = (B + FIR_SPB - 1) / FIR_SPB;
     int otd = 4;

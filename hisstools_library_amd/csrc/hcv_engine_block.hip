@@ -16,7 +16,14 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
     HCV_BLOCK_LOCALS(blk);
     const hipStream_t sS = serial ? mStream : st.stream;
     if (st.pre_hop < 0 || st.bg_launched >= st.bg_slices) return true;
-    const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M;
+    // Slices come due a little AHEAD of the even grid (HCV_BG_LEAD samples, default 64; stages of at least 4096 points): on the grid the
+    // tail's slice k falls due at sample k M / 16 = a multiple of 512, i.e. in the very call that also carries the hop boundaries of the
+    // 256- and 1024-point stages — with 32-sample calls of the 64 x 64 / 10 s engine every sixteenth call took 0.48 ms (a 0.2 ms tail
+    // slice on top of two boundaries) against 0.075 ms for its neighbours.  64 samples early the slice lands in a plain call
+    // (32-sample calls: the 14th of 16; 64-sample calls: the 7th of 8).
+    static const long long lead_env = std::getenv("HCV_BG_LEAD") ? std::atoll(std::getenv("HCV_BG_LEAD")) : 64;
+    const long long lead = st.M >= 2048 ? std::min<long long>(lead_env, (long long) st.M / (2 * std::max(1, st.bg_slices))) : 0;
+    const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M + lead;
     int due = boundary ? st.bg_slices : (int) std::min<long long>(st.bg_slices, std::max<long long>(0, into * st.bg_slices / (long long) st.M));
     const int per = (st.bg_parts + st.bg_slices - 1) / st.bg_slices;
     const long long slot_elems = (long long) mCfg.nout * st.M;
@@ -331,9 +338,11 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     if (head_here)
     {
         // head = partition "-1": Yh[t][o] = sum_i X[i][h_t] * Hhead[o][i]
+        // (the buffer holds Tmax hops of one slice: a call of fewer hops — the real-time sizes — splits the reduction over the inputs
+        //  into the room that is left, up to eight ways; one slice meant every wave walking all the inputs, 85 us on 64 x 64)
         const MacShape hs = mac_shape(st, /* P */ 1, /* Pcap */ 1,
                                       /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
-                                      /* T */ T, /* max_ksplit */ 1);
+                                      /* T */ T, /* max_ksplit */ (int) std::max<long long>(1, std::min<long long>(8, (long long) st.Tmax / std::max(1, T))));
         MacPlan hp;
         mac_plan(hs, hp);
         if (!mac(st, hs, hp, head_spec, head_y, h_first, false, sM)) return false;
@@ -356,6 +365,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     // ---- MAC phase (stream sM)
     MacPlan pl;
     pl.ksplit = 1;
+    bool boundary_split = false;
     if (st.P)
     {
         if (have_pre)
@@ -366,9 +376,16 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             HCV_TRY(launch_reduce_partials(st.Ypre, st.bg_slices, (long long) mCfg.nout * st.M, (long long) mCfg.nout * st.M, sM));
             MacShape s0 = sh;
             s0.P = 1;
-            s0.max_ksplit = 1;
+            // Partition 0 is a reduction over the inputs only — 64 terms on the 64 x 64 engine — and with ONE k-slice every wave walked
+            // them all one after the other: 85 us per boundary, for 4 MB of spectra, twice in the call that carries the boundaries of
+            // two stages.  Once their total sits in slot 0 the slices' other slots are free, so partition 0 is split up to seven ways
+            // into slots 1 .. and the inverse adds the slots up as it loads them (HCV_BOUNDARY_KSPLIT = 1: one slice, as before).
+            static const int bks = std::getenv("HCV_BOUNDARY_KSPLIT") ? std::atoi(std::getenv("HCV_BOUNDARY_KSPLIT")) : 7;
+            boundary_split = !is_big_fft(st.log2n) && bks > 1 && nout_act == mCfg.nout;
+            s0.max_ksplit = boundary_split ? std::min(bks, kBgSlices - 1) : 1;
             mac_plan(s0, pl);
-            if (!mac(st, s0, pl, st.Ht(), st.Y, h_first, check, sM)) return false;
+            if (pl.ksplit <= 1) boundary_split = false;
+            if (!mac(st, s0, pl, st.Ht(), boundary_split ? st.Ypre + (size_t) mCfg.nout * st.M : st.Y, h_first, check, sM)) return false;
         }
         else
         {
@@ -410,6 +427,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
                 HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 1, y_elems, h_first, 1, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1,
                                                  st.tw, &st.big, sI));
             }
+            else if (boundary_split)
+                HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Ypre, pl.ksplit + 1, y_elems, h_first, 1, (int) nout_act, st.timeline, st.tl_len,
+                                                 st.tl_len - 1, st.tw, &st.big, sI));
             else
                 HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 2, (long long) (st.Ypre - st.Y), h_first, 1, (int) nout_act, st.timeline, st.tl_len,
                                                  st.tl_len - 1, st.tw, &st.big, sI));

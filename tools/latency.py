@@ -56,8 +56,9 @@ for k in range(ncalls):
 ts = np.array(ts) * 1e3
 print(f"{w} block={B} paced={int(paced)} defer={os.environ.get('HCV_DEFER','1')}: calls={ncalls} mean={ts.mean():.3f} p50={np.percentile(ts,50):.3f} p99={np.percentile(ts,99):.3f} "
       f"max={ts.max():.3f} ms | budget {1e3*B/fs:.3f} ms | sum={ts.sum():.1f} ms for {1e3*ncalls*B/fs:.1f} ms of audio")
-slow = [(i, round(float(t), 3)) for i, t in enumerate(ts) if t > 0.6]
-print("   calls > 0.6 ms:", slow[:24])
+thr = float(os.environ.get("SLOW_MS", "0.6"))
+slow = [(i, round(float(t), 3)) for i, t in enumerate(ts) if t > thr]
+print(f"   calls > {thr} ms:", slow[:48])
 if set_ms:
     a = ts[after]
     print(f"   live swaps: {len(set_ms)}; set() mean {np.mean(set_ms):.3f} max {np.max(set_ms):.3f} ms; the call after a swap mean {a.mean():.3f} max {a.max():.3f} ms")

@@ -25,4 +25,18 @@ for s, e, k in ph:
 print(f"paced phase: {len(ph)} launches over {ncalls} calls = {len(ph) / ncalls:.1f} per call, {sum(v[1] for v in agg.values()) / ncalls:.1f} us of kernels per call, span {(ph[-1][1] - ph[0][0]) / 1e3 / ncalls:.1f} us per call")
 for k, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"  {n / ncalls:7.2f} per call  {us / n:8.2f} us each  {us / ncalls:8.2f} us per call  {k}")
+# timeline of individual calls: a call's launches end with its emit_kernel
+segs, cur = [], []
+for r in ph:
+    cur.append(r)
+    if "emit_kernel" in r[2]:
+        segs.append(cur); cur = []
+def short(k): return k.split("(")[0].replace("void hcv::", "").replace("(anonymous namespace)::", "")[:60]
+order = sorted(range(len(segs)), key=lambda i: -(segs[i][-1][1] - segs[i][0][0]))
+for idx in order[3:5] + order[len(order) // 2: len(order) // 2 + 1]:
+    sg = segs[idx]
+    t0 = sg[0][0]
+    print(f"call {idx}: {len(sg)} launches, {(sg[-1][1] - t0) / 1e3:.1f} us from its first kernel's start to the end of its emit")
+    for st_, e_, k in sg:
+        print(f"    +{(st_ - t0) / 1e3:8.1f} us  {(e_ - st_) / 1e3:7.1f} us  {short(k)}")
 PY

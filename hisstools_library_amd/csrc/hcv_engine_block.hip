@@ -16,12 +16,13 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
     HCV_BLOCK_LOCALS(blk);
     const hipStream_t sS = serial ? mStream : st.stream;
     if (st.pre_hop < 0 || st.bg_launched >= st.bg_slices) return true;
-    // Slices come due a little AHEAD of the even grid (HCV_BG_LEAD samples, default 64; stages of at least 4096 points): on the grid the
+    // Slices come due a little AHEAD of the even grid (HCV_BG_LEAD samples, default 192; stages of at least 4096 points): on the grid the
     // tail's slice k falls due at sample k M / 16 = a multiple of 512, i.e. in the very call that also carries the hop boundaries of the
     // 256- and 1024-point stages — with 32-sample calls of the 64 x 64 / 10 s engine every sixteenth call took 0.48 ms (a 0.2 ms tail
-    // slice on top of two boundaries) against 0.075 ms for its neighbours.  64 samples early the slice lands in a plain call
-    // (32-sample calls: the 14th of 16; 64-sample calls: the 7th of 8).
-    static const long long lead_env = std::getenv("HCV_BG_LEAD") ? std::atoll(std::getenv("HCV_BG_LEAD")) : 64;
+    // slice on top of two boundaries) against 0.075 ms for its neighbours.  192 samples early the slice lands in a plain call at 32
+    // and 64 samples per call (the 10th of 16, the 5th of 8) and, at 128 samples per call, in the call BEFORE the one with the
+    // 1024-point stage's boundary (p99 0.45 -> 0.28 ms there; 64 samples of lead, enough for the smaller calls, is not).
+    static const long long lead_env = std::getenv("HCV_BG_LEAD") ? std::atoll(std::getenv("HCV_BG_LEAD")) : 192;
     const long long lead = st.M >= 2048 ? std::min<long long>(lead_env, (long long) st.M / (2 * std::max(1, st.bg_slices))) : 0;
     const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M + lead;
     int due = boundary ? st.bg_slices : (int) std::min<long long>(st.bg_slices, std::max<long long>(0, into * st.bg_slices / (long long) st.M));

@@ -376,9 +376,23 @@ def main():
                 digests.append(also_leg(w, local))
         else:
             # N > 1: the further workloads run IN PROCESS on the same ranks and process group, STRONG-scaled — the workload's own
-            # matrix split over the ranks (c4: 64x64 by output rows, no exchange; c3: 8 -> 1 by inputs, one all-reduce per step)
+            # matrix split over the ranks (c4: 64x64 by output rows, no exchange; c3: 8 -> 1 by inputs, one all-reduce per step).
+            # They must never cost the run its headline: should a rank fail or a collective hang, a watchdog on every rank ends the
+            # process after BENCH_ALSO_TIMEOUT seconds (default 300), rank 0 printing the headline line with the error noted.
+            import threading
+
+            def give_up():
+                if rank == 0 and line is not None:
+                    line["config"]["also"] = digests + [{"scaling": "strong", "error": "strong-scaled legs did not finish in time; headline unaffected"}]
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+            dog = threading.Timer(float(os.environ.get("BENCH_ALSO_TIMEOUT", "300")), give_up)
+            dog.daemon = True
+            dog.start()
             for w in also:
                 digests.append(strong_leg(w, args, ctx))
+            dog.cancel()
         if rank == 0 and line is not None:
             line["config"]["also"] = digests
     if rank == 0 and line is not None:
@@ -404,6 +418,8 @@ def strong_leg(workload, args, ctx, steps=40, warmup=5):
         d = bench_line(a, ctx)
     except SystemExit as e:         # e.g. a matrix that cannot be split over this many ranks
         return {"workload": workload, "scaling": "strong", "error": str(e)}
+    except Exception as e:          # (the other ranks may now wait for this one in a collective: the watchdog in main() ends that)
+        return {"workload": workload, "scaling": "strong", "error": f"{type(e).__name__}: {e}"}
     if d is None:
         return None
     out = digest_of(d)

@@ -227,6 +227,24 @@ def test_bench_default_two_ranks_attach_strong_legs():
         assert a["value"] > 0 and a["self_check"]["ok"] and a["self_check"]["max_rel_err"] <= 1e-5, a
 
 
+def test_bare_multi_rank_run_keeps_its_headline_when_a_strong_leg_hangs():
+    """The strong-scaled legs of a bare `bench.py --gpus N` must never cost the run its headline: with the watchdog set to fire at
+    once (BENCH_ALSO_TIMEOUT) rank 0 still prints exactly one JSON line — the weak-scaled headline — with the failure noted."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_BACKEND="gloo", MASTER_PORT=str(port), BENCH_ALSO_TIMEOUT="0.2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batched-block", "0",
+           "--extended-ratio", "0", "--realtime-block", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "error" in d["config"]["also"][-1]
+
+
 def test_random_cases_through_sharded_objects(monkeypatch):
     """The randomised differential test (tests/perf/fuzz_parity.py: random matrices, latencies, call sizes, live IR swaps, clears and
     resets) with HCV_DEVICES set, so that every Convolver it builds is ONE object over two engines."""

@@ -101,7 +101,7 @@ __global__ __launch_bounds__((FourStepTile<(1 << L1), 8>::THREADS)) void big_col
     auto root = [&](int idx)
     {
         float sn, cs;
-        sincospif(-(float) (idx & (2 * M - 1)) / (float) M, &sn, &cs);
+        sincospif(-(float) (idx & (2 * M - 1)) * (1.0f / (float) M), &sn, &cs);       // (M is a power of two: the reciprocal and the product are exact, and a float division is ten instructions)
         return make_float2(cs, sn);
     };
     const int c = (int) threadIdx.x % BIG_COLS, k10 = (int) threadIdx.x / BIG_COLS;

@@ -476,7 +476,7 @@ namespace
     __device__ __forceinline__ float2 fx_twiddle(const float2 *__restrict__, int idx, int M)
     {
         float sn, cs;
-        sincospif(-(float) (idx & (2 * M - 1)) / (float) M, &sn, &cs);      // idx / 2M turns = idx / M half-turns; both powers of two: exact
+        sincospif(-(float) (idx & (2 * M - 1)) * (1.0f / (float) M), &sn, &cs);      // idx / 2M turns = idx / M half-turns; M is a power of two: reciprocal and product exact (a float division is ten instructions)
         return make_float2(cs, sn);
     }
     __device__ __forceinline__ double2 fx_twiddle(const double2 *__restrict__, int idx, int M)

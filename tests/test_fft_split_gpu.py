@@ -93,3 +93,29 @@ def test_fused_multi_hop_block_of_a_4096_point_stage_vs_oracle(block):
     if st1:
         assert st1["hop_tile"] == block // 2048 and st1["ksplit"] == 1, st1         # the fused launch ran the steady state ...
         assert st0["ksplit"] > 1, st0                                                # ... and the separate launches did without it
+
+
+def test_fused_multi_hop_block_with_a_lead_slot_vs_float64_truth():
+    """The same fused multi-hop block on a stage WITH a lead slot: a zero-latency 1 x 1 ladder that ends in a 4096-point stage
+    (MonoConvolve(L, true, 256, 1024, 4096): MonoConvolve.cpp:203-258), called with 8192 samples — whole-hop mode, four hops of the last
+    stage per block, partition 0 = the lead slot reading the block's own spectra.  Checked against a float64 FFT convolution (the
+    reference has a defect for zero-latency ladders of fewer than four sizes, DESIGN section 4 deviation 6), <= 2e-6 of the peak, fused
+    on and off."""
+    code = ("import sys, json, numpy as np, hisstools_library_amd as H\n"
+            "from oracle import oracle as O\n"
+            "from scipy.signal import fftconvolve\n"
+            "B = 8192; L = 50000 + 13; S = 36 * B\n"
+            "h = O.synth_ir(1, 0, L); x = O.synth_audio(5, S)\n"
+            "p = H.Convolver(1, 1, 0, custom=(L, True, 256, 1024, 4096, 0), maxBlock=B); assert p.set(0, 0, h, True) == 0\n"
+            "y = p.run(x[None, :], 1, B)[0]\n"
+            "t = fftconvolve(x.astype(np.float64), h.astype(np.float64))[:S]\n"
+            "st = p.stage_stats()[-1]\n"
+            "print(json.dumps({'err': float(np.abs(y - t).max() / np.abs(t).max()), 'hop_tile': int(st['hop_tile']), 'ksplit': int(st['ksplit']), 'fft': int(st['fft_size'])}))\n")
+    import json
+    for mode in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HCV_COOP_HOPS=mode))
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        assert r["fft"] == 4096 and r["err"] <= 2e-6, r
+        if mode == "1":
+            assert r["hop_tile"] == 4 and r["ksplit"] == 1, r

@@ -576,10 +576,11 @@ __global__ __launch_bounds__(FIR_THREADS) void fir_head_kernel(const float *__re
 // The kernel above gives a workgroup 512 output samples of one output and walks the inputs one after the other — two barriers and
 // L taps of serial work per input: with 32 samples per call 8 of its 128 threads have anything to do and a 64-input row takes
 // 222 us, three quarters of a 32-sample call of the 64 x 64 engine.  Here a workgroup owns 32 samples of one output and its 256
-// threads split the TAPS eight ways (thread = sample n, tap slice ks); the windows and taps of a whole batch of inputs are staged
-// in LDS at once (every global load in flight before the one barrier), each thread runs nin x L / 8 multiply-adds out of LDS
-// (x reads conflict-free, tap reads broadcast), and the eight slices are added up in LDS.  TimeDomainConvolve.cpp:100-163.
-constexpr int FIRS_THREADS = 256, FIRS_SAMPLES = 32, FIRS_SLICES = FIRS_THREADS / FIRS_SAMPLES;
+// threads split the TAPS sixteen ways (thread = sample n, tap slice ks); the windows and taps of a whole batch of inputs — all of them
+// while they fit 96 KiB — are staged in LDS at once (every global load in flight before the one barrier), each thread runs
+// nin x L / 16 multiply-adds out of LDS (x reads conflict-free, tap reads broadcast), and the slices are added up in LDS.
+// TimeDomainConvolve.cpp:100-163.
+constexpr int FIRS_THREADS = 512, FIRS_SAMPLES = 32, FIRS_SLICES = FIRS_THREADS / FIRS_SAMPLES;
 
 template <bool CHECK>
 __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
@@ -965,11 +966,13 @@ hipError_t launch_fir_head(const float *hist, long long hist_stride, long long h
     if (small_on && !diag && B <= 256 && nin >= 1 && Lpad >= 16 && Lpad <= 1024)
     {
         const int per_input = FIRS_SAMPLES + 2 * Lpad;                             // floats of LDS per staged input
-        const int ibmax = std::max(1, (60 * 1024 / 4 - FIRS_THREADS) / per_input);
+        const int ibmax = std::max(1, (96 * 1024 / 4 - FIRS_THREADS) / per_input);
         const int batches = (nin + ibmax - 1) / ibmax;
         const int ib = (nin + batches - 1) / batches;
         const size_t lds = sizeof(float) * ((size_t) ib * per_input + FIRS_THREADS);
         const dim3 grid((B + FIRS_SAMPLES - 1) / FIRS_SAMPLES, nout);
+        hipError_t ea = check ? allow_lds(fir_head_small_kernel<true>, lds) : allow_lds(fir_head_small_kernel<false>, lds);
+        if (ea != hipSuccess) return ea;
         if (check)
             hipLaunchKernelGGL((fir_head_small_kernel<true>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
                                nin_alloc, n0, B, valid_from, out, out_stride, ib);

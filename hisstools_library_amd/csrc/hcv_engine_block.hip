@@ -633,11 +633,15 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
 
     if (td)
     {
-        HCV_TRY(wt(sTd, mEvInput[q]));
+        // small calls: the head reads the call's own samples from the caller's block, so it starts beside the scatter instead of behind
+        // it (one cross-stream hand-over less in the chain scatter -> head -> emit of a plain real-time call) and only needs the ring
+        // complete up to the call's first sample — the previous block's input event
+        const bool head_direct = fir_head_is_small((int) B, (int) nin_act, (int) mTdLpad, mCfg.diag ? 1 : 0) && !direct_in;
+        HCV_TRY(wt(sTd, mEvInput[head_direct ? (q ^ 1) : q]));
         HCV_TRY(wt(sTd, mEvEmit[q]));      // emit(k-2) has consumed tdout[q]
         const bool check = td_check;
         HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
-                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, sTd));
+                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, sTd, head_direct ? din : nullptr, in_stride));
         HCV_TRY(rec(mEvTd[q], sTd));
     }
 

@@ -134,9 +134,12 @@ namespace hcv
     hipError_t launch_timeline_sub(float *row, long long mask, long long base, const float *tmp, int n, float scale, long long t_min, hipStream_t st);
 
     // ---- time-domain head ----
+    // calls of <= 256 samples take fir_head_small_kernel, which can read the call's own samples from the caller's block (din) instead
+    // of the ring: it then needs the ring complete only up to the call's first sample
+    bool fir_head_is_small(int B, int nin, int Lpad, int diag);
     hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                                int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
-                               long long out_stride, hipStream_t st);
+                               long long out_stride, hipStream_t st, const float *din = nullptr, long long in_stride = 0);
 
     // ---- ring bookkeeping ----
     hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,

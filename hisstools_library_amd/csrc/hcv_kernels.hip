@@ -586,7 +586,8 @@ template <bool CHECK>
 __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
                                                                       const float *__restrict__ taps, int Lpad, int tap_stride, int nin, int nin_alloc,
                                                                       long long n0, int B, const long long *__restrict__ valid_from,
-                                                                      float *__restrict__ out, long long out_stride, int ib)
+                                                                      float *__restrict__ out, long long out_stride, int ib,
+                                                                      const float *__restrict__ din, long long in_stride)
 {
     extern __shared__ __attribute__((aligned(16))) float firs_lds[];
     const int W = FIRS_SAMPLES + Lpad;                     // x[nblk - Lpad .. nblk + 32) of one input
@@ -609,7 +610,11 @@ __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const floa
         {
             const int i = e / W, j = e - i * W;
             const long long pos = nabs - Lpad + j;
-            float v = hist[(long long) (i0 + i) * hist_stride + (pos & hist_mask)];
+            // the call's own samples straight from the caller's block (din != nullptr): the kernel then does not wait for the scatter
+            // that files them in the ring, only for the ring's older contents
+            float v;
+            if (din && pos >= n0) v = pos - n0 < B ? din[(long long) (i0 + i) * in_stride + (pos - n0)] : 0.f;
+            else v = hist[(long long) (i0 + i) * hist_stride + (pos & hist_mask)];
             if (CHECK)
             {
                 if (pos < valid_from[(long long) o * nin_alloc + (i0 + i)]) v = 0.f;
@@ -955,15 +960,25 @@ static hipError_t launch_fir_otd(const float *hist, long long hist_stride, long 
     return hipGetLastError();
 }
 
+static bool fir_small_on()
+{
+    static const bool on = !(std::getenv("HCV_FIR_SMALL") && std::atoi(std::getenv("HCV_FIR_SMALL")) == 0);
+    return on;
+}
+
+bool fir_head_is_small(int B, int nin, int Lpad, int diag)
+{
+    return fir_small_on() && !diag && B > 0 && B <= 256 && nin >= 1 && Lpad >= 16 && Lpad <= 1024;
+}
+
 hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                            int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
-                           long long out_stride, hipStream_t st)
+                           long long out_stride, hipStream_t st, const float *din, long long in_stride)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
     // small calls of matrices with several inputs: taps split over the threads, a batch of inputs staged at once (HCV_FIR_SMALL = 0:
     // the general kernel everywhere)
-    static const bool small_on = !(std::getenv("HCV_FIR_SMALL") && std::atoi(std::getenv("HCV_FIR_SMALL")) == 0);
-    if (small_on && !diag && B <= 256 && nin >= 1 && Lpad >= 16 && Lpad <= 1024)
+    if (fir_head_is_small(B, nin, Lpad, diag))
     {
         const int per_input = FIRS_SAMPLES + 2 * Lpad;                             // floats of LDS per staged input
         const int ibmax = std::max(1, (96 * 1024 / 4 - FIRS_THREADS) / per_input);
@@ -975,10 +990,10 @@ hipError_t launch_fir_head(const float *hist, long long hist_stride, long long h
         if (ea != hipSuccess) return ea;
         if (check)
             hipLaunchKernelGGL((fir_head_small_kernel<true>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
-                               nin_alloc, n0, B, valid_from, out, out_stride, ib);
+                               nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride);
         else
             hipLaunchKernelGGL((fir_head_small_kernel<false>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
-                               nin_alloc, n0, B, valid_from, out, out_stride, ib);
+                               nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride);
         return hipGetLastError();
     }
     // widest output tile that still leaves >= 2 workgroups per CU

@@ -312,7 +312,7 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
     HCV_TRY(hipMalloc(&st.tickets, sizeof(unsigned) * (kMacTickets + 2)));
     HCV_TRY(hipMemset(st.tickets, 0, sizeof(unsigned) * (kMacTickets + 2)));
-    HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) kBgSlices * mCfg.nout * st.M));
+    HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) (kBgSlices + kBoundarySlices) * mCfg.nout * st.M));
     HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
     if (is_big_fft(st.log2n))
     {

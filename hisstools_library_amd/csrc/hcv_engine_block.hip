@@ -46,8 +46,7 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
         const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
         float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
         if (!mac(st, sb, pb, st.Ht() + (size_t) (1 + a) * st.M, scratch, hop, bcheck, sS)) return false;
-        HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS));
-        HCV_TRY(hipMemcpyAsync(slot, scratch, sizeof(float2) * slot_elems, hipMemcpyDeviceToDevice, sS));
+        HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS, slot));       // (the sum goes straight into the slot)
         HCV_TRY(hipEventRecord(st.bg_done, sS));
         st.bg_pending = true;
     }
@@ -374,19 +373,19 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             // boundary of a hop whose partitions 1..P-1 were accumulated in the background: whatever slices are still
             // due, their total into slot 0, then partition 0 only
             if (!advance_background(blk, st, true)) return false;
-            HCV_TRY(launch_reduce_partials(st.Ypre, st.bg_slices, (long long) mCfg.nout * st.M, (long long) mCfg.nout * st.M, sM));
             MacShape s0 = sh;
             s0.P = 1;
             // Partition 0 is a reduction over the inputs only — 64 terms on the 64 x 64 engine — and with ONE k-slice every wave walked
             // them all one after the other: 85 us per boundary, for 4 MB of spectra, twice in the call that carries the boundaries of
             // two stages.  Once their total sits in slot 0 the slices' other slots are free, so partition 0 is split up to seven ways
-            // into slots 1 .. and the inverse adds the slots up as it loads them (HCV_BOUNDARY_KSPLIT = 1: one slice, as before).
+            // into the slots BEHIND the slices' (Ypre has kBgSlices + kBoundarySlices of them) and the inverse adds all the slots up as
+            // it loads them — no launch for the slices' total either (HCV_BOUNDARY_KSPLIT = 1: total into slot 0, one slice, as before).
             static const int bks = std::getenv("HCV_BOUNDARY_KSPLIT") ? std::atoi(std::getenv("HCV_BOUNDARY_KSPLIT")) : 7;
             boundary_split = !is_big_fft(st.log2n) && bks > 1 && nout_act == mCfg.nout;
-            s0.max_ksplit = boundary_split ? std::min(bks, kBgSlices - 1) : 1;
+            s0.max_ksplit = boundary_split ? std::min(bks, kBoundarySlices) : 1;
             mac_plan(s0, pl);
-            if (pl.ksplit <= 1) boundary_split = false;
-            if (!mac(st, s0, pl, st.Ht(), boundary_split ? st.Ypre + (size_t) mCfg.nout * st.M : st.Y, h_first, check, sM)) return false;
+            if (!boundary_split) HCV_TRY(launch_reduce_partials(st.Ypre, st.bg_slices, (long long) mCfg.nout * st.M, (long long) mCfg.nout * st.M, sM));
+            if (!mac(st, s0, pl, st.Ht(), boundary_split ? st.Ypre + (size_t) st.bg_slices * mCfg.nout * st.M : st.Y, h_first, check, sM)) return false;
         }
         else
         {
@@ -429,7 +428,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
                                                  st.tw, &st.big, sI));
             }
             else if (boundary_split)
-                HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Ypre, pl.ksplit + 1, y_elems, h_first, 1, (int) nout_act, st.timeline, st.tl_len,
+                HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Ypre, st.bg_slices + pl.ksplit, y_elems, h_first, 1, (int) nout_act, st.timeline, st.tl_len,
                                                  st.tl_len - 1, st.tw, &st.big, sI));
             else
                 HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, 2, (long long) (st.Ypre - st.Y), h_first, 1, (int) nout_act, st.timeline, st.tl_len,

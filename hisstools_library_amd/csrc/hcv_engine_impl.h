@@ -46,6 +46,7 @@ struct DeviceGuard
 };
 
 constexpr int kBgSlices = 16;
+constexpr int kBoundarySlices = 7;       // k-slices of the partition-0 MAC at a deferred hop's boundary, in the slots behind the background slices'
 
 // HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
 // per stage and its pending output is not withdrawn) — for A/B comparison only
@@ -79,7 +80,8 @@ struct Engine::Stage
     // and hop h+1, in up to kBgSlices short launches spread over the calls of that hop in step with the samples that
     // have arrived (a single long launch would sit in a hardware queue that other streams share and stall them for
     // milliseconds); the boundary of hop h+1 then only pays partition 0 + the inverse FFT.
-    float2 *Ypre = nullptr;             // [kBgSlices][nout][M]: one partial sum per slice; slot 0 receives their total
+    float2 *Ypre = nullptr;             // [kBgSlices + kBoundarySlices][nout][M]: one partial sum per background slice, then the boundary's
+                                        // partition-0 slices; the inverse adds them up (HCV_BOUNDARY_KSPLIT = 1: slot 0 receives the total)
     long long pre_hop = -1;             // hop index the slices accumulate for (-1 = no plan)
     int bg_parts = 0;                   // partitions 1..bg_parts of that hop are to be accumulated
     int bg_slices = 0, bg_launched = 0; // planned / already launched slices

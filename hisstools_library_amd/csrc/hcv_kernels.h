@@ -109,7 +109,8 @@ namespace hcv
                                     // up in LDS — ksplit = 1, no partial sums in memory, no reduce_partials launch (small engines)
     };
     void mac_plan(const MacShape &s, MacPlan &pl);
-    hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st);
+    // (dst: where the sum goes; nullptr = slice 0 of Y itself)
+    hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st, float2 *dst = nullptr);
     // tickets (optional): kMacTickets zeroed counters; when the plan allows it (mac_can_fuse_reduce) the launch adds its split-K
     // slices up into slice 0 itself, in reduce_partials' order, and no reduce_partials launch is needed
     constexpr int kMacTickets = 1024;

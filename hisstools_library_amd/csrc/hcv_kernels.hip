@@ -404,7 +404,7 @@ __global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_rows_kernel(
 
 // Split-K epilogue: Y[0][e] = sum_ks Y[ks][e].  One float4 per thread, the ksplit strided loads of a thread are
 // independent (issued back to back), neighbouring threads are contiguous: a plain coalesced streaming reduction.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict__ Y, int ksplit, long long ks_stride4, long long n4, int pin, int fast)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *Y, int ksplit, long long ks_stride4, long long n4, int pin, int fast, float4 *dst)
 {
     int bx = blockIdx.x;
     if (pin >= 0)
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict
             {
                 s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w;
             }
-        Y[e] = s;
+        dst[e] = s;
         return;
     }
     float4 s = Y[e];
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *__restrict
         const float4 a = Y[(long long) ks * ks_stride4 + e];
         s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
-    Y[e] = s;
+    dst[e] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -932,15 +932,17 @@ hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long k
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st)
+hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st, float2 *dst)
 {
-    if (ksplit <= 1 || elems <= 0) return hipSuccess;
+    if (elems <= 0 || ksplit < 1) return hipSuccess;
+    if (!dst) dst = Y;
+    if (ksplit == 1 && dst == Y) return hipSuccess;            // (one slice elsewhere: the launch is the copy)
     const long long n4 = elems / 2;
     const int grid = (int) ((n4 + 255) / 256);
     const int pin = xcd_pin_for(grid);
     static const bool fast = !(std::getenv("HCV_REDUCE_FAST") && std::atoi(std::getenv("HCV_REDUCE_FAST")) == 0);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid * (pin >= 0 ? 8 : 1)), dim3(256), 0, st, reinterpret_cast<float4 *>(Y), ksplit, ks_stride / 2, n4, pin,
-                       (int) fast);
+                       (int) fast, reinterpret_cast<float4 *>(dst));
     return hipGetLastError();
 }
 

@@ -49,14 +49,22 @@ def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
     _scenario(H, oracle, entry)         # (one run, no retry: the lock criteria are structural now, the wall-clock ones generous)
 
 
-def _scenario(H, oracle, entry):
+def test_process_never_waits_for_set_or_regrow_at_32_samples_per_call(H, oracle):
+    """The same contract at the smallest block size hosts use: 32-sample calls (0.67 ms budget), 4200 of them (2.8 s of audio), beside
+    ~800 set(resize) calls.  The structural criteria are the same (lock never found taken, no block given up, one mailbox section per
+    set); of the wall-clock ones p99 stays below 3/4 of the budget (measured 0.36 ms), and the calls that run a swap section with its
+    retiring kernels may exceed 0.67 ms: 1 - 5 of 4200 do (0.7 - 1.1 ms; up to 6 ms when a regrow has the driver map new device
+    memory) — at most 12 are tolerated."""
+    _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200, over_max=12)
+
+
+def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=4):
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
     nin = nout = 16
-    fs, RB = 48000, 128
+    fs = 48000
     steady = [0, 1]                                    # output rows checked against the oracle (their pairs are never replaced)
-    L_fix = 60000
-    ncalls = 1400                                      # 3.7 s of audio
+    L_fix = 60000                                      # (ncalls = 1400 calls of 128 samples: 3.7 s of audio)
     S = ncalls * RB
     xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
     # ("sharded": the same through ONE object driving two engines on the GPU — rows 0..7 on the first, 8..15, the ones being
@@ -116,6 +124,7 @@ def _scenario(H, oracle, entry):
         ys = yd.cpu().numpy()
     rt = c.rt_stats()
     budget = 1e3 * RB / fs
+    print(f"[{entry}] over budget: {int((ts > 1e3 * RB / fs).sum())} of {ncalls} calls, slowest five {np.sort(ts)[-5:].round(3).tolist()}")
     print(f"[{entry}] {sets['n']} set(resize) calls (worst {sets['worst_ms']:.1f} ms each) beside {ncalls} paced calls: p50 {np.percentile(ts, 50):.3f} "
           f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); lock contended {rt['lock_contended']}x, longest wait "
           f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}, sections run by the audio thread {rt['mailbox_runs']}")
@@ -128,7 +137,7 @@ def _scenario(H, oracle, entry):
     # all but a handful of the 1400 calls inside the budget, none that looks like a stall behind an upload or a regrow (tens to
     # hundreds of milliseconds in round 1), p99 well inside it
     over = int((ts > budget).sum())
-    assert over <= 4 and ts.max() < 40.0, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
+    assert over <= over_max and ts.max() < 40.0, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
     assert np.percentile(ts, 99) < 0.75 * budget, f"p99 {np.percentile(ts, 99):.3f} ms"
     assert np.isfinite(ys).all()
     y_ref = ref.run(xs, len(steady), 2048)

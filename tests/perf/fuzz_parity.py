@@ -149,17 +149,18 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
-    t0, seed, n, worst = time.time(), args.seed, 0, 0.0
+    t0, seed, n, worst, worst_at = time.time(), args.seed, 0, 0.0, ""
     while time.time() - t0 < args.seconds:
         kind, desc, e = one_case(seed)
         n += 1
-        worst = max(worst, e)
+        if e > worst:
+            worst, worst_at = e, f"seed {seed} {kind} {desc.strip()}"
         flag = "" if e <= TOL else "   <-- MISMATCH"
         print(f"seed {seed:6d} {kind:11s} {desc:60s} err {e:.2e}{flag}", flush=True)
         if e > TOL:
             sys.exit(1)
         seed += 1
-    print(f"{n} cases, worst relative error {worst:.2e} (tolerance {TOL:.1e})")
+    print(f"{n} cases, worst relative error {worst:.2e} (tolerance {TOL:.1e}) at {worst_at}")
 
 
 if __name__ == "__main__":

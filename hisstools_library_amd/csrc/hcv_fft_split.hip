@@ -770,7 +770,7 @@ struct FusedHopsParams
     const float2 *tw, *tws;
     unsigned *bar;
     long long hist_mask, n0, h; // h = the block's first hop
-    int Rring, P, T, hmac_mod, new_from;   // hmac_mod = (hop that partition 0 of hop h reads) mod Rring; new_from = h - that hop (1 lone, 0 lead)
+    int Rring, P, T, hmac_mod;  // hmac_mod = (hop that partition 0 of hop h reads: h with a lead slot, h - 1 for a lone stage) mod Rring
     unsigned targetA, targetB;
 };
 
@@ -856,7 +856,8 @@ __global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams 
             }
         }
 
-        // ---- partitions p < T, one per wave: hop t's term reads hop hmac + t - p, written by this launch when t - p >= new_from
+        // ---- partitions p < T, one per wave: hop t's term reads hop hmac + t - p, which this launch itself may be writing (t - p >= h - hmac):
+        //      all of them after the hand-over, through agent-scope loads
         grid_wait(a.bar, a.targetA);
         if (ks < T && ks < a.P)
         {
@@ -1008,7 +1009,6 @@ hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, 
     a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
     a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.Rring = Rring; a.P = P; a.T = T;
     a.hmac_mod = (int) (h_mac % Rring);
-    a.new_from = (int) (h - h_mac);
     a.targetA = (arrived[0] += (unsigned) (T * (R / 2 + 1)));
     a.targetB = (arrived[1] += (unsigned) MACW);
     hipLaunchKernelGGL((fused_block_hops_kernel<LOG2N, LOG2R, TMAX>), dim3(MACW + T * (R / 2 + 1)), dim3(1024), lds, st, a);

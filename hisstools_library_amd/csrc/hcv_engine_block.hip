@@ -512,7 +512,16 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
     static const double serial_mb = std::getenv("HCV_SERIAL_MB") ? std::atof(std::getenv("HCV_SERIAL_MB")) : 1024.0;
     const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < serial_mb * 1048576.0;
-    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
+    // Small calls on ONE stream (HCV_SERIAL_SMALL = samples per call up to which, default 0 = off).  The chains of a real-time call — scatter,
+    // head, a stage boundary's transforms / partition-0 MAC / inverse, emit — are a few kernels of 4 - 20 us each, which this stack does not
+    // overlap across streams anyway (tools/small_call_trace.sh), and on one stream they lose the cross-stream hand-overs: 64 x 64 / 10 s at
+    // 32-sample calls p50 0.069 -> 0.059 ms, host enqueue halved.  But the tail's 0.2 ms deferred slices then sit in FRONT of the call that
+    // follows them, and p99 — what a real-time host budgets for — goes the other way (0.247 -> 0.275 ms; 128-sample calls 0.266 -> 0.300;
+    // with 32 slices of half the length 0.20 at 32 samples but 0.34 at 128).  Left off; serial foreground with the slices alone on the stage
+    // streams is the form that would keep both.
+    static const int serial_small = std::getenv("HCV_SERIAL_SMALL") ? std::atoi(std::getenv("HCV_SERIAL_SMALL")) : 0;
+    const bool small_call = !whole_hops && serial_small > 0 && (int) B <= serial_small;
+    const bool serial = mOneStream || small_call || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
     Block blk;
     blk.din = din; blk.dout = dout; blk.in_stride = in_stride; blk.out_stride = out_stride;
     blk.nin_act = nin_act; blk.nout_act = nout_act; blk.rows_in = rows_in; blk.B = B;

@@ -73,6 +73,29 @@ def run_case(op, prec, l2, gib, reps):
             "path": "lds" if (l2 if complex_op else l2 - 1) <= (14 if prec == "f32" else 13) else "four-step"}
 
 
+def vendor_case(prec, l2, gib, reps):
+    """Yardstick only (nothing of the product uses it): the vendor FFT that PyTorch-ROCm binds (rocFFT through torch.fft.fft) on the same
+    box and the same bytes — a batch of complex transforms, interleaved layout, out of place (one read + one write of the operand, as
+    the in-place split transform counts)."""
+    cdt = torch.complex64 if prec == "f32" else torch.complex128
+    per = 2 * (1 << l2) * (4 if prec == "f32" else 8)
+    batch = max(1, int(gib * (1 << 30)) // per)
+    x = torch.view_as_complex(torch.rand((batch, 1 << l2, 2), device="cuda", dtype=torch.float32 if prec == "f32" else torch.float64) * 2 - 1)
+    y = torch.fft.fft(x, dim=1)
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = torch.fft.fft(x, dim=1)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    gbs = 2.0 * batch * per / (best * 1e-3) / 1e9
+    return {"op": "fft", "precision": prec, "log2n": l2, "batch": batch, "ms": round(best, 4), "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 4),
+            "library": "rocFFT via torch.fft.fft (yardstick, interleaved, out of place)", "dtype": str(cdt)}
+
+
 def cpu_case(op, prec, l2, budget=1.5):
     """The compiled reference (oracle/_ref) on one host core: transforms per second for the same operation."""
     from oracle import oracle as O
@@ -106,6 +129,7 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--vendor", action="store_true", help="also time rocFFT (through torch.fft.fft) on the complex rows: a yardstick, never used by the product")
     ap.add_argument("--quick", action="store_true", help="a handful of complex sizes only (kernel tuning)")
     ap.add_argument("--only", default="", help="comma-separated op:precision:log2n rows (e.g. fft:f32:16,rfft:f32:20) instead of the plan")
     args = ap.parse_args()
@@ -124,6 +148,12 @@ def main():
             c = cpu_case(op, prec, l2)
             if c:
                 r["cpu_reference_transforms_per_s_1core"] = round(c, 1)
+        if args.vendor and op == "fft":
+            try:
+                v = vendor_case(prec, l2, args.gib, args.reps)
+                r["vendor_rocfft_GBps"] = v["achieved_GBps"]
+            except Exception as e:          # (a yardstick must not take the measurement down)
+                r["vendor_rocfft_GBps"] = f"error: {e}"
         rows.append(r)
         print(json.dumps(r), flush=True)
     if args.json:

@@ -848,6 +848,16 @@ def bench_line(args, ctx):
                                              f"({timing_note['profiled_ms_per_step']} ms per step there: the event records lengthen a launch-bound "
                                              f"chain), value / ms_per_step from the bare pass")
                 line["roofline"]["profiled_ms_per_step"] = timing_note["profiled_ms_per_step"]
+        if bound == "hbm":
+            try:
+                copy_gbs = box_copy_rate(dev)
+                line["roofline"]["box_copy_GBps"] = round(copy_gbs, 1)
+                line["roofline"]["achieved_over_box_copy"] = round(achieved / copy_gbs, 4)
+                line["roofline"]["box_copy_note"] = ("a 2 GiB device-to-device copy (torch) on this box right after the timed region, read + write bytes over its "
+                                                     "time: the box's own streaming yardstick (MI355X_MICROARCH.md: ~6.3 TB/s achievable).  The multiply-accumulate "
+                                                     "is almost read-only traffic with nontemporal loads and out-runs a copy; `frac` stays achieved / 8 TB/s")
+            except Exception as e:          # (context, never the measurement)
+                line["roofline"]["box_copy_GBps"] = f"error: {e}"
         if roofline_batched is not None:
             line["roofline_batched"] = roofline_batched
         if cpu is not None:
@@ -858,6 +868,28 @@ def bench_line(args, ctx):
             line["cpu_baseline_all_cores"] = cpu_all
         return line
     return None
+
+
+def box_copy_rate(dev, gib=2.0, reps=5):
+    """What THIS box streams when it does nothing else: a device-to-device copy of `gib` GiB (read + write bytes over the best of `reps`
+    timings, HIP events).  Boxes of the pool differ by up to 8 % in what their HBM delivers; the roofline object carries this figure so
+    that `frac` (against the 8 TB/s peak) can be read beside the box's own ceiling.  MI355X_MICROARCH.md quotes ~6.3 TB/s for it."""
+    import torch
+    n = int(gib * (1 << 30)) // 4
+    x = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+    y = torch.empty_like(x)
+    y.copy_(x)
+    torch.cuda.synchronize(dev)
+    best = 1e30
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = min(best, e0.elapsed_time(e1))
+    del x, y
+    return 2.0 * n * 4 / (best * 1e-3) / 1e9
 
 
 def also_leg(workload, device, steps=40, warmup=5, timeout=420):

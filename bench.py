@@ -853,6 +853,12 @@ def bench_line(args, ctx):
                 copy_gbs = box_copy_rate(dev)
                 line["roofline"]["box_copy_GBps"] = round(copy_gbs, 1)
                 line["roofline"]["achieved_over_box_copy"] = round(achieved / copy_gbs, 4)
+                import ctypes
+                rd = ctypes.c_double(0.0)
+                if H.load().hcv_box_read_rate(local, 4 << 30, 5, ctypes.byref(rd)) == 0 and rd.value > 0:
+                    # (a read-only stream with the kernel's own kind of loads: the ceiling this box has for the multiply-accumulate)
+                    line["roofline"]["box_read_GBps"] = round(rd.value, 1)
+                    line["roofline"]["achieved_over_box_read"] = round(achieved / rd.value, 4)
                 line["roofline"]["box_copy_note"] = ("a 2 GiB device-to-device copy (torch) on this box right after the timed region, read + write bytes over its "
                                                      "time: the box's own streaming yardstick (MI355X_MICROARCH.md: ~6.3 TB/s achievable).  The multiply-accumulate "
                                                      "is almost read-only traffic with nontemporal loads and out-runs a copy; `frac` stays achieved / 8 TB/s")

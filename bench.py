@@ -437,7 +437,8 @@ def digest_of(d):
         "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "n_gpus": d["n_gpus"], "steps": d["steps"], "warmup": d["warmup"],
         "ms_per_step": d["ms_per_step"], "realtime_factor": d["config"].get("realtime_factor"),
         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
-                                            "launches", "steady_launches", "traffic", "traffic_source", "profiled_ms_per_step")},
+                                            "launches", "steady_launches", "traffic", "traffic_source", "profiled_ms_per_step", "box_read_GBps",
+                                            "achieved_over_box_read", "box_copy_GBps") if k in rf},
         "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches", "error") if k in sc},
         "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
     }

@@ -459,9 +459,6 @@ namespace
 
     // -------------------------------------------------------------------------------------------- four-step passes
 
-#ifndef HCV_FX_TW_TABLE
-#define HCV_FX_TW_TABLE 1       // column pass: step factors of a thread's twiddles from a small roots table instead of sincospi (fx_cols_kernel)
-#endif
     template <int P, int ELEM_BYTES> using FxTile = FourStepTile<P, ELEM_BYTES>;
 
     template <class C>
@@ -506,8 +503,7 @@ namespace
     // M = M1 * M2, n = M2*n1 + n2, k = k1 + M1*k2.   cols: for every n2 an M1-point transform over n1, times W_M^(n2 k1)
     template <class T, int L1>
     __global__ __launch_bounds__((FxTile<(1 << L1), (int) sizeof(typename Cx<T>::type)>::THREADS)) void fx_cols_kernel(FxK<T> a0, typename Cx<T>::type *__restrict__ work, int M2, int M, long long q0,
-                                                          const typename Cx<T>::type *__restrict__ tw1, const typename Cx<T>::type *__restrict__ twN,
-                                                          const typename Cx<T>::type *__restrict__ twA)
+                                                          const typename Cx<T>::type *__restrict__ tw1, const typename Cx<T>::type *__restrict__ twN)
     {
         typedef typename Cx<T>::type C;
         constexpr int M1 = 1 << L1;
@@ -558,26 +554,6 @@ namespace
             const int c = ((int) threadIdx.x % (COLS / CV)) * CV, k10 = (int) threadIdx.x / (COLS / CV);
             const int n2 = col0 + c;
             C w[CV][NI];
-#if HCV_FX_TW_TABLE
-            // Round 3: one sincospi per thread instead of CV (1 + log2 NI) = 8 (a third of this pass's vector instructions).  The
-            // step factors S^bit = W_M^((n2 + j) DK bit) are roots of unity of order NA = M / DK: entry (bit (n2 + j)) mod NA of the
-            // NA-th roots table twA (8192 entries at 2^20 points: L2-resident, neighbouring lanes on neighbouring entries), each the
-            // correctly rounded value; and the second column's first twiddle is the first column's times W_M^k10 (table twN).
-            const int NA = M / DK;
-#pragma unroll
-            for (int j = 0; j < CV; j++)
-            {
-                if (j == 0) w[0][0] = fx_twiddle(twN, 2 * n2 * k10, M);
-                else w[j][0] = cmul(w[0][0], fx_root_rt(twN, 2 * j * k10, M));
-#pragma unroll
-                for (int bit = 1; bit < NI; bit *= 2)
-                {
-                    const C sb = fx_root_rt(twA, (bit * (n2 + j)) & (NA - 1), NA / 2);
-#pragma unroll
-                    for (int i = 0; i < bit; i++) w[j][bit + i] = cmul(w[j][i], sb);
-                }
-            }
-#else
 #pragma unroll
             for (int j = 0; j < CV; j++)
             {
@@ -591,7 +567,6 @@ namespace
                     for (int i = 0; i < bit; i++) w[j][bit + i] = cmul(w[j][i], sb);
                 }
             }
-#endif
 #pragma unroll
             for (int i = 0; i < NI; i++)
             {
@@ -859,22 +834,15 @@ namespace
         }
     }
 
-    template <class T, int L1> hipError_t launch_cols(int device, int lm, const FxK<T> &k, typename Cx<T>::type *work, int M2, int M, long long q0, int nb,
-                                                      const typename Cx<T>::type *tw1, const typename Cx<T>::type *twN, hipStream_t st, std::string *err)
+    template <class T, int L1> hipError_t launch_cols(const FxK<T> &k, typename Cx<T>::type *work, int M2, int M, long long q0, int nb,
+                                                      const typename Cx<T>::type *tw1, const typename Cx<T>::type *twN, hipStream_t st)
     {
         typedef typename Cx<T>::type C;
         typedef FxTile<(1 << L1), (int) sizeof(C)> Tile;
         const size_t lds = sizeof(C) * Tile::TILE * (size_t) fourstep_pitch(1 << L1);
         hipError_t e = allow_big_lds(fx_cols_kernel<T, L1>, lds);
         if (e != hipSuccess) return e;
-        // the step factors of the column pass's twiddles: roots of unity of order M / DK (fx_cols_kernel), DK = rows a thread's elements are apart
-        constexpr int CV = 16 / (int) sizeof(C) > 0 ? 16 / (int) sizeof(C) : 1;
-        constexpr int DK = Tile::THREADS / (Tile::TILE / CV > 0 ? Tile::TILE / CV : 1);
-        int ldk = 0;
-        while ((1 << ldk) < DK) ldk++;
-        const C *twA = fx_twiddles<T>(device, std::max(1, lm - ldk), err);
-        if (!twA) return hipErrorOutOfMemory;
-        hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / Tile::TILE, nb), dim3(Tile::THREADS), lds, st, k, work, M2, M, q0, tw1, twN, twA);
+        hipLaunchKernelGGL((fx_cols_kernel<T, L1>), dim3(M2 / Tile::TILE, nb), dim3(Tile::THREADS), lds, st, k, work, M2, M, q0, tw1, twN);
         return hipGetLastError();
     }
 
@@ -911,7 +879,7 @@ namespace
             const int nb = (int) std::min<long long>(chunk, k.batch - q0);
             switch (l1)
             {
-#define FX_CASE(L) case L: e = launch_cols<T, L>(device, lm, k, work, M2, M, q0, nb, tw1, twN, st, err); break;
+#define FX_CASE(L) case L: e = launch_cols<T, L>(k, work, M2, M, q0, nb, tw1, twN, st); break;
                 FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)
 #undef FX_CASE
                 default: e = hipErrorInvalidValue;

@@ -377,9 +377,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             s0.P = 1;
             // Partition 0 is a reduction over the inputs only — 64 terms on the 64 x 64 engine — and with ONE k-slice every wave walked
             // them all one after the other: 85 us per boundary, for 4 MB of spectra, twice in the call that carries the boundaries of
-            // two stages.  Once their total sits in slot 0 the slices' other slots are free, so partition 0 is split up to seven ways
-            // into the slots BEHIND the slices' (Ypre has kBgSlices + kBoundarySlices of them) and the inverse adds all the slots up as
-            // it loads them — no launch for the slices' total either (HCV_BOUNDARY_KSPLIT = 1: total into slot 0, one slice, as before).
+            // two stages.  Partition 0 is therefore split up to seven ways, its k-slices going into the slots BEHIND the background
+            // slices' (Ypre has kBgSlices + kBoundarySlices of them), and the inverse adds all the slots up as it loads them — no launch
+            // for the slices' total either (HCV_BOUNDARY_KSPLIT = 1: total into slot 0 and ONE slice into Y, as before round 3).
             static const int bks = std::getenv("HCV_BOUNDARY_KSPLIT") ? std::atoi(std::getenv("HCV_BOUNDARY_KSPLIT")) : 7;
             boundary_split = !is_big_fft(st.log2n) && bks > 1 && nout_act == mCfg.nout;
             s0.max_ksplit = boundary_split ? std::min(bks, kBoundarySlices) : 1;

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(FIR_THREADS) void fir_head_kernel(const float *__re
 // The same sum for SMALL calls of a matrix with many inputs (the real-time sizes: 32 .. 256 samples per call, 64 x 64 channels).
 // The kernel above gives a workgroup 512 output samples of one output and walks the inputs one after the other — two barriers and
 // L taps of serial work per input: with 32 samples per call 8 of its 128 threads have anything to do and a 64-input row takes
-// 222 us, three quarters of a 32-sample call of the 64 x 64 engine.  Here a workgroup owns 32 samples of one output and its 256
+// 222 us, three quarters of a 32-sample call of the 64 x 64 engine.  Here a workgroup owns 32 samples of one output and its 512
 // threads split the TAPS sixteen ways (thread = sample n, tap slice ks); the windows and taps of a whole batch of inputs — all of them
 // while they fit 96 KiB — are staged in LDS at once (every global load in flight before the one barrier), each thread runs
 // nin x L / 16 multiply-adds out of LDS (x reads conflict-free, tap reads broadcast), and the slices are added up in LDS.

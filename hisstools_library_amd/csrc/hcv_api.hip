@@ -1442,6 +1442,7 @@ extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_
     out->mac_steady_launches = s.mac_steady_launches;
     out->hop_tile = s.hop_tile;
     out->launch_partitions = s.launch_partitions;
+    out->fused_launches = s.fused_launches;
     return 0;
 }
 

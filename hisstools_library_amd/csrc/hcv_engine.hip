@@ -105,6 +105,10 @@ Engine *Engine::create(const EngineCfg &cfg, std::string *err)
 bool Engine::init(const EngineCfg &cfg)
 {
     mCfg = cfg;
+    {
+        static std::atomic<unsigned> engines { 0 };
+        mPinXcd = (int) (engines.fetch_add(1, std::memory_order_relaxed) & 7u);
+    }
     if (mCfg.nin < 1) mCfg.nin = 1;
     if (mCfg.nout < 1)
     {
@@ -312,6 +316,11 @@ bool Engine::alloc_stage(Stage &st)
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
     HCV_TRY(hipMalloc(&st.tickets, sizeof(unsigned) * (kMacTickets + 2)));
     HCV_TRY(hipMemset(st.tickets, 0, sizeof(unsigned) * (kMacTickets + 2)));
+    if (mCfg.nout == 1 && (st.log2n == 14 || st.log2n == 12))
+    {
+        HCV_TRY(hipMalloc(&st.coop_flags, sizeof(unsigned long long) * (kFusedMacTasks + kFusedFwdTasks)));
+        HCV_TRY(hipMemset(st.coop_flags, 0, sizeof(unsigned long long) * (kFusedMacTasks + kFusedFwdTasks)));
+    }
     HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) (kBgSlices + kBoundarySlices) * mCfg.nout * st.M));
     HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
     if (is_big_fft(st.log2n))
@@ -368,6 +377,7 @@ void Engine::free_stage(Stage &st)
     }
     if (st.hv) (void) hipFree(st.hv);
     if (st.tickets) (void) hipFree(st.tickets);
+    if (st.coop_flags) (void) hipFree(st.coop_flags);
     if (st.gh_start) (void) hipFree(st.gh_start);
     if (st.gh_ent) (void) hipFree(st.gh_ent);
     st.gh_start = nullptr;
@@ -970,6 +980,7 @@ bool Engine::stage_stats(size_t s, StageStats *out)
     out->mac_steady_launches = st.steady_launches;
     out->hop_tile = st.last_tt;
     out->launch_partitions = st.last_parts;
+    out->fused_launches = st.fused_launches;
     return true;
 }
 
@@ -978,7 +989,7 @@ void Engine::clear_stats()
     std::lock_guard<std::mutex> g(mMutex);
     for (Stage *st : mStages)
     {
-        st->launches = st->hops = st->steady_launches = 0;
+        st->launches = st->hops = st->steady_launches = st->fused_launches = 0;
         st->ms = 0.0;
     }
 }

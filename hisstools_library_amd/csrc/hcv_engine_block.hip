@@ -148,7 +148,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     const bool fuse_one = T == 1 && fused_block_1x1_applies(st.log2n);
     const bool fuse_hops = T > 1 && rows_in == 1 && fused_block_hops_applies(st.log2n, T);       // (several hops of a short stage: config 2)
     if (tail_head_here && direct_in && blk.direct_out && !blk.pipe2 && serial && rows_in >= 1 && nout_act == 1 && !mCfg.diag && !mProfiling &&
-        !st.gh_count && (fuse_one || fuse_hops))
+        !st.gh_count && !st.coop_off && st.coop_flags && (fuse_one || fuse_hops))
     {
         const int Pw = (int) (st.P + st.lead);
         const long long h_mac = h_first - (long long) (1 - st.lead);
@@ -156,27 +156,34 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
         if (!wcheck && p_live >= 1 && (long long) rows_in * p_live <= 2048 && (!fuse_hops || (p_live == Pw && st.y_elems >= (size_t) T * st.M)))
         {
+            hipError_t fe;
             if (fuse_hops)
-                HCV_TRY(launch_fused_block_hops(st.log2n, mHist, hmask, blk.din, n0, h_first, T, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
-                                                st.tickets + kMacTickets, st.coop_arrived, sS));
+                fe = launch_fused_block_hops(st.log2n, mHist, hmask, blk.din, n0, h_first, T, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
+                                             st.tickets + kMacTickets, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
             else if (rows_in == 1 && p_live <= 16)
-                HCV_TRY(launch_fused_block_1x1(st.log2n, mHist, hmask, blk.din, n0, h_first, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
-                                               st.tickets + kMacTickets, st.coop_arrived, sS));
+                fe = launch_fused_block_1x1(st.log2n, mHist, hmask, blk.din, n0, h_first, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
+                                            st.tickets + kMacTickets, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
             else
-                HCV_TRY(launch_fused_block_nx1(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, st.X, (int) st.R, st.Hs,
-                                               (long long) st.hstride(), (int) p_live, h_mac, st.Y, blk.dout, st.tw, st.tickets + kMacTickets, st.coop_arrived, sS));
-            st.launches++;
-            st.hops += (uint64_t) T;
-            st.last_ksplit = 1;
-            st.last_ot = 1;
-            st.last_tt = (uint32_t) T;
-            st.last_parts = (uint32_t) p_live;
-            HCV_TRY(rec(mEvInput[q], sS));
-            HCV_TRY(rec(mEvEmit[q], sS));
-            HCV_TRY(rec(st.done[q], sS));
-            HCV_TRY(wt(mStream, st.done[q]));
-            st.pre_hop = -1;
-            return true;
+                fe = launch_fused_block_nx1(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, st.X, (int) st.R, st.Hs,
+                                            (long long) st.hstride(), (int) p_live, h_mac, st.Y, blk.dout, st.tw, st.tickets + kMacTickets, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
+            if (fe == hipSuccess)
+            {
+                st.launches++;
+                st.hops += (uint64_t) T;
+                st.last_ksplit = 1;
+                st.last_ot = 1;
+                st.last_tt = (uint32_t) T;
+                st.last_parts = (uint32_t) p_live;
+                st.fused_launches++;
+                HCV_TRY(rec(mEvInput[q], sS));
+                HCV_TRY(rec(mEvEmit[q], sS));
+                HCV_TRY(rec(st.done[q], sS));
+                HCV_TRY(wt(mStream, st.done[q]));
+                st.pre_hop = -1;
+                return true;
+            }
+            // refused (nothing ran, the counters stand where they stood): the separate kernels, from now on
+            st.coop_off = true;
         }
     }
 
@@ -646,6 +653,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         // complete up to the call's first sample — the previous block's input event
         const bool head_direct = fir_head_is_small((int) B, (int) nin_act, (int) mTdLpad, mCfg.diag ? 1 : 0) && !direct_in;
         HCV_TRY(wt(sTd, mEvInput[head_direct ? (q ^ 1) : q]));
+        // (the previous block's input event is older than this call's control work — new taps, reset fences, an upload of the
+        // block itself, a foreign `after` event — which this block's own input event would have put in front of the head)
+        if (head_direct && ctl_was_dirty && sTd != mStream) HCV_TRY(wt(sTd, mEvCtl));
         HCV_TRY(wt(sTd, mEvEmit[q]));      // emit(k-2) has consumed tdout[q]
         const bool check = td_check;
         HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
@@ -690,7 +700,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // L2 instead of fetching it from the memory side (c1: 0.0182 -> 0.0169 ms per block; c2, 3.85 MB of spectra, loses 10 %)
     const bool pin_block = serial && whole_hops && !mStages.empty() &&
                            (double) (mStages[last]->live_parts + (uint64_t) rows_in * mStages[last]->R) * mStages[last]->M * sizeof(float2) <= 1.5 * 1048576.0;
-    xcd_pin_hint(pin_block);
+    xcd_pin_hint(pin_block, mPinXcd);
     // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
     for (size_t sj = 0; sj < mStages.size(); sj++)
         if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj))

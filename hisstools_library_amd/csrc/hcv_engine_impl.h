@@ -100,8 +100,11 @@ struct Engine::Stage
     long long *hv = nullptr;
     long long max_hv = 0;
     unsigned *tickets = nullptr;        // kMacTickets arrival counters of the fused split-K epilogue (zero between launches) + the two
-                                        // monotonic hand-over counters of the fused 1 x 1 block
+                                        // monotonic hand-over counters of the fused blocks
+    unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
+    unsigned long long coop_seq = 0;        // fused blocks launched so far
+    bool coop_off = false;              // a fused launch was refused by the runtime: this stage takes the separate kernels from then on
     // exact per-pair restart: device table of the live ghost entries of this stage, grouped by output
     int *gh_start = nullptr;            // [nout + 1]
     GhostEntry *gh_ent = nullptr;       // [pairs]
@@ -116,7 +119,7 @@ struct Engine::Stage
     uint64_t launches = 0, hops = 0;
     double ms = 0.0;
     uint32_t last_ksplit = 0, last_ot = 0, last_tt = 0, last_parts = 0;
-    uint64_t steady_launches = 0;
+    uint64_t steady_launches = 0, fused_launches = 0;
 };
 
 struct Engine::GhostEvent

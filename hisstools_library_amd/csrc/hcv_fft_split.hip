@@ -409,12 +409,35 @@ __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__r
 // ------------------------------------------------------------------------------------------------ the fused 1 x 1 block
 //
 // One whole-hop block of a 1 x 1 engine — forward transform, multiply-accumulate over the P live partitions, inverse transform,
-// PartitionedConvolve::process for one hop (PartitionedConvolve.cpp:243-385) — as ONE launch of R + R/2 + 1 workgroups with
-// in-launch hand-overs in place of two kernel boundaries.  What crosses workgroups inside the launch (X[h], then Y) is written
-// and read with agent-scope 8-byte atomics; every thread drains its stores before its workgroup is counted in, and the consumers
-// poll the counter from one lane with relaxed agent loads (`bar[k]` counts arrivals over all launches and the host keeps
-// the running totals: no reset).  The consumers must not be scheduled WITHOUT the producers (they spin): 25 workgroups of 256 CUs, and the
-// producers' workgroups never wait for anything.
+// PartitionedConvolve::process for one hop (PartitionedConvolve.cpp:243-385) — as ONE launch with in-launch hand-overs in place of
+// two kernel boundaries.  What crosses workgroups inside the launch (X[h], then Y) is written and read with agent-scope 8-byte
+// atomics; every thread drains its stores before its workgroup is counted in, and the consumers poll the counter from one lane
+// with relaxed agent loads (`bar[k]` counts arrivals over all launches and the host keeps the running totals: no reset).
+//
+// Forward progress BY CONSTRUCTION: no workgroup ever waits without bound.  A workgroup that spins on a counter holds its CU, so a
+// consumer placed while one of its producers is not yet resident could keep that producer off the chip for good (other engines'
+// launches, a CU mask or a 32-CU partition take the rest; the dispatcher's block order is per XCD and promises nothing across
+// them).  Two things keep that from ever mattering:
+//   * producers have the LOW block indices (forward transforms, then multiply-accumulate, whose first workgroups go on to the
+//     inverse), so in the ordinary case everything a workgroup waits for was dispatched before it;
+//   * every wait is BOUNDED (`spin` polls, ~1 us each), and a workgroup whose wait runs out does the missing work ITSELF: every
+//     task of the launch (residue class r of a forward transform, a multiply-accumulate bin range) is a pure function of data
+//     that is complete before the launch, or of tasks it can in turn complete itself, and writes the same values whoever runs
+//     it and however often — so a waiter walks the unfinished tasks (a per-task flag holds the sequence number of the launch that
+//     last completed it), runs them, and goes on.  Nobody then depends on a workgroup that is not running: the launch
+//     completes on one CU as on 256, under any mask, beside any number of other engines (work stealing, in effect — a consumer
+//     that got onto the chip early does the producers' work instead of idling).  The task's own workgroup, placed late, repeats
+//     it (same values) and is the only one counted in `bar`, so the counters' running totals stay exact.
+// HCV_COOP_SPIN = polls before helping (default 64; 0 = help at once: the tests run the whole parity suite that way).
+struct FusedSync
+{
+    unsigned *bar;                       // [2] arrival counters: forward transforms, multiply-accumulate
+    unsigned long long *flagF, *flagM;   // per task: sequence number of the launch that last completed it
+    unsigned long long seq;              // this launch
+    unsigned targetA, targetB;           // what the two counters read when this launch's producers have all arrived
+    int spin;
+};
+
 struct FusedBlockParams
 {
     float *hist;
@@ -424,60 +447,159 @@ struct FusedBlockParams
     const float2 *H;            // [P][M] the pair's partition spectra (lead slot first where the stage has one)
     float2 *Y;                  // [M] scratch
     const float2 *tw, *tws;
-    unsigned *bar;              // [2] arrival counters
+    FusedSync sy;
     long long hist_mask, n0, h;
     int Rring, P, hmac_mod;     // hmac_mod = (hop the MAC's partition 0 reads) mod Rring
-    unsigned targetA, targetB;  // what the two counters read when this launch's producers have all arrived
     int pin;
 };
 
-// arrive: every thread's agent-scope stores have been written through, then one lane counts the workgroup in
-__device__ __forceinline__ void grid_arrive(unsigned *counter)
+// (every helper takes the thread index from its caller: a workitem-id read inside the out-of-line slow path would make the kernel
+// keep the packed ids alive in a register of their own up to the call — one register too many for the 128 of the multi-hop kernel)
+// thread 0's value, to every thread of the workgroup
+__device__ __forceinline__ int wg_broadcast(int tid, int v, int *slot)
+{
+    __syncthreads();
+    if (tid == 0) *slot = v;
+    __syncthreads();
+    return *slot;
+}
+// publish a finished task: every thread's agent-scope stores have been written through, then one lane sets the task's flag and
+// — the task's own workgroup only (counter != nullptr) — counts the workgroup in
+__device__ __forceinline__ void grid_publish(int tid, unsigned long long *flag, unsigned long long seq, unsigned *counter)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void grid_wait(unsigned *counter, unsigned target)
-{
-    if (threadIdx.x == 0)
-        while ((int) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
-    __syncthreads();
-}
-
-// Workgroups 0 .. R-1: multiply-accumulate (512 bins each), then 0 .. R/2-1 the inverse; workgroups R .. R + R/2: the forward
-// transform's residue classes.  A lone stage (`lone`: its partitions read X[h-1] and older, PartitionedConvolve's one hop of
-// latency) needs no hand-over from the forward transform at all — it runs BESIDE the multiply-accumulate and the inverse instead
-// of in front of them; a lead-slot stage (partition 0 reads X[h]) makes the multiply-accumulate wait for the nine residue classes.
-template <int LOG2N, int LOG2R>
-__global__ __launch_bounds__(256) void fused_block_1x1_kernel(FusedBlockParams a)
-{
-    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, S = N >> LOG2R;
-    static_assert(M / 2 == R * 256, "one float4 (two bins) per thread in the multiply-accumulate phase");
-    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
-    const int tid = threadIdx.x;
-    int w = blockIdx.x;
-    if (a.pin >= 0)
+    if (tid == 0)
     {
-        if ((w & 7) != a.pin) return;
-        w >>= 3;
+        __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (counter) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int slot = (int) (a.h % a.Rring);
-    const bool lone = a.hmac_mod != slot;
-
-    if (w >= R)
+}
+// bounded wait: true when the counter reached `target` within `spin` polls.  FRESH: `slot` has not been read since the
+// workgroup's last barrier (the ordinary path gives each of its two waits a slot of its own), which saves the barrier in front
+template <bool FRESH = false> __device__ __forceinline__ bool grid_wait_bounded(int tid, unsigned *counter, unsigned target, int spin, int *slot)
+{
+    int ok = 0;
+    if (tid == 0)
+        for (int k = 0; k < spin; k++)
+        {
+            ok = (int) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    if constexpr (FRESH)
     {
-        // ---- the new frame's spectrum X[h]
-        rfft_split_body<LOG2N, LOG2R, true, true>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, w - R, a.hist, a.in, (a.h - 1) * (long long) M, a.n0,
-                                                  a.hist_mask, a.X + (long long) slot * M, a.tw, a.tws);
-        grid_arrive(a.bar);
+        if (tid == 0) *slot = ok;
+        __syncthreads();
+        return *slot != 0;
+    }
+    else
+        return wg_broadcast(tid, ok, slot) != 0;
+}
+__device__ __forceinline__ bool task_done(int tid, const unsigned long long *flag, unsigned long long seq, int *slot)
+{
+    int d = 0;
+    if (tid == 0) d = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq;
+    return wg_broadcast(tid, d, slot) != 0;
+}
+
+// What a multiply-accumulate workgroup does once one of its waits has run out (`from_mac_wait`: the second one).  Kept OUT OF
+// LINE and entered as the last thing the kernel does, so that the ordinary path — straight-line code, the bodies inlined once —
+// pays nothing for it: no registers held across it, no scratch, no extra copies of the transforms in its instruction stream (a
+// helping loop around the inlined bodies was measured against exactly that: hoisted loop invariants took the 1 x 1 kernel from
+// 98 to 222 registers and put the other two into scratch).  `Bodies` provides forward(task), mac_old(m) — the part of
+// multiply-accumulate task m that needs nothing of this launch —, mac_new(m) — the rest, the reduction and the store of Y — and
+// inverse(j).  Helpers start at different tasks and skip what has been completed meanwhile: they share the work instead of
+// repeating it.
+template <class Bodies>
+__device__ __forceinline__ void fused_slow_path(Bodies &b, const FusedSync &sy, int m, int nfwd, int nmac, int ninv, bool from_mac_wait, int *slot)
+{
+    if (!from_mac_wait)
+    {
+        // the forward tasks nobody has completed, then this workgroup's own multiply-accumulate from the start (nothing was kept)
+        const int first = (int) ((long long) m * nfwd / nmac);
+        for (int k = 0; k < nfwd; k++)
+        {
+            int task = first + k;
+            if (task >= nfwd) task -= nfwd;
+            if (task_done(b.tid, sy.flagF + task, sy.seq, slot)) continue;
+            b.forward(task);
+            grid_publish(b.tid, sy.flagF + task, sy.seq, nullptr);
+        }
+        b.mac_old(m);
+        b.mac_new(m);
+        grid_publish(b.tid, sy.flagM + m, sy.seq, sy.bar + 1);
+        if (m >= ninv) return;
+        if (grid_wait_bounded(b.tid, sy.bar + 1, sy.targetB, sy.spin, slot))
+        {
+            b.inverse(m);
+            return;
+        }
+    }
+    // the multiply-accumulate tasks nobody has completed (the forward transforms are known to be in), then the inverse
+    const int first = m * (nmac / ninv) + 1;
+    for (int k = 0; k < nmac; k++)
+    {
+        int task = first + k;
+        if (task >= nmac) task -= nmac;
+        if (task_done(b.tid, sy.flagM + task, sy.seq, slot)) continue;
+        b.mac_old(task);
+        b.mac_new(task);
+        grid_publish(b.tid, sy.flagM + task, sy.seq, nullptr);
+    }
+    b.inverse(m);
+}
+
+// The ordinary path of one workgroup of a fused launch: workgroup w < nfwd runs forward task w; workgroup nfwd + m runs
+// multiply-accumulate task m and, for m < ninv, the inverse.  `Slow` = the kernel's out-of-line entry to fused_slow_path.
+template <class Bodies, class Slow>
+__device__ __forceinline__ void fused_roles(Bodies &b, const FusedSync &sy, int w, int nfwd, int ninv, bool mac_needs_fwd, int *slot, const Slow &slow)
+{
+    if (w < nfwd)
+    {
+        b.forward(w);
+        grid_publish(b.tid, sy.flagF + w, sy.seq, sy.bar);
         return;
     }
-
-    // ---- Y[b] = sum_p X[hmac - p][b] H[p][b] for this workgroup's 512 bins; bin 0 = (DC, Nyquist): two real products
-    if (!lone) grid_wait(a.bar, a.targetA);
+    const int m = w - nfwd;
+    b.mac_old(m);
+    if (mac_needs_fwd && !grid_wait_bounded<true>(b.tid, sy.bar, sy.targetA, sy.spin, slot))
     {
-        const int b4 = w * 256 + tid;
+        slow(m, false);
+        return;
+    }
+    b.mac_new(m);
+    grid_publish(b.tid, sy.flagM + m, sy.seq, sy.bar + 1);
+    if (m >= ninv) return;
+    if (!grid_wait_bounded<true>(b.tid, sy.bar + 1, sy.targetB, sy.spin, slot + 1))
+    {
+        slow(m, true);
+        return;
+    }
+    b.inverse(m);
+}
+
+// Workgroups 0 .. R/2: the forward transform's residue classes; the next R: multiply-accumulate (512 bins each), of which the
+// first R/2 go on to the inverse.  A lone stage (`lone`: its partitions read X[h-1] and older, PartitionedConvolve's one hop of
+// latency) needs no hand-over from the forward transform at all — it runs BESIDE the multiply-accumulate and the inverse instead
+// of in front of them; a lead-slot stage (partition 0 reads X[h]) makes the multiply-accumulate wait for the nine residue classes.
+template <int LOG2N, int LOG2R> struct Fused1x1Bodies
+{
+    static constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, S = N >> LOG2R;
+    const FusedBlockParams &a;
+    float2 *dyn;
+    int tid, slot;
+
+    __device__ __forceinline__ void forward(int r) const      // residue class r of the new frame's spectrum X[h]
+    {
+        rfft_split_body<LOG2N, LOG2R, true, true>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, r, a.hist, a.in, (a.h - 1) * (long long) M, a.n0,
+                                                  a.hist_mask, a.X + (long long) slot * M, a.tw, a.tws);
+    }
+    __device__ __forceinline__ void mac_old(int) const {}
+    // Y[b] = sum_p X[hmac - p][b] H[p][b] for the 512 bins of range m; bin 0 = (DC, Nyquist): two real products
+    __device__ __forceinline__ void mac_new(int m) const
+    {
+        const int b4 = m * 256 + tid;
         const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float ny = 0.f;
@@ -521,12 +643,35 @@ __global__ __launch_bounds__(256) void fused_block_1x1_kernel(FusedBlockParams a
         put2<true>(y, make_float2(acc.x, acc.y));
         put2<true>(y + 1, make_float2(acc.z, acc.w));
     }
-    grid_arrive(a.bar + 1);
-    if (w >= R / 2) return;
+    __device__ __forceinline__ void inverse(int j) const { rifft_split_body<LOG2N, LOG2R, true>(dyn, tid, j, a.Y, 1, 0, a.out - M, a.tw, a.tws); }      // the hop's samples
+};
 
-    // ---- the hop's samples
-    grid_wait(a.bar + 1, a.targetB);
-    rifft_split_body<LOG2N, LOG2R, true>(dyn, tid, w, a.Y, 1, 0, a.out - M, a.tw, a.tws);
+// (`ka` = the launch's parameters in the kernel-argument segment: a reference to the kernel's own by-value copy would force that copy into scratch)
+template <int LOG2N, int LOG2R> __device__ __noinline__ void fused_1x1_slow(const FusedBlockParams *ka, float2 *dyn, int tid, int m, bool from_mac_wait, int *slot_b)
+{
+    constexpr int R = 1 << LOG2R;
+    Fused1x1Bodies<LOG2N, LOG2R> b = { *ka, dyn, tid, (int) (ka->h % ka->Rring) };
+    fused_slow_path(b, ka->sy, m, R / 2 + 1, R, R / 2, from_mac_wait, slot_b);
+}
+
+template <int LOG2N, int LOG2R>
+__global__ __launch_bounds__(256) void fused_block_1x1_kernel(FusedBlockParams a)
+{
+    constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, NF = R / 2 + 1;
+    static_assert(M / 2 == R * 256, "one float4 (two bins) per thread in the multiply-accumulate phase");
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    __shared__ int slot_b[2];
+    int w = blockIdx.x;
+    if (a.pin >= 0)
+    {
+        if ((w & 7) != a.pin) return;
+        w >>= 3;
+    }
+    const int slot = (int) (a.h % a.Rring);
+    const bool lone = a.hmac_mod != slot;
+    Fused1x1Bodies<LOG2N, LOG2R> b = { a, dyn, (int) threadIdx.x, slot };
+    fused_roles(b, a.sy, w, NF, R / 2, !lone, slot_b, [&](int m, bool from_mac_wait)
+                { fused_1x1_slow<LOG2N, LOG2R>((const FusedBlockParams *) __builtin_amdgcn_kernarg_segment_ptr(), dyn, b.tid, m, from_mac_wait, slot_b); });
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -632,8 +777,9 @@ hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long 
 
 // The same for nin inputs and ONE output (NToMonoConvolve::process, NToMonoConvolve.cpp:35-43, for one hop) and for 1 x 1 engines
 // with long impulse responses: the reduction over (input, partition) — K = nin P terms — is split over the 16 waves of 1024-thread
-// workgroups (64 lanes = 128 bins each) and added up in LDS, as spectral_mac_kernel's INWG form does.  Workgroups 0 .. M/128 - 1:
-// multiply-accumulate, then 0 .. R/2 - 1 the inverse; the rest: residue class r of input i's forward transform.
+// workgroups (64 lanes = 128 bins each) and added up in LDS, as spectral_mac_kernel's INWG form does.  Workgroups
+// 0 .. nin (R/2 + 1) - 1: residue class r of input i's forward transform; the next M/128: multiply-accumulate, of which the first
+// R/2 go on to the inverse.  Bounded waits and helping as in the 1 x 1 kernel.
 struct FusedNx1Params
 {
     float *hist;
@@ -643,44 +789,41 @@ struct FusedNx1Params
     const float2 *H;            // [nin rows of hstride float2][P][M]: output 0's pairs
     float2 *Y;
     const float2 *tw, *tws;
-    unsigned *bar;
+    FusedSync sy;
     long long hist_stride, in_stride, hist_mask, n0, h, hstride;
-    int Rring, P, hmac_mod, nin, kper;
-    unsigned targetA, targetB;
+    int Rring, P, hmac_mod, nin;
 };
 
-template <int LOG2N, int LOG2R>
-__global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
+template <int LOG2N, int LOG2R> struct FusedNx1Bodies
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, M2 = M / 2, R = 1 << LOG2R, S = N >> LOG2R, NF = R / 2 + 1, TG = 1024, MACW = M2 / 64;
-    static_assert(NF > 0, "");
-    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
-    const int tid = threadIdx.x, w = blockIdx.x;
-    const int slot = (int) (a.h % a.Rring);
-    const bool lone = a.hmac_mod != slot;
+    static constexpr int N = 1 << LOG2N, M = N / 2, M2 = M / 2, R = 1 << LOG2R, S = N >> LOG2R, NF = R / 2 + 1, TG = 1024;
+    const FusedNx1Params &a;
+    float2 *dyn;
+    int tid, slot;
+    bool lone;
+    float4 acc;
+    float ny;
 
-    if (w >= MACW)
+    __device__ __forceinline__ void forward(int task) const
     {
-        const int i = (w - MACW) / NF, r = (w - MACW) % NF;
+        const int i = task / NF, r = task % NF;
         rfft_split_body<LOG2N, LOG2R, true, true, TG>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, r, a.hist + (long long) i * a.hist_stride,
                                                       a.in + (long long) i * a.in_stride, (a.h - 1) * (long long) M, a.n0, a.hist_mask,
                                                       a.X + ((long long) i * a.Rring + slot) * M, a.tw, a.tws);
-        grid_arrive(a.bar);
-        return;
     }
-
+    // with a lead slot (partition 0 reads the NEW spectra X[h]) the terms of partitions >= 1 — all but nin of the nin P — are
+    // accumulated first, beside the forward transforms; the nin lead terms follow once those have arrived
+    __device__ __forceinline__ void mac_old(int m)
     {
         const int lane = tid & 63, ks = tid >> 6;
-        const int b4 = w * 64 + lane;
-        // with a lead slot (partition 0 reads the NEW spectra X[h]) the terms of partitions >= 1 — all but nin of the nin P — are
-        // accumulated first, beside the forward transforms; the nin lead terms follow once those have arrived
+        const int b4 = m * 64 + lane;
+        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
         const int P1 = lone ? a.P : a.P - 1, pofs = lone ? 0 : 1;
         const int K = a.nin * P1;
         const int kper = (K + 15) / 16;
         const int k0 = ks * kper, k1 = min(K, k0 + kper);
-        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float ny = 0.f;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        ny = 0.f;
         for (int kb = k0; kb < k1; kb += 8)
         {
             float4 x[8], hh[8];
@@ -705,9 +848,14 @@ __global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
                     ny += x[u].y * hh[u].y;
                 }
         }
+    }
+    __device__ __forceinline__ void mac_new(int m)
+    {
+        const int lane = tid & 63, ks = tid >> 6;
+        const int b4 = m * 64 + lane;
+        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
         if (!lone)
         {
-            grid_wait(a.bar, a.targetA);
             // the lead terms: input i by wave i, i + 16, ... (X[h] was written a moment ago by other workgroups of this launch)
             for (int i = ks; i < a.nin; i += 16)
             {
@@ -726,7 +874,7 @@ __global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
             acc.x += ny;                                    // (DC and Nyquist products are sums too: repaired per slice, added up below)
             acc.y = ny;
         }
-        float4 *red = reinterpret_cast<float4 *>(dyn);      // [16][64]
+        float4 *red = reinterpret_cast<float4 *>(dyn);      // [16][64] (free: whatever used the LDS before ended in a barrier)
         red[ks * 64 + lane] = acc;
         __syncthreads();
         if (ks == 0)
@@ -743,11 +891,29 @@ __global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
             put2<true>(y + 1, make_float2(sum.z, sum.w));
         }
     }
-    grid_arrive(a.bar + 1);
-    if (w >= R / 2) return;
+    __device__ __forceinline__ void inverse(int j) const { rifft_split_body<LOG2N, LOG2R, true, TG>(dyn, tid, j, a.Y, 1, 0, a.out - M, a.tw, a.tws); }
+};
 
-    grid_wait(a.bar + 1, a.targetB);
-    rifft_split_body<LOG2N, LOG2R, true, TG>(dyn, tid, w, a.Y, 1, 0, a.out - M, a.tw, a.tws);
+template <int LOG2N, int LOG2R> __device__ __noinline__ void fused_nx1_slow(const FusedNx1Params *ka, float2 *dyn, int tid, int m, bool from_mac_wait, int *slot_b)
+{
+    constexpr int R = 1 << LOG2R, MACW = (1 << LOG2N) / 4 / 64;
+    const int slot = (int) (ka->h % ka->Rring);
+    FusedNx1Bodies<LOG2N, LOG2R> b = { *ka, dyn, tid, slot, ka->hmac_mod != slot };
+    fused_slow_path(b, ka->sy, m, ka->nin * (R / 2 + 1), MACW, R / 2, from_mac_wait, slot_b);
+}
+
+template <int LOG2N, int LOG2R>
+__global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
+{
+    constexpr int N = 1 << LOG2N, R = 1 << LOG2R, NF = R / 2 + 1;
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    __shared__ int slot_b[2];
+    const int slot = (int) (a.h % a.Rring);
+    const bool lone = a.hmac_mod != slot;
+    FusedNx1Bodies<LOG2N, LOG2R> b = { a, dyn, (int) threadIdx.x, slot, lone };
+    fused_roles(b, a.sy, (int) blockIdx.x, a.nin * NF, R / 2, !lone, slot_b, [&](int m, bool from_mac_wait)
+                { fused_nx1_slow<LOG2N, LOG2R>((const FusedNx1Params *) __builtin_amdgcn_kernarg_segment_ptr(), dyn, b.tid, m, from_mac_wait, slot_b); });
+    (void) N;
 }
 
 
@@ -757,8 +923,9 @@ __global__ __launch_bounds__(1024) void fused_block_nx1_kernel(FusedNx1Params a)
 // with p < T) read spectra of EARLIER blocks, so the 16 waves of every multiply-accumulate workgroup first sum the partitions
 // p >= T over their slices — each IR spectrum loaded once for all T hops, the window of input spectra sliding as in the hop-tiled
 // kernel (hcv_mac_tiled.hip) — beside the T x (R/2 + 1) workgroups of the forward transforms, then wait for those and add the
-// T partitions p < T (one per wave).  Workgroups 0 .. M/128 - 1: multiply-accumulate (128 bins each), then 0 .. T R/2 - 1 the
-// inverse of hop t = w / (R/2); the rest: residue class r of hop t's forward transform.
+// T partitions p < T (one per wave).  Workgroups 0 .. T (R/2 + 1) - 1: residue class r of hop t's forward transform; the next
+// M/128: multiply-accumulate (128 bins each), of which the first T R/2 go on to the inverse of hop t = m / (R/2).  Bounded waits
+// and helping as in the 1 x 1 kernel.
 struct FusedHopsParams
 {
     float *hist;
@@ -768,60 +935,54 @@ struct FusedHopsParams
     const float2 *H;            // [P][M]
     float2 *Y;                  // [T][M] scratch
     const float2 *tw, *tws;
-    unsigned *bar;
+    FusedSync sy;
     long long hist_mask, n0, h; // h = the block's first hop
     int Rring, P, T, hmac_mod;  // hmac_mod = (hop that partition 0 of hop h reads: h with a lead slot, h - 1 for a lone stage) mod Rring
-    unsigned targetA, targetB;
 };
 
-template <int LOG2N, int LOG2R, int TMAX>
-__global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams a)
+template <int LOG2N, int LOG2R, int TMAX> struct FusedHopsBodies
 {
-    constexpr int N = 1 << LOG2N, M = N / 2, M2 = M / 2, R = 1 << LOG2R, S = N >> LOG2R, NF = R / 2 + 1, TG = 1024, MACW = M2 / 64;
-    static_assert(TMAX * (R / 2) <= MACW, "the inverse's workgroups are the first of the multiply-accumulate's");
-    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
-    const int tid = threadIdx.x, w = blockIdx.x;
-    const int T = a.T;
+    static constexpr int N = 1 << LOG2N, M = N / 2, M2 = M / 2, R = 1 << LOG2R, S = N >> LOG2R, NF = R / 2 + 1, TG = 1024;
+    const FusedHopsParams &a;
+    float2 *dyn;
+    int tid;
+    float4 acc[TMAX];
+    float ny[TMAX];
 
-    if (w >= MACW)
+    __device__ __forceinline__ void forward(int task) const
     {
-        const int t = (w - MACW) / NF, r = (w - MACW) % NF;
+        const int t = task / NF, r = task % NF;
         const long long h = a.h + t;
         rfft_split_body<LOG2N, LOG2R, true, true, TG>(dyn, dyn + lds_padded(S), dyn + lds_padded(S) + S, tid, r, a.hist, a.in, (h - 1) * (long long) M, a.n0,
                                                       a.hist_mask, a.X + (long long) (h % a.Rring) * M, a.tw, a.tws);
-        grid_arrive(a.bar);
-        return;
     }
-
+    __device__ __forceinline__ int slot_of(int d) const      // ring slot of hop (hmac + d), d in (-Rring, TMAX)
     {
-        const int lane = tid & 63, ks = tid >> 6;
-        const int b4 = w * 64 + lane;
+        int sl = a.hmac_mod + d;
+        if (sl < 0) sl += a.Rring;
+        if (sl >= a.Rring) sl -= a.Rring;
+        return sl;
+    }
+    static __device__ __forceinline__ void cmac(float4 &c, float &n, const float4 &x, const float4 &hv)
+    {
+        c.x += x.x * hv.x - x.y * hv.y;
+        c.y += x.x * hv.y + x.y * hv.x;
+        c.z += x.z * hv.z - x.w * hv.w;
+        c.w += x.z * hv.w + x.w * hv.z;
+        n += x.y * hv.y;
+    }
+    // ---- partitions p >= T: every spectrum they read is older than this block
+    __device__ __forceinline__ void mac_old(int m)
+    {
+        const int lane = tid & 63, ks = tid >> 6, T = a.T;
+        const int b4 = m * 64 + lane;
         const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
-        float4 acc[TMAX];
-        float ny[TMAX];
 #pragma unroll
         for (int t = 0; t < TMAX; t++)
         {
             acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             ny[t] = 0.f;
         }
-        auto slot_of = [&](int d) -> int                 // ring slot of hop (hmac + d), d in (-Rring, TMAX)
-        {
-            int sl = a.hmac_mod + d;
-            if (sl < 0) sl += a.Rring;
-            if (sl >= a.Rring) sl -= a.Rring;
-            return sl;
-        };
-        auto cmac = [&](float4 &c, float &n, const float4 &x, const float4 &hv)
-        {
-            c.x += x.x * hv.x - x.y * hv.y;
-            c.y += x.x * hv.y + x.y * hv.x;
-            c.z += x.z * hv.z - x.w * hv.w;
-            c.w += x.z * hv.w + x.w * hv.z;
-            n += x.y * hv.y;
-        };
-
-        // ---- partitions p >= T: every spectrum they read is older than this block
         const int K = a.P - T;
         if (K > 0)
         {
@@ -855,10 +1016,14 @@ __global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams 
                 }
             }
         }
-
-        // ---- partitions p < T, one per wave: hop t's term reads hop hmac + t - p, which this launch itself may be writing (t - p >= h - hmac):
-        //      all of them after the hand-over, through agent-scope loads
-        grid_wait(a.bar, a.targetA);
+    }
+    // ---- partitions p < T, one per wave: hop t's term reads hop hmac + t - p, which this launch itself may be writing (t - p >= h - hmac):
+    //      all of them after the hand-over, through agent-scope loads
+    __device__ __forceinline__ void mac_new(int m)
+    {
+        const int lane = tid & 63, ks = tid >> 6, T = a.T;
+        const int b4 = m * 64 + lane;
+        const float4 *X4 = reinterpret_cast<const float4 *>(a.X), *H4 = reinterpret_cast<const float4 *>(a.H);
         if (ks < T && ks < a.P)
         {
             const int p = ks;
@@ -872,7 +1037,7 @@ __global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams 
                     cmac(acc[t], ny[t], make_float4(lo.x, lo.y, hi.x, hi.y), hv);
                 }
         }
-        float4 *red = reinterpret_cast<float4 *>(dyn);      // [16][TMAX][64]
+        float4 *red = reinterpret_cast<float4 *>(dyn);      // [16][TMAX][64] (free: whatever used the LDS before ended in a barrier)
 #pragma unroll
         for (int t = 0; t < TMAX; t++)
         {
@@ -899,14 +1064,65 @@ __global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams 
             put2<true>(y + 1, make_float2(sum.z, sum.w));
         }
     }
-    grid_arrive(a.bar + 1);
-    if (w >= T * (R / 2)) return;
-
-    grid_wait(a.bar + 1, a.targetB);
+    __device__ __forceinline__ void inverse(int m) const
     {
-        const int t = w / (R / 2), j = w % (R / 2);
+        const int t = m / (R / 2), j = m % (R / 2);
         rifft_split_body<LOG2N, LOG2R, true, TG>(dyn, tid, j, a.Y + (long long) t * M, 1, 0, a.out + (long long) t * M - M, a.tw, a.tws);
     }
+};
+
+template <int LOG2N, int LOG2R, int TMAX> __device__ __noinline__ void fused_hops_slow(const FusedHopsParams *ka, float2 *dyn, int tid, int m, bool from_mac_wait, int *slot_b)
+{
+    constexpr int R = 1 << LOG2R, MACW = (1 << LOG2N) / 4 / 64;
+    FusedHopsBodies<LOG2N, LOG2R, TMAX> b = { *ka, dyn, tid };
+    fused_slow_path(b, ka->sy, m, ka->T * (R / 2 + 1), MACW, ka->T * (R / 2), from_mac_wait, slot_b);
+}
+
+template <int LOG2N, int LOG2R, int TMAX>
+__global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams a)
+{
+    constexpr int N = 1 << LOG2N, R = 1 << LOG2R, NF = R / 2 + 1, MACW = N / 4 / 64;
+    static_assert(TMAX * (R / 2) <= MACW, "the inverse's workgroups are the first of the multiply-accumulate's");
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];
+    __shared__ int slot_b[2];
+    FusedHopsBodies<LOG2N, LOG2R, TMAX> b = { a, dyn, (int) threadIdx.x };
+    fused_roles(b, a.sy, (int) blockIdx.x, a.T * NF, a.T * (R / 2), true, slot_b, [&](int m, bool from_mac_wait)
+                { fused_hops_slow<LOG2N, LOG2R, TMAX>((const FusedHopsParams *) __builtin_amdgcn_kernarg_segment_ptr(), dyn, b.tid, m, from_mac_wait, slot_b); });
+}
+
+// The host's running totals of the two counters and the launch sequence number move only once the runtime has accepted the
+// launch: a refused launch leaves the device counters where they were, and totals that ran ahead of them would make every later
+// launch wait (boundedly — and then redo everything by helping) for arrivals that never come.
+struct FusedHostState
+{
+    unsigned *arrived;          // [2]
+    unsigned long long *seq;
+};
+static int fused_spin()
+{
+    static const int s = std::getenv("HCV_COOP_SPIN") ? std::max(0, std::atoi(std::getenv("HCV_COOP_SPIN"))) : 64;
+    return s;
+}
+static FusedSync fused_sync(unsigned *bar, unsigned long long *flags, const unsigned *arrived, unsigned long long seq, unsigned producers, unsigned macs)
+{
+    FusedSync sy;
+    sy.bar = bar;
+    sy.flagM = flags;                       // [kFusedMacTasks]
+    sy.flagF = flags + kFusedMacTasks;      // [kFusedFwdTasks]
+    sy.seq = seq + 1;
+    sy.targetA = arrived[0] + producers;
+    sy.targetB = arrived[1] + macs;
+    sy.spin = fused_spin();
+    return sy;
+}
+static hipError_t fused_launched(unsigned *arrived, unsigned long long *seq, unsigned producers, unsigned macs)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    arrived[0] += producers;
+    arrived[1] += macs;
+    *seq += 1;
+    return hipSuccess;
 }
 
 bool fused_block_1x1_applies(int log2n)
@@ -917,10 +1133,10 @@ bool fused_block_1x1_applies(int log2n)
 
 hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0, long long h,
                                   int nin, float2 *X, int Rring, const float2 *H, long long hstride, int P, long long h_mac, float2 *Y, float *out, const float2 *tw,
-                                  unsigned *bar, unsigned *arrived, hipStream_t st)
+                                  unsigned *bar, unsigned long long *flags, unsigned *arrived, unsigned long long *seq, hipStream_t st)
 {
-    if (log2n != 14 || nin < 1) return hipErrorInvalidValue;
     constexpr int LOG2N = 14, LOG2R = 4, M = 1 << (LOG2N - 1), S = 1 << (LOG2N - LOG2R), R = 1 << LOG2R;
+    if (log2n != 14 || nin < 1 || nin * (R / 2 + 1) > kFusedFwdTasks) return hipErrorInvalidValue;
     const float2 *tws = sub_table(LOG2N - LOG2R);
     if (!tws) return hipErrorInvalidValue;
     constexpr size_t lds = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R);
@@ -935,20 +1151,21 @@ hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride,
         if (dev >= 0 && dev < 64) allowed[dev] = true;
     }
     FusedNx1Params a;
-    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
+    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws;
     a.hist_stride = hist_stride; a.in_stride = in_stride; a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.hstride = hstride;
     a.Rring = Rring; a.P = P; a.nin = nin;
     a.hmac_mod = (int) (h_mac % Rring);
-    a.kper = (nin * P + 15) / 16;
-    constexpr int G = M / 128 + 0;
-    a.targetA = (arrived[0] += (unsigned) (nin * (R / 2 + 1)));
-    a.targetB = (arrived[1] += (unsigned) G);
-    hipLaunchKernelGGL((fused_block_nx1_kernel<LOG2N, LOG2R>), dim3(G + nin * (R / 2 + 1)), dim3(1024), lds, st, a);
-    return hipGetLastError();
+    constexpr unsigned NM = M / 128;
+    static_assert(NM <= kFusedMacTasks, "");
+    const unsigned nfwd = (unsigned) (nin * (R / 2 + 1));
+    a.sy = fused_sync(bar, flags, arrived, *seq, nfwd, NM);
+    hipLaunchKernelGGL((fused_block_nx1_kernel<LOG2N, LOG2R>), dim3(nfwd + NM), dim3(1024), lds, st, a);
+    return fused_launched(arrived, seq, nfwd, NM);
 }
 
 hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, float2 *X, int Rring, const float2 *H,
-                                  int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived, hipStream_t st)
+                                  int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived,
+                                  unsigned long long *seq, hipStream_t st)
 {
     if (log2n != 14) return hipErrorInvalidValue;
     constexpr int LOG2N = 14, LOG2R = 4, M = 1 << (LOG2N - 1), S = 1 << (LOG2N - LOG2R), R = 1 << LOG2R;
@@ -966,28 +1183,26 @@ hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, c
         if (dev >= 0 && dev < 64) allowed[dev] = true;
     }
     FusedBlockParams a;
-    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
+    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws;
     a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.Rring = Rring; a.P = P;
     a.hmac_mod = (int) (h_mac % Rring);
-    a.targetA = (arrived[0] += (unsigned) (R / 2 + 1));
-    a.targetB = (arrived[1] += (unsigned) R);
-    constexpr int G = R + R / 2 + 1;
+    constexpr unsigned NFW = R / 2 + 1, NM = R, G = NFW + NM;
+    a.sy = fused_sync(bar, flags, arrived, *seq, NFW, NM);
     a.pin = xcd_pin_for(G);
     hipLaunchKernelGGL((fused_block_1x1_kernel<LOG2N, LOG2R>), dim3(G * (a.pin >= 0 ? 8 : 1)), dim3(256), lds, st, a);
-    return hipGetLastError();
+    return fused_launched(arrived, seq, NFW, NM);
 }
 
 
 bool fused_block_hops_applies(int log2n, int T)
 {
-    static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0) &&
-                           !(std::getenv("HCV_COOP_HOPS") && std::atoi(std::getenv("HCV_COOP_HOPS")) == 0);
+    static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0);
     return on && log2n == 12 && T >= 2 && T <= 4;
 }
 
 hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, int T, float2 *X, int Rring,
-                                   const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
-                                   hipStream_t st)
+                                   const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned long long *flags,
+                                   unsigned *arrived, unsigned long long *seq, hipStream_t st)
 {
     if (log2n != 12 || T < 2 || T > 4 || P < 1) return hipErrorInvalidValue;
     constexpr int LOG2N = 12, LOG2R = 3, TMAX = 4, M = 1 << (LOG2N - 1), S = 1 << (LOG2N - LOG2R), R = 1 << LOG2R, MACW = M / 128;
@@ -1006,13 +1221,13 @@ hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, 
         if (dev >= 0 && dev < 64) allowed[dev] = true;
     }
     FusedHopsParams a;
-    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws; a.bar = bar;
+    a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws;
     a.hist_mask = hist_mask; a.n0 = n0; a.h = h; a.Rring = Rring; a.P = P; a.T = T;
     a.hmac_mod = (int) (h_mac % Rring);
-    a.targetA = (arrived[0] += (unsigned) (T * (R / 2 + 1)));
-    a.targetB = (arrived[1] += (unsigned) MACW);
-    hipLaunchKernelGGL((fused_block_hops_kernel<LOG2N, LOG2R, TMAX>), dim3(MACW + T * (R / 2 + 1)), dim3(1024), lds, st, a);
-    return hipGetLastError();
+    const unsigned nfwd = (unsigned) (T * (R / 2 + 1));
+    a.sy = fused_sync(bar, flags, arrived, *seq, nfwd, MACW);
+    hipLaunchKernelGGL((fused_block_hops_kernel<LOG2N, LOG2R, TMAX>), dim3(nfwd + MACW), dim3(1024), lds, st, a);
+    return fused_launched(arrived, seq, nfwd, MACW);
 }
 
 } // namespace hcv

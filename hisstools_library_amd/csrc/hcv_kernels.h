@@ -44,7 +44,9 @@ namespace hcv
     //      launch of 8 x as many workgroups of which only those with b % 8 == 0 work keeps the whole chain on ONE XCD and its
     //      hand-overs in that XCD's L2.  Returns the XCD to pin a launch of `workgroups` to (one-dimensional grids), or -1.
     int xcd_pin_for(long long workgroups);
-    void xcd_pin_hint(bool on);     // set by the engine around a block's enqueue (thread-local): "this block's chain is tiny and its data fits one L2"
+    // set by the engine around a block's enqueue (thread-local): "this block's chain is tiny and its data fits one L2"; xcd = the
+    // XCD this engine's chains go to (engines of one process are spread over the eight)
+    void xcd_pin_hint(bool on, int xcd = 0);
 
     // ---- residue-split transforms (hcv_fft_split.hip): one hop transform over several workgroups that share nothing, for blocks
     //      of a few transforms.  `applies` = the rule (HCV_FFT_SPLIT = 0 / 1 forces it); `prepare` uploads the sub-transform tables
@@ -57,25 +59,29 @@ namespace hcv
                                        const float2 *tw, hipStream_t st);
 
     // ---- the fused 1 x 1 block (hcv_fft_split.hip): one hop of a one-input, one-output engine in ONE launch.  h = the hop, h_mac =
-    //      the hop partition 0 reads (h with a lead slot, h - 1 for a lone stage), H = the pair's P live partitions, bar = two
-    //      zero-initialised counters that only these launches touch, arrived = the host's running totals of what they will read
+    //      the hop partition 0 reads (h with a lead slot, h - 1 for a lone stage), H = the pair's P live partitions.  Hand-over state,
+    //      touched by these launches only, all zero-initialised: bar = two arrival counters, flags = kFusedMacTasks + kFusedFwdTasks
+    //      per-task completion marks; arrived / seq = the host's running totals of the counters and the launch sequence number
+    //      (advanced only by launches the runtime accepted).
+    constexpr int kFusedMacTasks = 64, kFusedFwdTasks = 2048 * 9;
     bool fused_block_1x1_applies(int log2n);
     hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, float2 *X, int Rring,
-                                      const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
-                                      hipStream_t st);
+                                      const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned long long *flags,
+                                      unsigned *arrived, unsigned long long *seq, hipStream_t st);
 
     // several hops of a short stage per block (1 x 1, 4096-point partitions, T = 2 .. 4 hops: BASELINE config 2 at 8192-sample calls);
     // h = the block's first hop, Y = room for T spectra, out = the block's T hops of output
     bool fused_block_hops_applies(int log2n, int T);
     hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, const float *in, long long n0, long long h, int T, float2 *X, int Rring,
-                                       const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned *arrived,
-                                       hipStream_t st);
+                                       const float2 *H, int P, long long h_mac, float2 *Y, float *out, const float2 *tw, unsigned *bar, unsigned long long *flags,
+                                       unsigned *arrived, unsigned long long *seq, hipStream_t st);
 
     // nin inputs -> one output, or 1 x 1 with a long reduction (K = nin P split over the waves of 1024-thread workgroups); H = output 0's
     // pairs, `hstride` float2 between two inputs' spectra
     hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0,
                                       long long h, int nin, float2 *X, int Rring, const float2 *H, long long hstride, int P, long long h_mac, float2 *Y,
-                                      float *out, const float2 *tw, unsigned *bar, unsigned *arrived, hipStream_t st);
+                                      float *out, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived, unsigned long long *seq,
+                                      hipStream_t st);
 
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,
                                int R, const float2 *tw, const BigFFTWork &w, hipStream_t st);

@@ -798,7 +798,12 @@ __global__ void fold_copy_kernel(float *__restrict__ dst, const float *__restric
     }
 
 static thread_local bool tlsPinHint = false;
-void xcd_pin_hint(bool on) { tlsPinHint = on; }
+static thread_local int tlsPinXcd = 0;
+void xcd_pin_hint(bool on, int xcd)
+{
+    tlsPinHint = on;
+    tlsPinXcd = xcd & 7;
+}
 
 int xcd_pin_for(long long workgroups)
 {
@@ -806,7 +811,7 @@ int xcd_pin_for(long long workgroups)
     static const int mode = std::getenv("HCV_XCD_PIN") ? std::atoi(std::getenv("HCV_XCD_PIN")) : -1;
     static const int limit = std::getenv("HCV_XCD_PIN_MAX") ? std::atoi(std::getenv("HCV_XCD_PIN_MAX")) : 32;
     if (mode == 0 || workgroups <= 0 || workgroups > limit) return -1;
-    return (mode > 0 || tlsPinHint) ? 0 : -1;
+    return (mode > 0 || tlsPinHint) ? tlsPinXcd : -1;
 }
 
 template <int L> static inline size_t fft_lds_bytes() { return sizeof(float2) * lds_padded(FFTGeom<L>::M) * FFTGeom<L>::G; }

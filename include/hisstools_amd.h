@@ -211,6 +211,9 @@ typedef struct hcv_stage_stats
      * (whole-hop blocks: the stage's own + the one holding the IR in front of its segment) */
     uint64_t mac_steady_launches;
     uint32_t hop_tile, launch_partitions;
+    /* of mac_launches: whole blocks of a one-output engine that ran as ONE launch (transforms, multiply-accumulate and inverse
+     * with in-launch hand-overs) */
+    uint64_t fused_launches;
 } hcv_stage_stats;
 HCV_API void hcv_convolver_set_profiling(hcv_convolver *h, int on);
 HCV_API int hcv_convolver_num_stages(hcv_convolver *h);

@@ -61,7 +61,7 @@ def test_fused_multi_hop_block_of_a_4096_point_stage_vs_oracle(block):
     and inverse of the block's hops in ONE launch) against the CPU oracle (bit-identical to the unmodified reference,
     PartitionedConvolve.cpp:243-426) with a dense decaying-noise IR, streamed past the IR length so that every partition is live,
     <= 2e-6 of the peak; the stage statistics must show the fused launch (one slice, hop tile = hops per block), and the same
-    stream with the fused block switched off (HCV_COOP_HOPS=0: transforms, hop-tiled MAC, reduction, inverse as four launches)
+    stream with the fused block switched off (HCV_COOP=0: transforms, hop-tiled MAC, reduction, inverse as four launches)
     must agree to rounding."""
     code = ("import sys, json, numpy as np, hisstools_library_amd as H\n"
             "from oracle import oracle as O\n"
@@ -82,7 +82,7 @@ def test_fused_multi_hop_block_of_a_4096_point_stage_vs_oracle(block):
         for mode in ("1", "0"):
             path = os.path.join(d, f"y{mode}.npy")
             out = subprocess.run([sys.executable, "-c", code, path, str(block)], capture_output=True, text=True, timeout=600, cwd=ROOT,
-                                 env=dict(os.environ, HCV_COOP_HOPS=mode))
+                                 env=dict(os.environ, HCV_COOP=mode))
             assert out.returncode == 0, out.stderr[-2000:]
             res[mode] = (np.load(path), json.loads(out.stdout.strip().splitlines()[-1]))
     (y1, st1), (y0, st0) = res["1"], res["0"]
@@ -113,7 +113,7 @@ def test_fused_multi_hop_block_with_a_lead_slot_vs_float64_truth():
             "print(json.dumps({'err': float(np.abs(y - t).max() / np.abs(t).max()), 'hop_tile': int(st['hop_tile']), 'ksplit': int(st['ksplit']), 'fft': int(st['fft_size'])}))\n")
     import json
     for mode in ("1", "0"):
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HCV_COOP_HOPS=mode))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, HCV_COOP=mode))
         assert out.returncode == 0, out.stderr[-2000:]
         r = json.loads(out.stdout.strip().splitlines()[-1])
         assert r["fft"] == 4096 and r["err"] <= 2e-6, r

@@ -72,6 +72,13 @@ WORKLOADS = {
 }
 
 
+# BENCH_IR_DIV=n (tests only): every workload's impulse responses n times shorter — the driver's exact multi-rank command on a one-GPU
+# test box in bounded time.  The line says so (config.reduced_ir_div) and names the IR length it ran.
+IR_DIV = max(1, int(os.environ.get("BENCH_IR_DIV", "1") or 1))
+if IR_DIV > 1:
+    WORKLOADS = {k: (v[0], v[1], max(20000, v[2] // IR_DIV), v[3], v[4]) for k, v in WORKLOADS.items()}
+
+
 def stage_layout(L, layout):
     """(fft_size, partitions) per FFT stage for an IR of L samples — MonoConvolve::setPartitions arithmetic."""
     zero, *sizes = layout
@@ -162,50 +169,78 @@ def cpu_sub_matrix(workload):
     return sub_in, sub_out
 
 
-def cpu_baseline(workload, hops=64):
-    """Reference CPU path on one host core, on a bounded sub-matrix of the same workload (steady state: the
-    stream is first run for as many hops as the tail has partitions so every partition is live, then timed).
-    `_outs` (popped by the caller before printing) is what it computed: [sub_out][warm + S] — the self-check's reference."""
+def cpu_baseline(workload, hops=64, seg_hops=16, protocol=True):
+    """Reference CPU path on one host core, on a bounded sub-matrix of the same workload (steady state: the stream is first run
+    for as many hops as the tail has partitions so every partition is live, then timed) — BASELINE.md section 3's protocol:
+    best of 3 timed segments, process blocks of 512 and 2048 samples, the -O3 -msse2 build (the reference's fixed 4-wide SIMD;
+    `value` = its 512-sample figure) and, where it travelled, the -O3 -mavx2 -mfma build standing in for -march=native (the
+    sources cannot be compiled on the GPU box).  `_outs` (popped by the caller before printing) is what the first build computed
+    over the warm-up and the first timed segment: [sub_out][warm + S] — the self-check's reference."""
     import numpy as np
     from oracle import oracle as O
 
     nin, nout, L, fs, layout = WORKLOADS[workload]
     kind = "reference" if O.have_ref() else "port"
-    backend = "ref" if kind == "reference" else "port"
     tail, p_tail = stage_layout(L, layout)[-1]
     sub_in, sub_out = cpu_sub_matrix(workload)
     hop = tail // 2
-    warm, S = p_tail * hop, hops * hop
-    block = 512
-    xs = np.stack([O.synth_audio(i, warm + S) for i in range(sub_in)])
-    t_set = time.perf_counter()
-    if workload in ("c2", "c1"):
-        block = 2048
-        p = O.PartitionedConvolve(layout[1], L, 0, 0, backend=backend)
-        p.setResetOffset(0)
-        p.set(O.synth_ir(0, 0, L))
+    warm, S, S2 = p_tail * hop, hops * hop, seg_hops * hop
+    n_total = warm + S + 5 * S2
+    xs = np.stack([O.synth_audio(i, n_total) for i in range(sub_in)])
+    mono = workload in ("c2", "c1")
+    irs = {(i, o): O.synth_ir(i, o, L) for o in range(1 if mono else sub_out) for i in range(1 if mono else sub_in)}
+
+    def stream(engine, x, block):
+        """(outs, seconds) of one segment"""
+        if mono:
+            t0 = time.perf_counter()
+            y = engine.run(x[0], block)                 # (a Python loop over the calls: ~3 us of ctypes per call beside >= 60 us of work)
+            return y[None, :], time.perf_counter() - t0
+        return engine.stream_timed(np.ascontiguousarray(x), sub_out, block)
+
+    def one_build(backend, keep_outs):
+        t_set = time.perf_counter()
+        if mono:
+            e = O.PartitionedConvolve(layout[1], L, 0, 0, backend=backend)
+            e.setResetOffset(0)
+            e.set(irs[(0, 0)])
+        else:
+            e = O.Convolver(sub_in, sub_out, 0, backend=backend)
+            for (i, o), h in irs.items():
+                e.set(i, o, h, True)
         t_set = time.perf_counter() - t_set
-        y0 = p.run(xs[0, :warm], block)
-        t0 = time.perf_counter()
-        y1 = p.run(xs[0, warm:], block)
-        secs = time.perf_counter() - t0
-        outs = np.concatenate([y0, y1])[None, :]
-    else:
-        c = O.Convolver(sub_in, sub_out, 0, backend=backend)
-        for o in range(sub_out):
-            for i in range(sub_in):
-                c.set(i, o, O.synth_ir(i, o, L), True)
-        t_set = time.perf_counter() - t_set
-        y0, _ = c.stream_timed(np.ascontiguousarray(xs[:, :warm]), sub_out, block)
-        y1, secs = c.stream_timed(np.ascontiguousarray(xs[:, warm:]), sub_out, block)
-        outs = np.concatenate([y0, y1], axis=1)
-    pair_rate = sub_in * sub_out * S / secs                       # pair-samples / s on one core
-    value = pair_rate / nin / 1e6                                 # == output-channel Msamples/s for the full matrix
+        pos = 0
+        y0, _ = stream(e, xs[:, :warm], 512)
+        pos = warm
+        rates = {512: [], 2048: []}
+        outs, secs0 = None, None
+        plan = [(512, S)] + ([(512, S2), (512, S2), (2048, S2), (2048, S2), (2048, S2)] if protocol else [])
+        for block, n in plan:
+            y, secs = stream(e, xs[:, pos:pos + n], block)
+            if outs is None:
+                outs, secs0 = (np.concatenate([y0, y], axis=1) if keep_outs else None), secs
+            pos += n
+            rates[block].append((1 if mono else sub_in * sub_out) * n / secs)
+        return {b_: max(v) for b_, v in rates.items() if v}, outs, secs0, t_set
+
+    best, outs, secs, t_set = one_build("ref" if kind == "reference" else "port", True)
+    wide = None
+    if protocol and kind == "reference" and O.have_ref_wide():
+        try:
+            wide = one_build("ref_wide", False)[0]
+        except Exception:
+            wide = None
+    pair_rate = best[512]                                          # pair-samples / s on one core
+    to_value = lambda r: None if r is None else round(r / nin / 1e6, 6)     # == output-channel Msamples/s for the full matrix
     return {
-        "value": round(value, 6), "unit": "Msamples/s", "cores": 1, "kind": kind,
-        "sample": f"{sub_in}x{sub_out} sub-matrix of the {nin}x{nout} workload, same {L}-sample IRs, {S} samples timed in {block}-sample calls "
-                  f"after a {warm}-sample warm-up (all partitions live), 1 thread; value = pair-samples/s / {nin} inputs = the whole-matrix "
-                  f"output rate one core would sustain; IR load took {t_set:.1f} s",
+        "value": to_value(pair_rate), "unit": "Msamples/s", "cores": 1, "kind": kind,
+        "flags": "-O3 -msse2", "block": 512, "best_of": 3 if protocol else 1,
+        "b2048": to_value(best.get(2048)),
+        "wide_flags": None if wide is None else "-O3 -mavx2 -mfma (stands in for -march=native: the sources cannot be compiled on this host)",
+        "wide_b512": None if wide is None else to_value(wide.get(512)), "wide_b2048": None if wide is None else to_value(wide.get(2048)),
+        "sample": f"{sub_in}x{sub_out} sub-matrix of the {nin}x{nout} workload, same {L}-sample IRs, after a {warm}-sample warm-up (all partitions live): "
+                  f"best of 3 timed segments ({S}, {S2}, {S2} samples) in 512-sample calls, then 3 x {S2} samples in 2048-sample calls, 1 thread; value = "
+                  f"pair-samples/s / {nin} inputs = the whole-matrix output rate one core would sustain; IR load took {t_set:.1f} s",
         "pair_msamples_per_s": round(pair_rate / 1e6, 4),
         "seconds": round(secs, 3),
         "_outs": outs, "_sub": (sub_in, sub_out, warm + S),
@@ -383,8 +418,8 @@ def main():
 
             def give_up():
                 if rank == 0 and line is not None:
-                    line["config"]["also"] = digests + [{"scaling": "strong", "error": "strong-scaled legs did not finish in time; headline unaffected"}]
-                    print(json.dumps(line), flush=True)
+                    line["config"]["also"] = digests + [{"workload": "legs", "scaling": "strong", "error": "strong-scaled legs did not finish in time; headline unaffected"}]
+                    print(json.dumps(emit(line)), flush=True)
                 os._exit(0)
 
             dog = threading.Timer(float(os.environ.get("BENCH_ALSO_TIMEOUT", "300")), give_up)
@@ -396,9 +431,104 @@ def main():
         if rank == 0 and line is not None:
             line["config"]["also"] = digests
     if rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        # (a child bench of an `also` leg hands its parent the rich line; the driver's line is the short one)
+        print(json.dumps(line if args.leg else emit(line)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _leg_key(d):
+    """'ns64' of a digest whose workload text starts with 'ns64: ...' (+ '_strong' for the strong-scaled legs of an N > 1 run)"""
+    w = str(d.get("workload", "")).split(":")[0].strip() or "leg"
+    return w + ("_strong" if d.get("scaling") == "strong" else "")
+
+
+def flat_scalars(line):
+    """Everything a reader needs to check every shape, as flat scalars (the driver's record keeps scalar config keys only)"""
+    cfg, out = line["config"], {}
+    rt = cfg.get("realtime") or {}
+    if "host_pointers" in rt:
+        out.update({"rt128_host_p50_ms": rt["host_pointers"].get("p50_ms"), "rt128_host_p99_ms": rt["host_pointers"].get("p99_ms"),
+                    "rt128_over_budget": rt["host_pointers"].get("over_budget"), "rt128_dev_p99_ms": (rt.get("device_pointers") or {}).get("p99_ms"),
+                    "host_pointer_step_msamples_per_s": (rt.get("host_pointer_steps") or {}).get("msamples_per_s")})
+    if cfg.get("batched"):
+        out["batched_block"] = cfg["batched"].get("block")
+        out["batched_msamples_per_s"] = cfg["batched"].get("msamples_per_s")
+        out["batched_mac_hbm_frac"] = (line.get("roofline_batched") or {}).get("hbm_frac")
+    ex = cfg.get("extended_layout") or {}
+    if ex:
+        out.update({"extended_tail_ratio": ex.get("tail_ratio"), "extended_msamples_per_s": ex.get("msamples_per_s"), "extended_ms_per_step": ex.get("ms_per_step"),
+                    "extended_step_frac": (ex.get("roofline_step") or {}).get("frac"), "extended_max_rel_err": (ex.get("self_check") or {}).get("max_rel_err"),
+                    "extended_error": ex.get("error")})
+    for d in cfg.get("also") or []:
+        if not d:
+            continue
+        k = _leg_key(d)
+        if d.get("error"):
+            out[k + "_error"] = str(d["error"])[:160]
+            continue
+        rf, sc, cb = d.get("roofline") or {}, d.get("self_check") or {}, d.get("cpu_baseline") or {}
+        out.update({k + "_msamples_per_s": d.get("value"), k + "_ms_per_step": d.get("ms_per_step"), k + "_realtime_factor": d.get("realtime_factor"),
+                    k + "_bound": rf.get("bound"), k + "_mac_frac": rf.get("frac") if rf.get("bound") == "hbm" else None,
+                    k + "_mac_ms": rf.get("avg_launch_ms"), k + "_max_rel_err": sc.get("max_rel_err"), k + "_self_check_ok": sc.get("ok"),
+                    k + "_cpu_1core": cb.get("value"), k + "_cpu_1core_b2048": cb.get("b2048"), k + "_cpu_1core_wide": cb.get("wide_b512")})
+        if rf.get("bound") == "hbm":
+            out[k + "_mac_over_box_read"] = rf.get("achieved_over_box_read")
+            out[k + "_whole_step_frac"] = rf.get("whole_step_frac")
+        else:
+            out[k + "_kernel"] = str(rf.get("kernel", "")).split(" ")[0]
+            out[k + "_kernel_share_of_step"] = rf.get("kernel_share_of_step")
+        if rf.get("note_ceiling"):
+            out[k + "_note"] = rf["note_ceiling"][:300]
+        sb = (d.get("realtime") or {}).get("small_blocks") or {}
+        hp = (d.get("realtime") or {}).get("host_pointers") or {}
+        if hp:
+            out[k + "_rt128_p99_ms"] = hp.get("p99_ms")
+        for blk in ("64", "32"):
+            if blk in sb:
+                out[f"{k}_rt{blk}_p50_ms"] = sb[blk].get("p50_ms")
+                out[f"{k}_rt{blk}_p99_ms"] = sb[blk].get("p99_ms")
+                out[f"{k}_rt{blk}_over_budget"] = sb[blk].get("over_budget")
+    return out
+
+
+def emit(line):
+    """The ONE line printed: short (< 4 KB) and flat, so that it survives a scalars-only parser and an 8 KB output tail.  The rich
+    record (digests of every further workload, the real-time, batched and extended-ladder objects, the samples' descriptions) goes to
+    a side file beside it: BENCH_DETAILS (default gpurun_out/bench_details.json)."""
+    import copy
+    path = os.environ.get("BENCH_DETAILS", os.path.join(ROOT, "gpurun_out", "bench_details.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(line, f, indent=1)
+    except Exception as e:
+        path = f"not written: {e}"
+    short = copy.deepcopy(line)
+    cfg = short["config"]
+    flat = flat_scalars(line)
+    sc = cfg.get("self_check") or {}
+    keep = {k: cfg.get(k) for k in ("workload", "sharding", "realtime_factor", "pair_msamples_per_s", "ir_load_s", "finite_output", "max_rel_err", "tail_ratio",
+                                    "reduced_ir_div")}
+    keep["inputs"] = "SURVEY 8d generator (mt19937-seeded 60 dB decaying-noise IRs of unit norm, uniform audio)"
+    keep["self_check_ok"] = sc.get("ok")
+    keep["self_check_against"] = None if not sc else f"{str(sc.get('against', ''))[:60]}..."
+    keep.update(flat)
+    keep["details_file"] = path
+    short["config"] = keep
+    rf = short.get("roofline") or {}
+    short["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
+                                                 "launches", "steady_launches", "box_read_GBps", "achieved_over_box_read", "whole_step_frac",
+                                                 "survey_8d_ceiling_msamples_per_s", "kernel_share_of_step", "avg_launch_source") if k in rf}
+    if rf.get("traffic") is not None:
+        short["roofline"]["traffic_source"] = "static: profiles/traffic_<workload>.json (rocprofv3 --pmc passes of this command), not measured in this run"
+    for key in ("cpu_baseline", "cpu_baseline_all_cores"):
+        cb = short.get(key)
+        if cb:
+            short[key] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "flags", "block", "best_of", "b2048", "wide_b512", "wide_b2048") if k in cb}
+            short[key]["sample"] = str(cb.get("sample", ""))[:200]
+    short.pop("roofline_batched", None)
+    return short
 
 
 def strong_leg(workload, args, ctx, steps=40, warmup=5):
@@ -438,9 +568,11 @@ def digest_of(d):
         "ms_per_step": d["ms_per_step"], "realtime_factor": d["config"].get("realtime_factor"),
         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
                                             "launches", "steady_launches", "traffic", "traffic_source", "profiled_ms_per_step", "box_read_GBps",
-                                            "achieved_over_box_read", "box_copy_GBps") if k in rf},
+                                            "achieved_over_box_read", "box_copy_GBps", "avg_launch_source", "kernel_share_of_step", "whole_step_frac",
+                                            "note_ceiling") if k in rf},
         "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches", "error") if k in sc},
-        "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind")},
+        "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind", "flags", "block", "best_of", "b2048",
+                                                                           "wide_b512", "wide_b2048")},
     }
     rt = d.get("config", {}).get("realtime")
     if rt:
@@ -591,10 +723,18 @@ def bench_line(args, ctx):
         launch_bound = 8 * (tail_fft // 2) * tail_p * nin * nout <= (256 << 20) and tail_ratio == args.tail_ratio
         if launch_bound:
             tmax = timed(False)
-            timing_note["profiled_ms_per_step"] = round(1e3 * float(timed(True).item()) / steps, 4)
+            stats = conv.stage_stats()
+            if not stats[-1].get("fused_launches"):
+                # (a block of several launches: the multiply-accumulate's own time from a second pass with its HIP events on.  A block
+                # that IS one launch has no such figure — with the events on the engine takes the separate kernels)
+                timing_note["profiled_ms_per_step"] = round(1e3 * float(timed(True).item()) / steps, 4)
+                bare = stats
+                stats = conv.stage_stats()
+                for s_new, s_old in zip(stats, bare):
+                    s_new["fused_launches"] = s_old.get("fused_launches", 0)
         else:
             tmax = timed(True)
-        stats = conv.stage_stats()
+            stats = conv.stage_stats()
         conv.set_profiling(False)
         finite = bool(torch.isfinite(yb if reduce_path else ys).all().item())
 
@@ -638,7 +778,7 @@ def bench_line(args, ctx):
     check_all_ranks = world > 1 and args.leg and args.scaling == "strong" and not args.no_self_check
     if ((rank == 0 and world == 1) or check_all_ranks) and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(args.workload, hops=16 if check_all_ranks else 64)
+            cpu = cpu_baseline(args.workload, hops=16 if check_all_ranks else 64, protocol=not check_all_ranks)
         except Exception as e:      # the baseline must never take the GPU number down with it
             cpu = {"value": None, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
 
@@ -823,6 +963,7 @@ def bench_line(args, ctx):
                 "realtime": realtime,
                 "extended_layout": extended,
                 "tail_ratio": args.tail_ratio,
+                "reduced_ir_div": IR_DIV if IR_DIV > 1 else None,
             },
             "roofline": {
                 "bound": bound,
@@ -842,6 +983,30 @@ def bench_line(args, ctx):
             },
         }
         if bound == "launch":
+            fused = int(tail.get("fused_launches", 0))
+            if fused:
+                # the whole block — forward transforms, multiply-accumulate, inverse — is ONE launch (hcv_fft_split.hip): that kernel is what
+                # ran, and its duration cannot be had from inside the run without lengthening the chain; profiles/kernel_us.json holds the
+                # rocprofv3 --kernel-trace average of this command (tools/r04_profiles.sh), quoted only while it is consistent with the step
+                hops_blk = max(1, B // Hh)
+                kname = "fused_block_hops_kernel" if hops_blk > 1 else ("fused_block_1x1_kernel" if nin == 1 and parts <= 16 else "fused_block_nx1_kernel")
+                k_us, k_src = None, None
+                try:
+                    rec = json.load(open(os.path.join(ROOT, "profiles", "kernel_us.json"))).get(args.workload)
+                    if rec and rec.get("kernel", "").startswith(kname):
+                        k_us, k_src = float(rec["us"]), rec.get("source")
+                except Exception:
+                    pass
+                step_ms = 1e3 * elapsed / args.steps
+                if k_us is not None and k_us * 1e-3 > step_ms:
+                    k_us, k_src = None, None            # (another box, another clock: never quote a kernel longer than the step it sits in)
+                line["roofline"].update({
+                    "kernel": f"{kname} (one launch per {B}-sample block: {nin} forward transform(s), multiply-accumulate over P={parts}, inverse; FFT {tail['fft_size']})",
+                    "launches": fused, "avg_launch_ms": None if k_us is None else round(k_us * 1e-3, 5), "avg_launch_source": k_src,
+                    "kernel_share_of_step": None if k_us is None else round(k_us * 1e-3 / step_ms, 3),
+                    "achieved": None if k_us is None else round(alg_bytes / (k_us * 1e-6) / 1e9, 1),
+                    "frac": None if k_us is None else round(alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
+                line["roofline"].pop("all_stage_mac_ms", None)
             line["roofline"]["note"] = (f"{live_bytes / 1048576.0:.1f} MiB of live spectra stay in the 256 MiB Infinity Cache: the step is bound by its "
                                         f"kernel launches, not by HBM; `achieved` is cache bandwidth and `frac` is not an HBM fraction")
             if "profiled_ms_per_step" in timing_note:
@@ -849,6 +1014,18 @@ def bench_line(args, ctx):
                                              f"({timing_note['profiled_ms_per_step']} ms per step there: the event records lengthen a launch-bound "
                                              f"chain), value / ms_per_step from the bare pass")
                 line["roofline"]["profiled_ms_per_step"] = timing_note["profiled_ms_per_step"]
+        # SURVEY 8d's ceiling for the reference's stage list (every stage's partitions read once per hop) beside what the engine's
+        # whole-hop step actually moves (one lead partition in place of the head and the shorter stages)
+        sum_p, n_st = sum(p_ for _, p_ in stages), len(stages)
+        bytes_per_sample = 8.0 * nin * (nout + 1) * sum_p + 12.0 * nin * n_st + 4.0 * nout * n_st
+        ceiling = HBM_PEAK_GBS * 1e9 / bytes_per_sample * nout / 1e6
+        line["roofline"]["survey_8d_ceiling_msamples_per_s"] = round(ceiling * world, 1)
+        if bound == "hbm":
+            line["roofline"]["whole_step_frac"] = round(alg_bytes / hops_per_launch * (B / Hh) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
+            if value / world > ceiling:
+                line["roofline"]["note_ceiling"] = (f"value exceeds SURVEY 8d's {ceiling * world:.0f} Msamples/s ceiling: that figure reads every stage's partitions "
+                                                    f"per hop (sum P = {sum_p}); a call made of whole tail hops is ONE uniform convolution over the lead slot and "
+                                                    f"the tail's own partitions (P = {parts}), so fewer bytes move for the same output (parity: self_check)")
         if bound == "hbm":
             try:
                 copy_gbs = box_copy_rate(dev)

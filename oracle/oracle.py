@@ -21,6 +21,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_PATH = os.path.join(_HERE, "libhcv_oracle.so")
 REF_PATH = os.path.join(_HERE, "_ref", "libhisstools_ref.so")
+REF_WIDE_PATH = os.path.join(_HERE, "_ref", "libhisstools_ref_wide.so")      # the same sources under -O3 -mavx2 -mfma (CPU-baseline leg only)
 REF_ROOT = "/root/reference"
 
 _f32p = C.POINTER(C.c_float)
@@ -38,6 +39,10 @@ def build(ref: bool = True) -> None:
 
 def have_ref() -> bool:
     return os.path.exists(REF_PATH)
+
+
+def have_ref_wide() -> bool:
+    return os.path.exists(REF_WIDE_PATH)
 
 
 def _fp(a: np.ndarray):
@@ -80,13 +85,14 @@ def lib(backend: str):
         n.update(conv_set_f32="hcvo_conv_set_f32", conv_set_f64="hcvo_conv_set_f64",
                  conv_process_f32="hcvo_conv_process_f32", conv_process_f64="hcvo_conv_process_f64",
                  rfft="hcvo_rfft_f32", rifft="hcvo_rifft_f32", fft="hcvo_fft_f32")
-    elif backend == "ref":
-        if not os.path.exists(REF_PATH):
+    elif backend in ("ref", "ref_wide"):
+        path = REF_PATH if backend == "ref" else REF_WIDE_PATH
+        if not os.path.exists(path):
             if os.path.isdir(REF_ROOT):
                 build(ref=True)
             else:
-                raise FileNotFoundError(REF_PATH + " (reference build) is not available here")
-        L = C.CDLL(REF_PATH)
+                raise FileNotFoundError(path + " (reference build) is not available here")
+        L = C.CDLL(path)
         n = {k: "ref_" + k for k in (
             "part_new part_delete part_set_fft_size part_set_length part_set_offset part_set_reset_offset "
             "part_set part_reset part_process td_new td_delete td_set_length td_set_offset td_set td_reset "

@@ -3,7 +3,11 @@
 latency modes, call-size patterns and mid-stream control calls.  Runs for --seconds and prints one line per case; exits 1 on
 the first mismatch (with the seed to reproduce it).
 
-    python tests/perf/fuzz_parity.py [--seconds 120] [--seed 1]
+    python tests/perf/fuzz_parity.py [--seconds 120] [--seed 1] [--attribute 20]
+
+--attribute K: after the run, the K worst cases are repeated against a float64 truth (FFT convolution in double precision, where the
+case has one: no mid-stream control calls) and the engine's and the oracle's deviation from it are printed side by side — whose
+rounding an engine-vs-oracle figure consists of.
 
 Control calls: sets before streaming, and for the matrix classes IR swaps, clears and restarts of single pairs mid-stream
 (exact to the sample on both sides) as well as resets of everything; the whole output is compared, transients included."""
@@ -21,7 +25,7 @@ import torch  # noqa: F401,E402  (one HIP runtime for both libraries)
 import hisstools_library_amd as H  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
-TOL = 1.5e-5
+TOL = 1e-5          # SURVEY 8c's stated bound (the worst of 100 000+ cases so far: 8.7e-6, a 32-point stage with ~1700 partitions)
 
 
 def rel(y, r):
@@ -46,7 +50,21 @@ def blocks(rng, total):
         pos += n
 
 
-def one_case(seed):
+def truth64(x, h, n, latency):
+    """float64 FFT convolution of one pair, delayed by the stage layout's latency, first n samples"""
+    m = 1 << int(np.ceil(np.log2(len(x) + len(h))))
+    y = np.fft.irfft(np.fft.rfft(x.astype(np.float64), m) * np.fft.rfft(h.astype(np.float64), m), m)[:n]
+    return np.concatenate([np.zeros(latency), y])[:n]
+
+
+def one_case(seed, attribute=False):
+    """(kind, description, engine-vs-oracle error); with `attribute` a fourth element: (engine vs float64 truth, oracle vs float64
+    truth), or None where the case has mid-stream control calls"""
+    kind, desc, err, both = _one_case(seed, attribute)
+    return (kind, desc, err, both) if attribute else (kind, desc, err)
+
+
+def _one_case(seed, attribute):
     rng = np.random.default_rng(seed)
     kind = rng.choice(["convolver", "convolver", "mono", "partitioned", "parallel"])
     latency = int(rng.integers(0, 3))
@@ -62,7 +80,11 @@ def one_case(seed):
         y = np.zeros(S, np.float32)
         for pos, n in blocks(rng, S):
             y[pos:pos + n] = gpu.run(x[pos:pos + n], n)
-        return kind, f"N={N} L={L} S={S}", rel(y, y_ref)
+        both = None
+        if attribute:
+            t = truth64(x, h, S, N // 2)
+            both = (rel(y, t), rel(y_ref, t))
+        return kind, f"N={N} L={L} S={S}", rel(y, y_ref), both
     if kind == "mono":
         L = int(rng.integers(1, 120000))
         S = int(rng.integers(5000, 150000))
@@ -90,7 +112,11 @@ def one_case(seed):
                 y[p0 + k:p0 + n] = gpu.run(x[p0 + k:p0 + n], n - k)
             else:
                 y[p0:p0 + n] = gpu.run(x[p0:p0 + n], n)
-        return kind, f"latency={latency} L={L} S={S} reset={reset_at}", rel(y, y_ref)
+        both = None
+        if attribute and reset_at < 0:
+            t = truth64(x, h, S, (0, 128, 512)[latency])
+            both = (rel(y, t), rel(y_ref, t))
+        return kind, f"latency={latency} L={L} S={S} reset={reset_at}", rel(y, y_ref), both
     # matrices
     if kind == "parallel":
         nin = nout = int(rng.integers(1, 6))
@@ -104,9 +130,11 @@ def one_case(seed):
     else:
         ref, gpu = O.Convolver(nin, nout, latency), H.Convolver(nin, nout, latency)
         pairs = [(i, o) for i in range(nin) for o in range(nout) if rng.random() < 0.8]
+    loaded = {}
     for (i, o) in pairs:
         L = int(rng.integers(1, 60000))
         h = O.synth_ir((seed + i) % 60, o, L)
+        loaded[(i, o)] = h
         assert ref.set(i, o, h, True) == gpu.set(i, o, h, True), (i, o)
     # mid-stream control calls, applied to both sides at the same sample: IR swaps, clears and restarts of single pairs while
     # the others keep running (exact to the sample on both sides), and resets of everything
@@ -142,17 +170,27 @@ def one_case(seed):
             y[:, a + pos:a + pos + n] = gpu.run(np.ascontiguousarray(xs[:, a + pos:a + pos + n]), nout, n)
     peak = max(float(np.abs(y_ref).max()), 1e-30)
     worst = max(float(np.abs(y[o].astype(np.float64) - y_ref[o].astype(np.float64)).max()) / peak for o in range(nout))
-    return kind, f"{nin}x{nout} latency={latency} pairs={len(pairs)} S={S} events={sum(len(v) for v in events.values())}", worst
+    both = None
+    if attribute and not events:
+        t = np.zeros((nout, S))
+        for (i, o), h in loaded.items():
+            t[o] += truth64(xs[i], h, S, (0, 128, 512)[latency])
+        pk = max(float(np.abs(t).max()), 1e-30)
+        both = (float(np.abs(y - t).max()) / pk, float(np.abs(y_ref - t).max()) / pk)
+    return kind, f"{nin}x{nout} latency={latency} pairs={len(pairs)} S={S} events={sum(len(v) for v in events.values())}", worst, both
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--attribute", type=int, default=0, help="repeat the K worst cases against a float64 truth: engine and oracle side by side")
     args = ap.parse_args()
     t0, seed, n, worst, worst_at = time.time(), args.seed, 0, 0.0, ""
+    top = []
     while time.time() - t0 < args.seconds:
         kind, desc, e = one_case(seed)
         n += 1
+        top = sorted(top + [(e, seed)], reverse=True)[:max(0, args.attribute)]
         if e > worst:
             worst, worst_at = e, f"seed {seed} {kind} {desc.strip()}"
         flag = "" if e <= TOL else "   <-- MISMATCH"
@@ -161,6 +199,13 @@ def main():
             sys.exit(1)
         seed += 1
     print(f"{n} cases, worst relative error {worst:.2e} (tolerance {TOL:.1e}) at {worst_at}")
+    if top:
+        print(f"\nthe {len(top)} worst cases against a float64 truth (relative to the output peak):")
+        print(f"{'seed':>8s} {'engine vs oracle':>17s} {'engine vs truth':>16s} {'oracle vs truth':>16s}  case")
+        for e, sd in top:
+            kind, desc, e2, both = one_case(sd, attribute=True)
+            et, ot = ("      -", "      -") if both is None else (f"{both[0]:.2e}", f"{both[1]:.2e}")
+            print(f"{sd:8d} {e2:17.2e} {et:>16s} {ot:>16s}  {kind} {desc.strip()}" + ("" if both is not None else "  (mid-stream control calls: no closed-form truth)"))
 
 
 if __name__ == "__main__":

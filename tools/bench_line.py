@@ -6,7 +6,7 @@ for l in out.stdout.splitlines():
     if l.startswith("{"):
         d = json.loads(l); r = d["roofline"]
         print(" ".join(sys.argv[1:]), "->", d["value"], "Msamples/s", d["ms_per_step"], "ms/step | tail mac", r["avg_launch_ms"], "ms", r["achieved"], "GB/s",
-              r["kernel"][33:], "| stage mac ms", r["all_stage_mac_ms"])
+              r["kernel"][33:])
         break
 else:
     print("FAILED", out.stdout[-2000:], out.stderr[-3000:])

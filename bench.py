@@ -468,27 +468,27 @@ def flat_scalars(line):
             out[k + "_error"] = str(d["error"])[:160]
             continue
         rf, sc, cb = d.get("roofline") or {}, d.get("self_check") or {}, d.get("cpu_baseline") or {}
-        out.update({k + "_msamples_per_s": d.get("value"), k + "_ms_per_step": d.get("ms_per_step"), k + "_realtime_factor": d.get("realtime_factor"),
+        # (the line must stay under 4 KB: the b2048 / wide-build CPU figures, the 64-sample leg and the realtime factors of the further
+        # workloads are in the side file)
+        out.update({k + "_msamples_per_s": d.get("value"), k + "_ms_per_step": d.get("ms_per_step"),
                     k + "_bound": rf.get("bound"), k + "_mac_frac": rf.get("frac") if rf.get("bound") == "hbm" else None,
                     k + "_mac_ms": rf.get("avg_launch_ms"), k + "_max_rel_err": sc.get("max_rel_err"), k + "_self_check_ok": sc.get("ok"),
-                    k + "_cpu_1core": cb.get("value"), k + "_cpu_1core_b2048": cb.get("b2048"), k + "_cpu_1core_wide": cb.get("wide_b512")})
+                    k + "_cpu_1core": None if cb.get("value") is None else round(cb["value"], 4)})
         if rf.get("bound") == "hbm":
-            out[k + "_mac_over_box_read"] = rf.get("achieved_over_box_read")
             out[k + "_whole_step_frac"] = rf.get("whole_step_frac")
         else:
             out[k + "_kernel"] = str(rf.get("kernel", "")).split(" ")[0]
             out[k + "_kernel_share_of_step"] = rf.get("kernel_share_of_step")
         if rf.get("note_ceiling"):
-            out[k + "_note"] = rf["note_ceiling"][:300]
+            out[k + "_note"] = f"above SURVEY 8d's {rf.get('survey_8d_ceiling_msamples_per_s')} ceiling: whole-hop calls fold the stages' sum P into lead + tail partitions"
         sb = (d.get("realtime") or {}).get("small_blocks") or {}
         hp = (d.get("realtime") or {}).get("host_pointers") or {}
         if hp:
             out[k + "_rt128_p99_ms"] = hp.get("p99_ms")
-        for blk in ("64", "32"):
-            if blk in sb:
-                out[f"{k}_rt{blk}_p50_ms"] = sb[blk].get("p50_ms")
-                out[f"{k}_rt{blk}_p99_ms"] = sb[blk].get("p99_ms")
-                out[f"{k}_rt{blk}_over_budget"] = sb[blk].get("over_budget")
+        if "32" in sb:
+            out[f"{k}_rt32_p50_ms"] = sb["32"].get("p50_ms")
+            out[f"{k}_rt32_p99_ms"] = sb["32"].get("p99_ms")
+            out[f"{k}_rt32_over_budget"] = sb["32"].get("over_budget")
     return out
 
 
@@ -510,23 +510,27 @@ def emit(line):
     sc = cfg.get("self_check") or {}
     keep = {k: cfg.get(k) for k in ("workload", "sharding", "realtime_factor", "pair_msamples_per_s", "ir_load_s", "finite_output", "max_rel_err", "tail_ratio",
                                     "reduced_ir_div")}
-    keep["inputs"] = "SURVEY 8d generator (mt19937-seeded 60 dB decaying-noise IRs of unit norm, uniform audio)"
+    keep["inputs"] = "SURVEY 8d generator (mt19937)"
     keep["self_check_ok"] = sc.get("ok")
-    keep["self_check_against"] = None if not sc else f"{str(sc.get('against', ''))[:60]}..."
-    keep.update(flat)
+    keep["self_check_against"] = None if not sc else str(sc.get("against", "")).split(":")[0]
+    keep.update({k: v for k, v in flat.items() if v is not None})         # (absent = not applicable: a launch-bound leg has no mac_frac)
+    keep["workload"] = str(keep.get("workload", "")).replace(", audio + spectra resident in HBM", "").replace("process block", "block")
     keep["details_file"] = path
+    for k in [k for k, v in keep.items() if v is None or k.endswith("_bound")]:      # (a leg's bound shows in what it carries: mac_frac or kernel)
+        if k not in ("max_rel_err",):
+            keep.pop(k)
     short["config"] = keep
     rf = short.get("roofline") or {}
     short["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
                                                  "launches", "steady_launches", "box_read_GBps", "achieved_over_box_read", "whole_step_frac",
                                                  "survey_8d_ceiling_msamples_per_s", "kernel_share_of_step", "avg_launch_source") if k in rf}
     if rf.get("traffic") is not None:
-        short["roofline"]["traffic_source"] = "static: profiles/traffic_<workload>.json (rocprofv3 --pmc passes of this command), not measured in this run"
+        short["roofline"]["traffic_source"] = "static: profiles/traffic_<workload>.json (rocprofv3 --pmc), not measured in this run"
     for key in ("cpu_baseline", "cpu_baseline_all_cores"):
         cb = short.get(key)
         if cb:
             short[key] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "flags", "block", "best_of", "b2048", "wide_b512", "wide_b2048") if k in cb}
-            short[key]["sample"] = str(cb.get("sample", ""))[:200]
+            short[key]["sample"] = str(cb.get("sample", ""))[:110]
     short.pop("roofline_batched", None)
     return short
 
@@ -1033,7 +1037,9 @@ def bench_line(args, ctx):
                 line["roofline"]["achieved_over_box_copy"] = round(achieved / copy_gbs, 4)
                 import ctypes
                 rd = ctypes.c_double(0.0)
-                if H.load().hcv_box_read_rate(local, 4 << 30, 5, ctypes.byref(rd)) == 0 and rd.value > 0:
+                aid = ctypes.CDLL(os.path.join(ROOT, "tools", "benchaid", "libhcv_benchaid.so"))      # (a bench aid beside the product, built by build())
+                aid.hcv_benchaid_box_read_rate.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+                if aid.hcv_benchaid_box_read_rate(local, 4 << 30, 5, ctypes.byref(rd)) == 0 and rd.value > 0:
                     # (a read-only stream with the kernel's own kind of loads: the ceiling this box has for the multiply-accumulate)
                     line["roofline"]["box_read_GBps"] = round(rd.value, 1)
                     line["roofline"]["achieved_over_box_read"] = round(achieved / rd.value, 4)

@@ -53,7 +53,6 @@ class AudioFileInfo(C.Structure):    # hcv_audiofile_info
 SIGNATURES = {
     "hcv_version": (C.c_char_p, []),
     "hcv_device_count": (C.c_int, []),
-    "hcv_box_read_rate": (C.c_int, [C.c_int, usz, C.c_int, C.POINTER(C.c_double)]),
     "hcv_set_default_device": (C.c_int, [C.c_int]),
     "hcv_get_default_device": (C.c_int, []),
     "hcv_last_error": (C.c_char_p, []),

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using hcv::Engine;
@@ -227,6 +228,7 @@ namespace
         std::vector<uint32_t> sizes;
         bool zeroLatency = false;
         uint32_t tailOffset = 0, largest = 0;
+        int pivot = -1;                          // extended ladder: index of the reference's own tail stage, in front of the rungs (-1: no rungs)
         std::vector<StageCfg> fixedStages;       // the non-resizable PartitionedConvolves, in order
         std::string error;
 
@@ -283,6 +285,7 @@ namespace
             if (ratio < 2) return;
             const uint64_t latency = zeroLatency ? 0 : sizes[0] >> 1;
             uint64_t cur = largest, curOffset = tailOffset;
+            const int ownTail = (int) fixedStages.size();
             while (cur * ratio <= (uint64_t(1) << 20))
             {
                 const uint64_t next = cur * ratio, nextOffset = (next >> 1) - latency;
@@ -296,6 +299,7 @@ namespace
                 cur = next;
                 curOffset = nextOffset;
             }
+            if ((int) fixedStages.size() > ownTail) pivot = ownTail;
             largest = (uint32_t) cur;
             tailOffset = (uint32_t) curOffset;
         }
@@ -308,12 +312,35 @@ namespace
         }
     };
 
+    // The extended far-tail ladder for callers that never heard of it (the reference-shaped constructors): HCV_TAIL_RATIO = 2 / 4 / 8
+    // always continues the partition ladder past the reference's largest FFT, 0 never does; unset = the rule below.
+    constexpr uint32_t kLadderAuto = 0xFFFFFFFFu;           // make_matrix: "what the environment / the rule says"
+    uint32_t env_tail_ratio()
+    {
+        static const int r = std::getenv("HCV_TAIL_RATIO") ? std::atoi(std::getenv("HCV_TAIL_RATIO")) : -1;
+        return r < 0 ? kLadderAuto : (r == 2 || r == 4 || r == 8) ? (uint32_t) r : 0u;
+    }
+    // Unset: ratio 8 where the reference's tail would be HBM-bound — at least 32 partitions of it and at least 1 GiB of tail spectra
+    // over the matrix (c5 703 partitions / 11.8 GB: 8.8 x faster on the ladder, 64 x 64 with 10 s IRs 58 / 15.7 GB: 2.5 x; 64 x 64 with
+    // 2 s IRs, 11 partitions, and the cache-resident one-output engines, which run as ONE launch per block, are faster as they are).
+    constexpr uint64_t kLadderMinParts = 32, kLadderMinBytes = uint64_t(1) << 30;
+
     struct Matrix
     {
         Layout layout;
         uint32_t nin = 1, nout = 1;
         bool diag = false;
         std::unique_ptr<Engine> engine;
+        // what the object was built from, kept for a re-layout (relayout_for)
+        struct { bool zero = false; uint32_t A = 0, B = 0, C = 0, D = 0; int device = 0; uint32_t maxBlock = 0; } args;
+        uint32_t ladder = 0;                // 0: the layout is the caller's; 2 / 4 / 8: that ratio; kLadderAuto: the rule
+        uint64_t laidFor = 0;               // the longest impulse response the current stage list was laid out for
+        bool pristineOnly = false;          // (a shard of a sharded object: re-laid only before its first process call)
+        std::atomic<bool> everProcessed { false };
+        // audio-side calls in flight / a control call replacing the engine of an EMPTY object (the audio side never waits for it:
+        // the block of an empty object is silence either way)
+        std::atomic<int> users { 0 };
+        std::atomic<bool> swapping { false };
         std::vector<uint64_t> mLength, part4Size;
         std::vector<uint8_t> part4Alloc;
         intptr_t resetOffset = -1;
@@ -327,38 +354,86 @@ namespace
             nin = parallel ? numOuts : numIns;
             nout = numOuts;
             diag = parallel;
-            EngineCfg cfg;
-            cfg.nin = nin;
-            cfg.nout = nout;
-            cfg.diag = diag;
-            cfg.device = device;
-            cfg.max_block = maxBlock;
-            if (layout.zeroLatency)
-            {
-                cfg.has_td = true;
-                cfg.td_offset = 0;
-                cfg.td_length = layout.sizes[0] >> 1;                   // TimeDomainConvolve(0, A/2), :240
-                if (cfg.td_length > 2044) cfg.td_length = 2044;         // TimeDomainConvolve::setLength clamp
-            }
-            cfg.stages = layout.fixedStages;
-            StageCfg tl;
-            tl.fft_size = layout.largest;
-            tl.offset = layout.tailOffset;
-            tl.length = 0;
-            tl.capacity = layout.tail_capacity(maxLength);
-            cfg.stages.push_back(tl);
-            std::string err;
-            engine.reset(Engine::create(cfg, &err));
-            if (!engine)
-            {
-                set_error(err);
-                return false;
-            }
+            args.device = device;
+            args.maxBlock = maxBlock;
+            laidFor = maxLength;
+            engine.reset(make_engine(layout, maxLength));
+            if (!engine) return false;
             const size_t pairs = (size_t) nout * (diag ? 1 : nin);
             mLength.assign(pairs, 0);
             part4Size.assign(pairs, maxLength);                          // part4.equal(..., maxLength), :254
             part4Alloc.assign(pairs, maxLength ? 1 : 0);
             return true;
+        }
+
+        uint32_t ratio_for(uint64_t length) const
+        {
+            if (ladder != kLadderAuto) return ladder;
+            const uint32_t e = env_tail_ratio();
+            if (e != kLadderAuto) return e;
+            Layout base;
+            if (!base.build(args.zero, args.A, args.B, args.C, args.D) || base.largest != 16384 || length <= base.tailOffset) return 0;
+            const uint64_t hop = base.largest >> 1, parts = (length - base.tailOffset + hop - 1) / hop;
+            const uint64_t bytes = parts * hop * 8 * (uint64_t) nout * (diag ? 1 : nin);
+            return (parts >= kLadderMinParts && bytes >= kLadderMinBytes) ? 8u : 0u;
+        }
+
+        // An EMPTY object (no pair loaded) asked to hold a longer impulse response than its stage list was laid out for: lay the
+        // ladder out again for that length and replace the engine.  Nothing audible can change — no pair is loaded, the next set()
+        // restarts its pair from silence anyway (MonoConvolve.cpp:139-150) — and a running audio thread never waits: a process call
+        // that meets the swap writes the silence the empty object would have produced.  Once pairs are loaded the stage list stays
+        // (a longer IR then extends the last stage, as the reference extends its tail).  Caller holds stateMutex.
+        void relayout_for(uint64_t length)
+        {
+            if (!ladder || length <= laidFor) return;
+            for (uint64_t l : mLength)
+                if (l) return;
+            if (pristineOnly && everProcessed.load(std::memory_order_acquire)) return;
+            const uint32_t ratio = ratio_for(length);
+            Layout nl;
+            if (!nl.build(args.zero, args.A, args.B, args.C, args.D)) return;
+            nl.extend_tail(length, ratio);
+            laidFor = length;
+            if (nl.fixedStages.size() == layout.fixedStages.size()) return;            // the same stage list
+            uint64_t cap = length;
+            for (uint64_t s : part4Size) cap = std::max(cap, s);
+            std::unique_ptr<Engine> fresh(make_engine(nl, cap));
+            if (!fresh) return;                                                         // (the old layout stays; the error text is set)
+            swapping.store(true, std::memory_order_seq_cst);
+            while (users.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
+            engine.swap(fresh);
+            layout = nl;
+            swapping.store(false, std::memory_order_release);
+            // (`fresh` now holds the old engine: destroyed here, after whatever it still had in flight)
+        }
+
+        Engine *make_engine(const Layout &l, uint64_t maxLength)
+        {
+            EngineCfg cfg;
+            cfg.nin = nin;
+            cfg.nout = nout;
+            cfg.diag = diag;
+            cfg.device = args.device;
+            cfg.max_block = args.maxBlock;
+            if (l.zeroLatency)
+            {
+                cfg.has_td = true;
+                cfg.td_offset = 0;
+                cfg.td_length = l.sizes[0] >> 1;                        // TimeDomainConvolve(0, A/2), :240
+                if (cfg.td_length > 2044) cfg.td_length = 2044;         // TimeDomainConvolve::setLength clamp
+            }
+            cfg.stages = l.fixedStages;
+            cfg.pivot = l.pivot;
+            StageCfg tl;
+            tl.fft_size = l.largest;
+            tl.offset = l.tailOffset;
+            tl.length = 0;
+            tl.capacity = l.tail_capacity(maxLength);
+            cfg.stages.push_back(tl);
+            std::string err;
+            Engine *e = Engine::create(cfg, &err);
+            if (!e) set_error(err);
+            return e;
         }
 
         // MemorySwap::equal on the tail (MemorySwap.h:209-229)
@@ -392,6 +467,7 @@ namespace
             std::lock_guard<std::mutex> g(stateMutex);
             const size_t p = pair(in, out);
             mLength[p] = 0;
+            relayout_for(length);
             engine->set_ir(in, out, nullptr, 0, false);                  // the pair is silent until the next set
             tail_equal(p, length);
             return part4Size[p] == length ? HCV_ERR_NONE : HCV_ERR_MEM_UNAVAILABLE;
@@ -403,7 +479,11 @@ namespace
             std::lock_guard<std::mutex> g(stateMutex);
             const size_t p = pair(in, out);
             mLength[p] = 0;
-            if (requestResize) tail_equal(p, length);
+            if (requestResize)
+            {
+                relayout_for(length);
+                tail_equal(p, length);
+            }
             bool ok = true;
             if (part4Alloc[p])
             {
@@ -421,6 +501,24 @@ namespace
         }
     };
 
+    // An audio-side call's hold on the matrix's engine (see Matrix::relayout_for): `ok` false = a control call is replacing the
+    // engine of this (empty) object right now; the caller delivers the silence it would have computed.
+    struct EngineUse
+    {
+        Matrix &m;
+        bool ok;
+        explicit EngineUse(Matrix &mm) : m(mm)
+        {
+            m.users.fetch_add(1, std::memory_order_seq_cst);
+            ok = !m.swapping.load(std::memory_order_seq_cst);
+            if (!ok) m.users.fetch_sub(1, std::memory_order_seq_cst);
+            else if (!m.everProcessed.load(std::memory_order_relaxed)) m.everProcessed.store(true, std::memory_order_release);
+        }
+        ~EngineUse() { if (ok) m.users.fetch_sub(1, std::memory_order_release); }
+        EngineUse(const EngineUse &) = delete;
+        EngineUse &operator=(const EngineUse &) = delete;
+    };
+
     Matrix *make_matrix(uint32_t numIns, uint32_t numOuts, bool parallel, uint64_t maxLength, bool zeroLatency, uint32_t A, uint32_t B, uint32_t C,
                         uint32_t D, int device, uint32_t maxBlock, std::string *err, uint32_t tailRatio = 0)
     {
@@ -431,7 +529,12 @@ namespace
             set_error(m->layout.error);
             return nullptr;
         }
-        m->layout.extend_tail(maxLength, tailRatio);
+        m->args.zero = zeroLatency; m->args.A = A; m->args.B = B; m->args.C = C; m->args.D = D;
+        m->ladder = tailRatio;
+        m->nin = parallel ? numOuts : numIns;
+        m->nout = numOuts;
+        m->diag = parallel;
+        m->layout.extend_tail(maxLength, m->ratio_for(maxLength));
         if (!m->build(numIns, numOuts, parallel, maxLength, device, maxBlock))
         {
             if (err) *err = tlsError;
@@ -513,10 +616,10 @@ struct hcv_convolver
 
 // ---- MonoConvolve
 
-extern "C" hcv_mono *hcv_mono_create_custom(uintptr_t maxLength, int zeroLatency, uint32_t A, uint32_t B, uint32_t C, uint32_t D, char *err, size_t errlen)
+static hcv_mono *mono_create(uintptr_t maxLength, int zeroLatency, uint32_t A, uint32_t B, uint32_t C, uint32_t D, char *err, size_t errlen, uint32_t ladder)
 {
     std::string e;
-    Matrix *m = make_matrix(1, 1, false, maxLength, zeroLatency != 0, A, B, C, D, gDefaultDevice, 0, &e);
+    Matrix *m = make_matrix(1, 1, false, maxLength, zeroLatency != 0, A, B, C, D, gDefaultDevice, 0, &e, ladder);
     if (!m)
     {
         if (err && errlen)
@@ -531,12 +634,17 @@ extern "C" hcv_mono *hcv_mono_create_custom(uintptr_t maxLength, int zeroLatency
     return h;
 }
 
+extern "C" hcv_mono *hcv_mono_create_custom(uintptr_t maxLength, int zeroLatency, uint32_t A, uint32_t B, uint32_t C, uint32_t D, char *err, size_t errlen)
+{
+    return mono_create(maxLength, zeroLatency, A, B, C, D, err, errlen, 0);        // (the caller's own partitioning: never extended)
+}
+
 extern "C" hcv_mono *hcv_mono_create(uintptr_t maxLength, int latency)
 {
     bool zero;
     uint32_t A, B, C, D;
     latency_sizes(latency, zero, A, B, C, D);
-    return hcv_mono_create_custom(maxLength, zero, A, B, C, D, nullptr, 0);
+    return mono_create(maxLength, zero, A, B, C, D, nullptr, 0, kLadderAuto);
 }
 
 extern "C" void hcv_mono_destroy(hcv_mono *h) { delete h; }
@@ -556,6 +664,8 @@ extern "C" int hcv_mono_process(hcv_mono *h, const float *in, float *temp, float
 {
     (void) temp;                                            // stage summation happens on the device
     if (!h->m->active(0)) return 0;                         // MonoConvolve.cpp:183: out untouched
+    EngineUse use(*h->m);
+    if (!use.ok) return 0;                                  // (the engine of an empty object is being replaced: nothing loaded, out untouched)
     const float *ins[1] = { in };
     float *outs[1] = { out };
     if (!h->m->engine->process(ins, outs, 1, 1, numSamples, accumulate != 0))
@@ -573,7 +683,7 @@ extern "C" hcv_ntomono *hcv_ntomono_create(uint32_t inChans, uintptr_t maxLength
     bool zero;
     uint32_t A, B, C, D;
     latency_sizes(latency, zero, A, B, C, D);
-    Matrix *m = make_matrix(inChans, 1, false, maxLength, zero, A, B, C, D, gDefaultDevice, 0, nullptr);
+    Matrix *m = make_matrix(inChans, 1, false, maxLength, zero, A, B, C, D, gDefaultDevice, 0, nullptr, kLadderAuto);
     if (!m) return nullptr;
     hcv_ntomono *h = new hcv_ntomono();
     h->m.reset(m);
@@ -604,6 +714,12 @@ extern "C" int hcv_ntomono_process(hcv_ntomono *h, const float *const *ins, floa
     (void) temp;
     float *outs[1] = { out };
     const uint32_t act = (uint32_t) std::min<size_t>(activeInChans, h->m->nin);
+    EngineUse use(*h->m);
+    if (!use.ok)
+    {
+        std::memset(out, 0, sizeof(float) * numSamples);    // (an empty object whose engine is being replaced: the sum of no inputs, .cpp:39)
+        return 0;
+    }
     if (!h->m->engine->process(ins, outs, act, 1, numSamples, false))   // zero + accumulate == overwrite with the sum (.cpp:39-42)
     {
         set_error(h->m->engine->last_error());
@@ -634,7 +750,7 @@ static void split_range(uint32_t n, uint32_t parts, uint32_t index, uint32_t &lo
 }
 
 static hcv_convolver *make_sharded(uint32_t numIns, uint32_t numOuts, bool parallel, uint64_t maxLength, bool zeroLatency, uint32_t A, uint32_t B,
-                                   uint32_t C, uint32_t D, const int *devices, int n, uint32_t maxBlock)
+                                   uint32_t C, uint32_t D, const int *devices, int n, uint32_t maxBlock, uint32_t ladder = 0)
 {
     if (!devices || n < 1 || n > 64 || !numOuts)
     {
@@ -676,8 +792,9 @@ static hcv_convolver *make_sharded(uint32_t numIns, uint32_t numOuts, bool paral
             split_range(numOuts, go, r, x.out_lo, x.out_hi);
             if (parallel) { x.in_lo = x.out_lo; x.in_hi = x.out_hi; }
             else split_range(numIns, gi, c, x.in_lo, x.in_hi);
-            x.m.reset(make_matrix(x.in_hi - x.in_lo, x.out_hi - x.out_lo, parallel, maxLength, zeroLatency, A, B, C, D, x.device, maxBlock, nullptr));
+            x.m.reset(make_matrix(x.in_hi - x.in_lo, x.out_hi - x.out_lo, parallel, maxLength, zeroLatency, A, B, C, D, x.device, maxBlock, nullptr, ladder));
             if (!x.m) { ok = false; break; }
+            x.m->pristineOnly = true;        // (the shard pool's jobs hold engine pointers across a block: re-laid before the first block only)
             sh.maxBlock = x.m->engine->max_block();
             ok = hipSetDevice(x.device) == hipSuccess;
             // every device reads the caller's buffers (on the home device) and the row root reads its group's partial blocks
@@ -742,7 +859,7 @@ static bool env_devices(std::vector<int> &out)
         out.push_back((int) v);
         p = (*end == ',') ? end + 1 : end;
     }
-    return out.size() > 1 || (out.size() == 1 && std::getenv("HCV_DEVICES_FORCE"));
+    return out.size() > 1;
 }
 
 extern "C" hcv_convolver *hcv_convolver_create_on(uint32_t numIns, uint32_t numOuts, int latency, int device, uint32_t maxBlock)
@@ -754,10 +871,10 @@ extern "C" hcv_convolver *hcv_convolver_create_on(uint32_t numIns, uint32_t numO
     std::vector<int> devs;
     if (device < 0 && env_devices(devs))
     {
-        if (hcv_convolver *h = make_sharded(numIns, numOuts, false, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), maxBlock)) return h;
+        if (hcv_convolver *h = make_sharded(numIns, numOuts, false, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), maxBlock, kLadderAuto)) return h;
         std::fprintf(stderr, "hisstools_amd: HCV_DEVICES could not be honoured (%s); using one device\n", tlsError.c_str());
     }
-    return wrap(make_matrix(numIns, numOuts, false, 16384, zero, A, B, C, D, device < 0 ? gDefaultDevice : device, maxBlock, nullptr));
+    return wrap(make_matrix(numIns, numOuts, false, 16384, zero, A, B, C, D, device < 0 ? gDefaultDevice : device, maxBlock, nullptr, kLadderAuto));
 }
 
 extern "C" hcv_convolver *hcv_convolver_create(uint32_t numIns, uint32_t numOuts, int latency)
@@ -774,10 +891,10 @@ extern "C" hcv_convolver *hcv_convolver_create_parallel(uint32_t numIO, int late
     std::vector<int> devs;
     if (env_devices(devs))
     {
-        if (hcv_convolver *h = make_sharded(numIO, numIO, true, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), 0)) return h;
+        if (hcv_convolver *h = make_sharded(numIO, numIO, true, 16384, zero, A, B, C, D, devs.data(), (int) devs.size(), 0, kLadderAuto)) return h;
         std::fprintf(stderr, "hisstools_amd: HCV_DEVICES could not be honoured (%s); using one device\n", tlsError.c_str());
     }
-    return wrap(make_matrix(numIO, numIO, true, 16384, zero, A, B, C, D, gDefaultDevice, 0, nullptr));
+    return wrap(make_matrix(numIO, numIO, true, 16384, zero, A, B, C, D, gDefaultDevice, 0, nullptr, kLadderAuto));
 }
 
 extern "C" hcv_convolver *hcv_convolver_create_custom(uint32_t numIns, uint32_t numOuts, int parallel, uintptr_t maxLength, int zeroLatency, uint32_t A,
@@ -1015,6 +1132,7 @@ namespace
 static int sharded_process_host(hcv_convolver *h, const float *const *ins, float *const *outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
     hcv_shards &sh = *h->sh;
+    for (hcv_shard &x : sh.s) x.m->everProcessed.store(true, std::memory_order_release);      // (from here on the shards keep their stage lists)
     HostJob j;
     j.sh = &sh;
     j.ins = ins;
@@ -1121,6 +1239,13 @@ extern "C" int hcv_convolver_process_f32(hcv_convolver *h, const float *const *i
     Matrix &m = *h->m;
     const uint32_t no = (uint32_t) std::min<size_t>(numOuts, m.nout);
     const uint32_t ni = m.diag ? no : (uint32_t) std::min<size_t>(numIns, m.nin);
+    EngineUse use(m);
+    if (!use.ok)
+    {
+        // (an empty object whose engine is being replaced, Matrix::relayout_for: the silence it would have computed)
+        for (uint32_t o = 0; o < no; o++) std::memset(outs[o], 0, sizeof(float) * numSamples);
+        return 0;
+    }
     if (gRegionCount.load(std::memory_order_relaxed) > 0 && no && numSamples)
     {
         const float *din = nullptr, *dout = nullptr;
@@ -1165,10 +1290,16 @@ extern "C" int hcv_convolver_process_f64(hcv_convolver *h, const double *const *
     {
         if (sharded_process_host(h, ip.data(), op.data(), ni, no, numSamples) != 0) return -1;
     }
-    else if (!h->m->engine->process(ip.data(), op.data(), ni, no, numSamples, false))
+    else
     {
-        set_error(h->m->engine->last_error());
-        return -1;
+        EngineUse use(*h->m);
+        if (!use.ok)
+            std::fill(h->tmpOut.begin(), h->tmpOut.end(), 0.f);        // (an empty object whose engine is being replaced: silence)
+        else if (!h->m->engine->process(ip.data(), op.data(), ni, no, numSamples, false))
+        {
+            set_error(h->m->engine->last_error());
+            return -1;
+        }
     }
     for (uint32_t o = 0; o < no; o++)
         for (size_t j = 0; j < numSamples; j++) outs[o][j] = op[o][j];
@@ -1257,6 +1388,7 @@ static int sharded_process_dev(hcv_convolver *h, const float *ins_dev, size_t in
         set_error("sharded Convolver: no peer access between the devices; use the host-pointer entry point (hcv_convolver_process_f32)");
         return -1;
     }
+    for (hcv_shard &x : sh.s) x.m->everProcessed.store(true, std::memory_order_release);
     DevJob j;
     j.sh = &sh;
     j.ins = ins_dev;
@@ -1300,6 +1432,19 @@ extern "C" int hcv_convolver_process_f32_dev(hcv_convolver *h, const float *ins_
     Matrix &m = *h->m;
     const uint32_t no = (uint32_t) std::min<size_t>(numOuts, m.nout);
     const uint32_t ni = m.diag ? no : (uint32_t) std::min<size_t>(numIns, m.nin);
+    EngineUse use(m);
+    if (!use.ok)
+    {
+        // (an empty object whose engine is being replaced, Matrix::relayout_for: the silence it would have computed — on the null
+        // stream, which everything the caller enqueues later is ordered behind)
+        if (no && numSamples && hipMemset2DAsync(outs_dev, sizeof(float) * out_stride, 0, sizeof(float) * numSamples, no, nullptr) != hipSuccess)
+        {
+            (void) hipGetLastError();
+            set_error("process_f32_dev: could not clear the output block");
+            return -1;
+        }
+        return 0;
+    }
     if (!m.engine->process_dev(ins_dev, (int64_t) in_stride, outs_dev, (int64_t) out_stride, ni, no, numSamples, sync != 0))
     {
         set_error(m.engine->last_error());
@@ -1320,6 +1465,8 @@ extern "C" int hcv_convolver_synchronize(hcv_convolver *h)
             }
         return 0;
     }
+    EngineUse use(*h->m);
+    if (!use.ok) return 0;          // (an empty object whose engine is being replaced: nothing of the caller's is in flight on it)
     if (!h->m->engine->synchronize())
     {
         set_error(h->m->engine->last_error());
@@ -1459,82 +1606,6 @@ extern "C" int hcv_device_count(void)
         return 0;
     }
     return n;
-}
-
-// The box's own read ceiling (MI355X extension, measurement aid): a grid-stride sum over `bytes` of device memory with the loads the
-// multiply-accumulate kernel streams its IR spectra with (nontemporal 16-byte loads, 768 workgroups of 256 threads, eight loads in flight
-// per thread), timed with HIP events, best of `reps`.  bench.py prints it beside the roofline fraction: boxes differ by several per cent.
-namespace
-{
-    __global__ __launch_bounds__(256) void stream_read_kernel(const float4 *__restrict__ p, size_t n4, float *__restrict__ sink)
-    {
-        typedef float v4 __attribute__((ext_vector_type(4)));
-        const size_t stride = (size_t) gridDim.x * blockDim.x;
-        size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-        float acc = 0.f;
-        for (; i + 7 * stride < n4; i += 8 * stride)
-        {
-            v4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p + i + k * stride));
-#pragma unroll
-            for (int k = 0; k < 8; k++) acc += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-        }
-        for (; i < n4; i += stride)
-        {
-            const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p + i));
-            acc += (v.x + v.y) + (v.z + v.w);
-        }
-        if (acc == 123456.789f) *sink = acc;           // (keeps the loads alive; never true for a zeroed buffer)
-    }
-}
-
-extern "C" int hcv_box_read_rate(int device, size_t bytes, int reps, double *gbs)
-{
-    if (!gbs || bytes < (1u << 20) || reps < 1)
-    {
-        set_error("hcv_box_read_rate: bad arguments");
-        return -1;
-    }
-    int prev_dev = 0;
-    (void) hipGetDevice(&prev_dev);
-    if (hipSetDevice(device < 0 ? gDefaultDevice : device) != hipSuccess)
-    {
-        (void) hipGetLastError();
-        set_error("hcv_box_read_rate: no such device");
-        return -1;
-    }
-    void *buf = nullptr;
-    float *sink = nullptr;
-    hipEvent_t a = nullptr, b = nullptr;
-    int rc = -1;
-    float best = 1e30f;
-    const size_t n4 = bytes / 16;
-    if (hipMalloc(&buf, n4 * 16) != hipSuccess || hipMalloc(&sink, sizeof(float)) != hipSuccess) goto out;
-    if (hipMemset(buf, 0, n4 * 16) != hipSuccess || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) goto out;
-    for (int r = 0; r < reps + 1; r++)
-    {
-        if (hipEventRecord(a, nullptr) != hipSuccess) goto out;
-        hipLaunchKernelGGL(stream_read_kernel, dim3(768), dim3(256), 0, nullptr, static_cast<const float4 *>(buf), n4, sink);
-        if (hipEventRecord(b, nullptr) != hipSuccess || hipEventSynchronize(b) != hipSuccess) goto out;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) goto out;
-        if (r > 0 && ms < best) best = ms;              // (the first pass warms the TLBs)
-    }
-    *gbs = (double) (n4 * 16) / ((double) best * 1e-3) / 1e9;
-    rc = 0;
-out:
-    if (a) (void) hipEventDestroy(a);
-    if (b) (void) hipEventDestroy(b);
-    if (buf) (void) hipFree(buf);
-    if (sink) (void) hipFree(sink);
-    if (rc != 0)
-    {
-        (void) hipGetLastError();
-        set_error("hcv_box_read_rate: HIP error");
-    }
-    (void) hipSetDevice(prev_dev);
-    return rc;
 }
 
 extern "C" int hcv_set_default_device(int device)

@@ -69,6 +69,8 @@ namespace hcv
         std::vector<StageCfg> stages;
         int device = -1;            // -1 = current default (HCV_DEVICE env or 0)
         uint32_t max_block = 0;     // 0 = default (HCV_MAX_BLOCK env or 32768)
+        int pivot = -1;             // >= 0: the stages behind this index are far-tail rungs of the extended ladder (hcv_api.hip: Layout::extend_tail):
+                                    // whole-hop mode runs on stage `pivot` and the rungs keep their own (deferred) schedule beside it.  -1 = the last stage
     };
 
     struct StageStats
@@ -197,8 +199,7 @@ namespace hcv
         void collect_events();
         // exact per-pair restart (hcv_ghost.hip): ghost spectra of the input before the restart, the pair's pending output retired
         struct GhostEvent;
-        bool mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream,
-                 bool fuse_reduce = false);
+        bool mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream);
         bool retire_pair(size_t pair);
         bool make_ghost_event(const std::vector<size_t> &pairs);
         bool rebuild_ghost_tables();
@@ -241,8 +242,6 @@ namespace hcv
         uint32_t mPipeRun = 0;              // consecutive pipelined single-hop blocks before the one being enqueued
         int64_t mPipeRecA = -1, mPipeRecB = -1;   // the last two pipelined blocks that recorded an end event (sequence numbers)
         uint32_t mPipeSince = 0;            // pipelined blocks since the pipe stream was last lined up behind the main stream
-        hipStream_t mPipeStream2 = nullptr; // three-deep pipeline: the MAC (+ reduction) of a pipelined block; its inverse stays on the main stream
-        hipEvent_t mEvPipeB[2] = { nullptr, nullptr };
         bool mPrevPipe2 = false;
         bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
@@ -268,7 +267,8 @@ namespace hcv
         // (head + shorter stages) is one extra zero-latency partition of it
         // (the spectrum of IR[0 : Mlast) lives in the lead slot of the last stage's spectra, Stage::lead)
         bool mTailHead = false;             // the layout allows whole-hop blocks (contiguous zero-latency ladder, or a lone FFT stage)
-        bool mLeadSlot = false;             // ... of the first kind: the last stage carries the lead slot (Stage::lead)
+        bool mLeadSlot = false;             // ... of the first kind: the pivot stage carries the lead slot (Stage::lead)
+        size_t mPivot = 0;                  // the stage whole-hop blocks run on: the last one, or the last in front of the extended ladder's rungs
         bool mTailHeadPrev = false;         // the previous block ran in whole-hop mode
         float *mTaps = nullptr;
         long long *mTdValid = nullptr;

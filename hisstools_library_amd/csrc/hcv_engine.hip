@@ -29,10 +29,9 @@ static std::map<std::pair<int, int>, float2 *> gTwTables;
 // A single-stage engine without a time-domain head (a plain PartitionedConvolve) has nothing to overlap within a block:
 // its kernels form one dependency chain, and every cross-stream hop of that chain costs microseconds.  It runs every
 // kernel on one stream (measured on config 2: 0.070 -> 0.052 ms per 8192-sample block; the four-stage config 3 loses
-// 30 % without the overlap, so multi-stage engines keep their streams).  HCV_ONE_STREAM = 0 / 1 forces the choice.
+// 30 % without the overlap, so multi-stage engines keep their streams).
 static bool one_stream_mode(const EngineCfg &cfg)
 {
-    if (const char *env = std::getenv("HCV_ONE_STREAM")) return std::atoi(env) != 0;
     return cfg.stages.size() == 1 && !cfg.has_td;
 }
 
@@ -189,8 +188,6 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipStreamCreateWithFlags(&mPipeStream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipe[k], hipEventDisableTiming));
     for (int k = 0; k < 4; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeEnd[k], hipEventDisableTiming));
-    HCV_TRY(hipStreamCreateWithFlags(&mPipeStream2, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeB[k], hipEventDisableTiming));
     HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
 
     // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
@@ -228,6 +225,10 @@ bool Engine::init(const EngineCfg &cfg)
     // Whole-hop mode (see enqueue_chunk): needs the zero-latency ladder — head at [0, a), every shorter stage continuing
     // where the previous coverage ends, the last stage starting exactly one of its hops in.  The last stage then keeps the
     // spectrum of IR[0 : its hop) in a lead slot in front of every pair's partitions (Stage::lead).
+    // With far-tail rungs behind it (EngineCfg::pivot, the extended ladder) the stage in front of them takes that role: whole-hop blocks
+    // are whole hops of THAT stage, and the rungs keep their own schedule beside it (enqueue_chunk).
+    mPivot = mCfg.stages.empty() ? 0 : mCfg.stages.size() - 1;
+    if (mCfg.pivot >= 0 && (size_t) mCfg.pivot < mCfg.stages.size()) mPivot = (size_t) mCfg.pivot;
     if (mCfg.stages.size() >= 2 || (mCfg.has_td && !mCfg.stages.empty()))
     {
         static const bool allow = !(std::getenv("HCV_TAIL_HEAD") && std::atoi(std::getenv("HCV_TAIL_HEAD")) == 0);
@@ -238,15 +239,16 @@ bool Engine::init(const EngineCfg &cfg)
             ok = ok && mCfg.td_offset == 0 && mCfg.td_length > 0;
             end = mCfg.td_length;
         }
-        for (size_t k = 0; ok && k + 1 < mCfg.stages.size(); k++)
+        for (size_t k = 0; ok && k < mPivot; k++)
         {
             const StageCfg &sc = mCfg.stages[k];
             ok = sc.offset == end && sc.length > 0;
             end = sc.offset + sc.length;
         }
-        const StageCfg &tl = mCfg.stages.back();
+        const StageCfg &tl = mCfg.stages[mPivot];
         ok = ok && tl.offset == end && tl.offset == tl.fft_size / 2 && !is_big_fft(ilog2(tl.fft_size));
         mTailHead = mLeadSlot = ok;
+        if (!ok) mPivot = mCfg.stages.size() - 1;
     }
     else if (mCfg.stages.size() == 1 && !mCfg.has_td && !is_big_fft(ilog2(mCfg.stages[0].fft_size)))
     {
@@ -260,7 +262,7 @@ bool Engine::init(const EngineCfg &cfg)
     {
         Stage *st = new Stage();
         st->cfg = sc;
-        st->lead = (mLeadSlot && &sc == &mCfg.stages.back()) ? 1 : 0;
+        st->lead = (mLeadSlot && &sc == &mCfg.stages[mPivot]) ? 1 : 0;
         st->log2n = ilog2(sc.fft_size);
         st->N = sc.fft_size;
         st->M = sc.fft_size / 2;
@@ -271,7 +273,7 @@ bool Engine::init(const EngineCfg &cfg)
         fft_split_prepare(st->log2n);               // (tables of the residue-split transforms, hcv_fft_split.hip)
         if (!alloc_stage(*st)) return false;
     }
-    if (mLeadSlot) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages.back()->M));
+    if (mLeadSlot) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages[mPivot]->M));
     // Head through the FFT: the head's taps (<= one hop of the first FFT stage, MonoConvolve.cpp:235-240) form one extra,
     // zero-latency partition of that stage, whose input spectra exist anyway.  Used for hop-aligned blocks of larger
     // matrices, where the direct-form FIR would cost more than all FFT-stage MACs together; ragged blocks and small
@@ -280,8 +282,7 @@ bool Engine::init(const EngineCfg &cfg)
     {
         const Stage &s0 = *mStages[0];
         const uint64_t lim = mCfg.td_length ? mCfg.td_length : 2044;
-        static const bool allow = !(std::getenv("HCV_HEAD_FFT") && std::atoi(std::getenv("HCV_HEAD_FFT")) == 0);
-        if (allow && lim <= s0.M && !is_big_fft(s0.log2n) && (size_t) mCfg.nout * mNinAlloc >= 16)
+        if (lim <= s0.M && !is_big_fft(s0.log2n) && (size_t) mCfg.nout * mNinAlloc >= 16)
         {
             mHeadFFT = true;
             HCV_TRY(hipMalloc(&mHeadSpec, sizeof(float2) * pairs * s0.M));
@@ -314,10 +315,10 @@ bool Engine::alloc_stage(Stage &st)
     st.Y = st.Yq[0];
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
-    HCV_TRY(hipMalloc(&st.tickets, sizeof(unsigned) * (kMacTickets + 2)));
-    HCV_TRY(hipMemset(st.tickets, 0, sizeof(unsigned) * (kMacTickets + 2)));
     if (mCfg.nout == 1 && (st.log2n == 14 || st.log2n == 12))
     {
+        HCV_TRY(hipMalloc(&st.coop_bar, sizeof(unsigned) * 2));
+        HCV_TRY(hipMemset(st.coop_bar, 0, sizeof(unsigned) * 2));
         HCV_TRY(hipMalloc(&st.coop_flags, sizeof(unsigned long long) * (kFusedMacTasks + kFusedFwdTasks)));
         HCV_TRY(hipMemset(st.coop_flags, 0, sizeof(unsigned long long) * (kFusedMacTasks + kFusedFwdTasks)));
     }
@@ -376,7 +377,7 @@ void Engine::free_stage(Stage &st)
         st.mac_done[k] = nullptr;
     }
     if (st.hv) (void) hipFree(st.hv);
-    if (st.tickets) (void) hipFree(st.tickets);
+    if (st.coop_bar) (void) hipFree(st.coop_bar);
     if (st.coop_flags) (void) hipFree(st.coop_flags);
     if (st.gh_start) (void) hipFree(st.gh_start);
     if (st.gh_ent) (void) hipFree(st.gh_ent);
@@ -410,7 +411,6 @@ Engine::~Engine()
     DeviceGuard dg(mDevice);
     if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);
     if (mPipeStream) (void) hipStreamSynchronize(mPipeStream);
-    if (mPipeStream2) (void) hipStreamSynchronize(mPipeStream2);
     if (mInStream) (void) hipStreamSynchronize(mInStream);
     if (mTdStream) (void) hipStreamSynchronize(mTdStream);
     for (Stage *st : mStages)
@@ -462,11 +462,9 @@ Engine::~Engine()
     if (mStageTailHead) (void) hipFree(mStageTailHead);
     if (mCtlStream) (void) hipStreamDestroy(mCtlStream);
     if (mPipeStream) (void) hipStreamDestroy(mPipeStream);
-    if (mPipeStream2) (void) hipStreamDestroy(mPipeStream2);
     for (int k = 0; k < 2; k++)
     {
         if (mEvPipe[k]) (void) hipEventDestroy(mEvPipe[k]);
-        if (mEvPipeB[k]) (void) hipEventDestroy(mEvPipeB[k]);
     }
     for (int k = 0; k < 4; k++)
         if (mEvPipeEnd[k]) (void) hipEventDestroy(mEvPipeEnd[k]);
@@ -632,10 +630,8 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     // the old buffers' last readers are behind mEvSnap: the frees are ordered after it on the control stream (the first
     // buffers of a stage came from hipMalloc in init and are parked until the engine goes: hipFree would stall the device)
     (void) hipStreamWaitEvent(mCtlStream, mEvSnap, 0);
-    static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
-    if (old_ctl || !async)
+    if (old_ctl)
     {
-        if (!async) (void) hipEventSynchronize(mEvSnap);
         ctl_free(oHs);
         ctl_free(oX);
     }
@@ -644,7 +640,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
         mParked.push_back(oHs);
         mParked.push_back(oX);
     }
-    st.hs_ctl = async;
+    st.hs_ctl = true;
     return true;
 }
 
@@ -679,24 +675,15 @@ static hipMemPool_t ctl_pool(int device)
 
 hipError_t Engine::ctl_alloc(void **p, size_t bytes)
 {
-    static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
-    if (async)
-    {
-        hipMemPool_t pool = ctl_pool(mDevice);
-        const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);
-        if (e == hipSuccess) return e;
-        (void) hipGetLastError();
-        return e;
-    }
-    return hipMalloc(p, bytes);
+    hipMemPool_t pool = ctl_pool(mDevice);
+    const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);
+    if (e != hipSuccess) (void) hipGetLastError();
+    return e;
 }
 
 void Engine::ctl_free(void *p)
 {
-    static const bool async = !(std::getenv("HCV_CTL_ASYNC_ALLOC") && std::atoi(std::getenv("HCV_CTL_ASYNC_ALLOC")) == 0);
-    if (!p) return;
-    if (async) (void) hipFreeAsync(p, mCtlStream);
-    else (void) hipFree(p);
+    if (p) (void) hipFreeAsync(p, mCtlStream);
 }
 
 // staging room of a stage for one pair's spectra (grown with the stage's capacity); control thread only
@@ -784,7 +771,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
     }
     if (mLeadSlot)
     {
-        Stage &tl = *mStages.back();
+        Stage &tl = *mStages[mPivot];
         const uint64_t first = std::min<uint64_t>(len, tl.M);
         HCV_TRY(launch_rfft_ir(tl.log2n, first ? dsrc : mHist, (long long) first, 1, mStageTailHead, tl.tw, &tl.big_ctl, mCtlStream));
     }
@@ -822,7 +809,7 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
             any = any || taps;
         }
         if (mLeadSlot)
-            HCV_TRY(hipMemcpyAsync(mStages.back()->Hs + pair * mStages.back()->hstride(), mStageTailHead, sizeof(float2) * mStages.back()->M,
+            HCV_TRY(hipMemcpyAsync(mStages[mPivot]->Hs + pair * mStages[mPivot]->hstride(), mStageTailHead, sizeof(float2) * mStages[mPivot]->M,
                                    hipMemcpyDeviceToDevice, mStream));
         mLoaded[pair] = any ? 1 : 0;
         __atomic_store_n(&mPending[pair], (uint8_t) 1, __ATOMIC_RELEASE);           // set() always ends in reset()

@@ -16,14 +16,14 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
     HCV_BLOCK_LOCALS(blk);
     const hipStream_t sS = serial ? mStream : st.stream;
     if (st.pre_hop < 0 || st.bg_launched >= st.bg_slices) return true;
-    // Slices come due a little AHEAD of the even grid (HCV_BG_LEAD samples, default 192; stages of at least 4096 points): on the grid the
+    // Slices come due a little AHEAD of the even grid (kBgLead = 192 samples; stages of at least 4096 points): on the grid the
     // tail's slice k falls due at sample k M / 16 = a multiple of 512, i.e. in the very call that also carries the hop boundaries of the
     // 256- and 1024-point stages — with 32-sample calls of the 64 x 64 / 10 s engine every sixteenth call took 0.48 ms (a 0.2 ms tail
     // slice on top of two boundaries) against 0.075 ms for its neighbours.  192 samples early the slice lands in a plain call at 32
     // and 64 samples per call (the 10th of 16, the 5th of 8) and, at 128 samples per call, in the call BEFORE the one with the
     // 1024-point stage's boundary (p99 0.45 -> 0.28 ms there; 64 samples of lead, enough for the smaller calls, is not).
-    static const long long lead_env = std::getenv("HCV_BG_LEAD") ? std::atoll(std::getenv("HCV_BG_LEAD")) : 192;
-    const long long lead = st.M >= 2048 ? std::min<long long>(lead_env, (long long) st.M / (2 * std::max(1, st.bg_slices))) : 0;
+    constexpr long long kBgLead = 192;
+    const long long lead = st.M >= 2048 ? std::min<long long>(kBgLead, (long long) st.M / (2 * std::max(1, st.bg_slices))) : 0;
     const long long into = (long long) (n0 + B) - st.pre_hop * (long long) st.M + lead;
     int due = boundary ? st.bg_slices : (int) std::min<long long>(st.bg_slices, std::max<long long>(0, into * st.bg_slices / (long long) st.M));
     const int per = (st.bg_parts + st.bg_slices - 1) / st.bg_slices;
@@ -92,18 +92,18 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     HCV_BLOCK_LOCALS(blk);
     Stage &st = *mStages[si];
     const hipStream_t sS = serial ? mStream : st.stream;
-    if (whole_hops && entering)
+    if (whole_hops && entering && si <= last)
     {
-        // what this stage has pending duplicates what the last stage's whole-hop convolution now computes (for the last stage
+        // what this stage has pending duplicates what the pivot stage's whole-hop convolution now computes (for the pivot stage
         // itself: its own partitions' result for the block's first hop): drop it — after the emit that may still be reading
-        // it — together with any plan of a deferred accumulation
+        // it — together with any plan of a deferred accumulation.  (The rungs of an extended ladder, si > last, go on as they were.)
         HCV_TRY(wt(sS, mEvEmit[q ^ 1]));
         HCV_TRY(hipMemsetAsync(st.timeline, 0, sizeof(float) * mCfg.nout * st.tl_len, sS));
         HCV_TRY(rec(st.done[q], sS));
         HCV_TRY(wt(mStream, st.done[q]));
         st.pre_hop = -1;
     }
-    if (whole_hops && si != last) return true;
+    if (whole_hops && si < last) return true;
     blk.src.timeline[blk.src.count] = st.timeline;              // the ring may still hold hops of earlier calls
     blk.src.stride[blk.src.count] = st.tl_len;
     blk.src.mask[blk.src.count] = st.tl_len - 1;
@@ -116,10 +116,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     if (!st.P && !head_here && !tail_head_here) return true;
     const long long h_first = n0 / st.M;
     const int T = (int) ((n0 + B) / st.M - h_first);
-    if (leaving && st.P && h_first >= 1 && !catch_up_stage(blk, st, h_first, /* rebuild_spectra */ si != last)) return false;
+    if (leaving && si <= last && st.P && h_first >= 1 && !catch_up_stage(blk, st, h_first, /* rebuild_spectra */ si != last)) return false;
     // Deferred mode: calls shorter than the hop (real-time block sizes) with more than one partition.
     static const bool allow_defer = !(std::getenv("HCV_DEFER") && std::atoi(std::getenv("HCV_DEFER")) == 0);
-    static const int slices_env = std::getenv("HCV_BG_SLICES") ? std::atoi(std::getenv("HCV_BG_SLICES")) : kBgSlices;
     if (T <= 0)
     {
         if (st.pre_hop >= 0 && (!full_matrix || st.pre_hop != h_first)) st.pre_hop = -1;     // the plan no longer fits what is being processed
@@ -128,7 +127,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             // no plan for the hop in progress (the first small call after large ones, or control work dropped it): make it
             // now — the frames it needs are complete — so that the boundary does not pay the whole accumulation inline
             st.bg_parts = (int) std::min<long long>(st.P - 1, h_first);
-            st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
+            st.bg_slices = std::max(1, std::min(kBgSlices, st.bg_parts));
             st.bg_launched = 0;
             st.pre_hop = h_first;
         }
@@ -159,13 +158,13 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             hipError_t fe;
             if (fuse_hops)
                 fe = launch_fused_block_hops(st.log2n, mHist, hmask, blk.din, n0, h_first, T, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
-                                             st.tickets + kMacTickets, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
+                                             st.coop_bar, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
             else if (rows_in == 1 && p_live <= 16)
                 fe = launch_fused_block_1x1(st.log2n, mHist, hmask, blk.din, n0, h_first, st.X, (int) st.R, st.Hs, (int) p_live, h_mac, st.Y, blk.dout, st.tw,
-                                            st.tickets + kMacTickets, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
+                                            st.coop_bar, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
             else
                 fe = launch_fused_block_nx1(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, st.X, (int) st.R, st.Hs,
-                                            (long long) st.hstride(), (int) p_live, h_mac, st.Y, blk.dout, st.tw, st.tickets + kMacTickets, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
+                                            (long long) st.hstride(), (int) p_live, h_mac, st.Y, blk.dout, st.tw, st.coop_bar, st.coop_flags, st.coop_arrived, &st.coop_seq, sS);
             if (fe == hipSuccess)
             {
                 st.launches++;
@@ -187,7 +186,8 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         }
     }
 
-    if (direct_in && blk.pipe2)
+    const bool direct_here = direct_in && si == last;       // (a rung of the extended ladder reads its frames from the history ring)
+    if (direct_here && blk.pipe2)
     {
         // two-stream pipeline of a small engine: this block's transforms run on the pipe stream, beside the previous block's
         // multiply-accumulate and inverse on the main stream.  The ring slots they write are read by the MAC of the block two
@@ -199,12 +199,11 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         // An event record costs the recording stream about 4 us here, so a pipelined block records ONE end event (mEvPipeEnd, a ring of
         // four) in place of st.done[q]; the first block after the pipe stream was lined up behind the main stream (mEvSerial) needs
         // no wait at all.
-        static const bool far_wait = !(std::getenv("HCV_PIPE_DEPTH") && std::atoi(std::getenv("HCV_PIPE_DEPTH")) < 2);
-        // In a run of single-hop blocks only every second block records its end (HCV_PIPE_SPARSE = 0: every block): the transforms of
+        // In a run of single-hop blocks only every second block records its end: the transforms of
         // block n need the MAC of block n - 4 done, and the newer of the last two recorded ends that is not younger than n - 3 — or,
         // failing that, the latest one — covers it.
         const long long cur = (long long) mPipeSeq;
-        const bool far = far_wait && T == 1 && mPipeRun >= 3 && mPipeSince >= 3 && st.Tmax >= 2;
+        const bool far = T == 1 && mPipeRun >= 3 && mPipeSince >= 3 && st.Tmax >= 2;
         blk.pipe_far = far;
         if (mPipeSince >= 2 && mPipeRecA >= 0)      // (blocks from before the line-up are behind mEvSerial, which this stream has waited for)
         {
@@ -215,19 +214,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw,
                                           mPipeStream));
         HCV_TRY(hipEventRecord(mEvPipe[q], mPipeStream));
-        // three deep (HCV_PIPE3, default OFF — measured slower): the MAC and its reduction on a stream of their own, the inverse alone on
-        // the main stream, so that the block rate would be the longest of the three parts instead of MAC + reduction + inverse.  The
-        // main stream still ends every block (its inverse waits for the MAC, which waited for the transforms), so everything that
-        // orders itself behind the main stream — synchronize(), control work, the next unpipelined block — is behind the whole block
-        // as before; Y is double buffered by block parity, and the inverse of block n - 1 ends (st.done) before this block's
-        // transforms, hence its MAC, start.  Correct (the parity / restart / steady-state suites pass with it forced on every small
-        // engine) but the third hand-over costs more than the two-deep pipeline's remaining serial part: c3 0.0311 -> 0.039-0.041 ms
-        // per block (13.5 | 12 | 8.5 us of kernels), c1 0.0233 -> 0.0356 forced (profiles/r02d_pipe3_ab.txt).
-        static const bool pipe3 = std::getenv("HCV_PIPE3") && std::atoi(std::getenv("HCV_PIPE3")) != 0;
-        if (pipe3 && mPipeStream2 && tail_head_here && blk.direct_out) sM = mPipeStream2;
         HCV_TRY(hipStreamWaitEvent(sM, mEvPipe[q], 0));
     }
-    else if (direct_in)
+    else if (direct_here)
     {
         // the transforms read the caller's block themselves and file it in the history ring: no scatter, no wait for one
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, sF));
@@ -271,25 +260,15 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const int Pw = (int) (st.P + st.lead);
         const long long h_mac = h_first - (long long) (1 - st.lead);
         const long long p_live = std::max<long long>(0, std::min<long long>(Pw, h_mac + T));
-        // (HCV_SERIAL_KSPLIT = n caps a small, serial engine at n slices, which the inverse then adds up itself — one launch
-        // less; measured on the 8 -> 1 workload it loses: the MAC wants its 30 slices, 10.6 -> 20 us at 8.  Off by default.)
-        static const int serial_ksplit = std::getenv("HCV_SERIAL_KSPLIT") ? std::atoi(std::getenv("HCV_SERIAL_KSPLIT")) : 0;
-        size_t ks_cap = std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M));
-        if (serial && serial_ksplit > 0) ks_cap = std::min<size_t>(ks_cap, (size_t) serial_ksplit);
+        const size_t ks_cap = std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M));
         MacShape sw = mac_shape(st, /* P */ (int) p_live, /* Pcap */ st.hparts(),
                                 /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
                                 /* T */ T, /* max_ksplit */ (int) ks_cap);
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
         MacPlan pw;
         mac_plan(sw, pw);
-        // HCV_FUSE_REDUCE = 1 (default OFF — measured slower): a small engine's split-K slices added up by the MAC launch itself (its
-        // last workgroup per bin block, in reduce_partials' order: bit-identical), one launch less in a chain of four.  The
-        // publication costs more than the launch it saves: 8 -> 1, MAC 7.7 us + reduction 4.1 against 13.9 fused with write-through
-        // stores and L1-bypassing loads, 26 with agent-scope fences
-        static const bool fuse_env = std::getenv("HCV_FUSE_REDUCE") && std::atoi(std::getenv("HCV_FUSE_REDUCE")) != 0;
-        const bool fused = fuse_env && serial && st.tickets && mac_can_fuse_reduce(pw);
         if (!begin_event()) return false;
-        if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM, fused)) return false;
+        if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM)) return false;
         if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
         st.launches++;
         st.hops += (uint64_t) T;
@@ -299,17 +278,10 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         st.last_parts = (uint32_t) p_live;
         if (!wcheck && pw.nt) st.steady_launches++;
         const long long w_elems = (long long) T * nout_act * st.M;
-        static const int fold_max_w = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
         // (every workgroup of a residue-split inverse stages the WHOLE spectrum: it takes the one summed slice)
-        const bool fold_w = !fused && pw.ksplit > 1 && pw.ksplit <= fold_max_w && ((long long) T * nout_act >= 16 || serial) &&
+        const bool fold_w = pw.ksplit > 1 && pw.ksplit <= kFoldMax && ((long long) T * nout_act >= 16 || serial) &&
                             !(blk.direct_out && fft_split_applies(st.log2n, T * (int) nout_act));
-        if (!fold_w && !fused) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sM != sI ? sM : sI));
-        if (sM != sI)
-        {
-            // (three-deep pipeline: hand the reduced spectra over to the inverse on the main stream)
-            HCV_TRY(hipEventRecord(mEvPipeB[q], sM));
-            HCV_TRY(hipStreamWaitEvent(sI, mEvPipeB[q], 0));
-        }
+        if (!fold_w) HCV_TRY(launch_reduce_partials(st.Y, pw.ksplit, w_elems, w_elems, sI));
         if (blk.direct_out)
         {
             // the inverse delivers the block itself; "emit" of this block = the end of this launch
@@ -325,8 +297,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         if (blk.pipe2)
         {
             // (serial blocks record no events otherwise; in a run of single-hop blocks every second one does)
-            static const bool sparse = !(std::getenv("HCV_PIPE_SPARSE") && std::atoi(std::getenv("HCV_PIPE_SPARSE")) == 0);
-            if (!(sparse && blk.pipe_far) || (long long) mPipeSeq - mPipeRecA >= 2)
+            if (!blk.pipe_far || (long long) mPipeSeq - mPipeRecA >= 2)
             {
                 HCV_TRY(hipEventRecord(mEvPipeEnd[mPipeSeq & 3], sI));
                 mPipeRecB = mPipeRecA;
@@ -386,10 +357,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             // them all one after the other: 85 us per boundary, for 4 MB of spectra, twice in the call that carries the boundaries of
             // two stages.  Partition 0 is therefore split up to seven ways, its k-slices going into the slots BEHIND the background
             // slices' (Ypre has kBgSlices + kBoundarySlices of them), and the inverse adds all the slots up as it loads them — no launch
-            // for the slices' total either (HCV_BOUNDARY_KSPLIT = 1: total into slot 0 and ONE slice into Y, as before round 3).
-            static const int bks = std::getenv("HCV_BOUNDARY_KSPLIT") ? std::atoi(std::getenv("HCV_BOUNDARY_KSPLIT")) : 7;
-            boundary_split = !is_big_fft(st.log2n) && bks > 1 && nout_act == mCfg.nout;
-            s0.max_ksplit = boundary_split ? std::min(bks, kBoundarySlices) : 1;
+            // for the slices' total either.
+            boundary_split = !is_big_fft(st.log2n) && nout_act == mCfg.nout;
+            s0.max_ksplit = boundary_split ? kBoundarySlices : 1;
             mac_plan(s0, pl);
             if (!boundary_split) HCV_TRY(launch_reduce_partials(st.Ypre, st.bg_slices, (long long) mCfg.nout * st.M, (long long) mCfg.nout * st.M, sM));
             if (!mac(st, s0, pl, st.Ht(), boundary_split ? st.Ypre + (size_t) st.bg_slices * mCfg.nout * st.M : st.Y, h_first, check, sM)) return false;
@@ -446,8 +416,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             // the split-K partial sums are added up by the inverse transform's loads when that is cheaper than a launch of its
             // own: few slices, many transforms (each workgroup then reads ksplit spectra instead of one — c4: 6 x 64 KB per
             // output, 14 us less per step; c5's 24 slices over 16 outputs keep the reduction kernel, which uses the whole chip)
-            static const int fold_max = std::getenv("HCV_FOLD_REDUCE") ? std::atoi(std::getenv("HCV_FOLD_REDUCE")) : 8;
-            const bool fold = pl.ksplit > 1 && pl.ksplit <= fold_max && !is_big_fft(st.log2n) && (long long) T * nout_act >= 16;
+            const bool fold = pl.ksplit > 1 && pl.ksplit <= kFoldMax && !is_big_fft(st.log2n) && (long long) T * nout_act >= 16;
             if (!fold) HCV_TRY(launch_reduce_partials(st.Y, pl.ksplit, y_elems, y_elems, sI));
             HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, fold ? pl.ksplit : 1, y_elems, h_first, T, (int) nout_act, st.timeline, st.tl_len, st.tl_len - 1,
                                              st.tw, &st.big, sI));
@@ -462,7 +431,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         // plan the background accumulation for hop h+1: partitions 1 .. min(P-1, h+1) (those that have input), in up to
         // kBgSlices launches that the following calls issue as the hop's samples arrive (advance_background)
         st.bg_parts = (int) std::min<long long>(st.P - 1, h_first + 1);
-        st.bg_slices = std::max(1, std::min(std::min(kBgSlices, slices_env), st.bg_parts));
+        st.bg_slices = std::max(1, std::min(kBgSlices, st.bg_parts));
         st.bg_launched = 0;
         st.pre_hop = st.bg_parts > 0 ? h_first + 1 : -1;
     }
@@ -502,7 +471,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // shorter stages — a dozen launches in latency-bound chains — are not run at all.  Entering the mode drops their
     // pending (now duplicate) results; leaving it rebuilds their input spectra from the history ring and catches up on
     // the one hop whose result is due in the new block (see the stage loop).
-    const size_t last = mStages.empty() ? 0 : mStages.size() - 1;
+    const size_t last = mStages.empty() ? 0 : mPivot;          // the stage whole-hop blocks run on
+    const bool rungs = !mStages.empty() && mPivot + 1 < mStages.size();      // the extended ladder's far-tail stages run beside it
     const bool whole_hops = mTailHead && !td_check && (n0 % mStages[last]->M) == 0 && (B % mStages[last]->M) == 0 &&
                             !(mStages[last]->max_hv > n0 / mStages[last]->M);
     const bool entering = whole_hops && !mTailHeadPrev, leaving = !whole_hops && mTailHeadPrev;
@@ -517,18 +487,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // 60 us of kernels on the 8x1 workload) is bound by its own enqueue; big engines keep the overlap.  HCV_SERIAL = 0 / 1
     // forces the choice for whole-hop blocks; single-stream engines are always serial.
     static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
-    static const double serial_mb = std::getenv("HCV_SERIAL_MB") ? std::atof(std::getenv("HCV_SERIAL_MB")) : 1024.0;
-    const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < serial_mb * 1048576.0;
-    // Small calls on ONE stream (HCV_SERIAL_SMALL = samples per call up to which, default 0 = off).  The chains of a real-time call — scatter,
-    // head, a stage boundary's transforms / partition-0 MAC / inverse, emit — are a few kernels of 4 - 20 us each, which this stack does not
-    // overlap across streams anyway (tools/small_call_trace.sh), and on one stream they lose the cross-stream hand-overs: 64 x 64 / 10 s at
-    // 32-sample calls p50 0.069 -> 0.059 ms, host enqueue halved.  But the tail's 0.2 ms deferred slices then sit in FRONT of the call that
-    // follows them, and p99 — what a real-time host budgets for — goes the other way (0.247 -> 0.275 ms; 128-sample calls 0.266 -> 0.300;
-    // with 32 slices of half the length 0.20 at 32 samples but 0.34 at 128).  Left off; serial foreground with the slices alone on the stage
-    // streams is the form that would keep both.
-    static const int serial_small = std::getenv("HCV_SERIAL_SMALL") ? std::atoi(std::getenv("HCV_SERIAL_SMALL")) : 0;
-    const bool small_call = !whole_hops && serial_small > 0 && (int) B <= serial_small;
-    const bool serial = mOneStream || small_call || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
+    constexpr double kSerialMB = 1024.0;
+    const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < kSerialMB * 1048576.0;
+    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
     Block blk;
     blk.din = din; blk.dout = dout; blk.in_stride = in_stride; blk.out_stride = out_stride;
     blk.nin_act = nin_act; blk.nout_act = nout_act; blk.rows_in = rows_in; blk.B = B;
@@ -572,26 +533,21 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         for (Stage *st : mStages) HCV_TRY(wt(st->stream, mEvCtl));
         mCtlDirty = false;
     }
-    // HCV_PIPELINE=0 serialises consecutive blocks (block k+1 starts after emit(k)); default lets them overlap
-    static const bool pipeline = !(std::getenv("HCV_PIPELINE") && std::atoi(std::getenv("HCV_PIPELINE")) == 0);
-    // Direct input (HCV_DIRECT_IN, default on): when exactly one FFT stage runs this block and the block is made of whole,
+    // Direct input: when exactly one FFT stage runs this block and the block is made of whole,
     // aligned hops of it — whole-hop mode, or a single-stage engine — that stage's forward transforms read the caller's block
     // in their first pass and file it in the history ring themselves (launch_rfft_frames_direct).  The scatter launch goes,
     // and with it the cross-stream hand-over in front of the stage's first kernel: on a 64x64 engine with 2 s IRs the next
     // block's scatter used to sit in a hardware queue behind the tail MAC (there are fewer queues than streams), 25-40 us of
     // every 0.58 ms step.  Needs 8-byte aligned input rows (the first pass loads sample pairs).
-    static const bool allow_direct = !(std::getenv("HCV_DIRECT_IN") && std::atoi(std::getenv("HCV_DIRECT_IN")) == 0);
-    const bool direct_in = allow_direct && rows_in > 0 && whole_hops && !is_big_fft(mStages[last]->log2n) && ((uintptr_t) din % 8) == 0 &&
+    const bool direct_in = rows_in > 0 && whole_hops && !is_big_fft(mStages[last]->log2n) && ((uintptr_t) din % 8) == 0 &&
                            (in_stride % 2) == 0 && !entering;
     blk.direct_in = direct_in;
-    // Direct output (HCV_DIRECT_OUT, default on): a whole-hop block past the mode's first has empty timelines and one
+    // Direct output: a whole-hop block past the mode's first has empty timelines and one
     // zero-latency transform per output and hop, so the inverse's last pass writes the caller's block (launch_rifft_emit) and the
     // emit launch — with its wait for the stage's stream — goes too.  Needs 8-byte aligned output rows.
-    static const bool allow_direct_out = !(std::getenv("HCV_DIRECT_OUT") && std::atoi(std::getenv("HCV_DIRECT_OUT")) == 0);
-    blk.direct_out = allow_direct_out && whole_hops && !entering && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
+    blk.direct_out = whole_hops && !entering && !rungs && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
     if (!direct_in)
     {
-        if (!pipeline) HCV_TRY(wt(sIn, mEvEmit[q ^ 1]));
         // the block two back read the history this scatter may overwrite
         for (Stage *st : mStages) HCV_TRY(wt(sIn, st->done[q]));
         HCV_TRY(wt(sIn, mEvTd[q]));
@@ -600,8 +556,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
         HCV_TRY(rec(mEvInput[q], sIn));
     }
-    else if (!pipeline)
-        HCV_TRY(wt(serial ? mStream : mStages[last]->stream, mEvEmit[q ^ 1]));
     mPrevDirect = direct_in;
     // Two-stream pipeline of a small engine's whole-hop blocks (enqueue_stage): the NEXT block's forward transforms on a second stream
     // beside the current block's MAC, reduction and inverse.  A cross-stream hand-over is dear on this stack — the wait on the
@@ -701,13 +655,19 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const bool pin_block = serial && whole_hops && !mStages.empty() &&
                            (double) (mStages[last]->live_parts + (uint64_t) rows_in * mStages[last]->R) * mStages[last]->M * sizeof(float2) <= 1.5 * 1048576.0;
     xcd_pin_hint(pin_block, mPinXcd);
-    // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it
+    // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it.  (A whole-hop block of
+    // an extended ladder: the pivot stage first — its transforms file the block's samples in the history ring, which a rung at
+    // its hop boundary reads — then the rungs.)
     for (size_t sj = 0; sj < mStages.size(); sj++)
-        if (!enqueue_stage(blk, mStages.size() - 1 - sj, sj))
+    {
+        size_t si = mStages.size() - 1 - sj;
+        if (whole_hops && rungs) si = sj == 0 ? last : (sj <= mStages.size() - 1 - last ? mStages.size() - sj : mStages.size() - 1 - sj);
+        if (!enqueue_stage(blk, si, sj))
         {
             xcd_pin_hint(false);
             return false;
         }
+    }
     xcd_pin_hint(false);
 
     if (!blk.direct_out)

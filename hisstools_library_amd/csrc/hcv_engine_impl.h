@@ -46,6 +46,7 @@ struct DeviceGuard
 };
 
 constexpr int kBgSlices = 16;
+constexpr int kFoldMax = 8;              // the inverse adds up to this many split-K slices itself instead of a reduce_partials launch
 constexpr int kBoundarySlices = 7;       // k-slices of the partition-0 MAC at a deferred hop's boundary, in the slots behind the background slices'
 
 // HCV_EXACT_RESTART=0 falls back to the hop-granular fence alone (the restarted pair may see up to two hops of older input
@@ -99,8 +100,7 @@ struct Engine::Stage
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
-    unsigned *tickets = nullptr;        // kMacTickets arrival counters of the fused split-K epilogue (zero between launches) + the two
-                                        // monotonic hand-over counters of the fused blocks
+    unsigned *coop_bar = nullptr;       // fused blocks: the two monotonic hand-over counters (one-output engines only)
     unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
     unsigned long long coop_seq = 0;        // fused blocks launched so far
@@ -147,7 +147,8 @@ struct Engine::Block
     uint32_t nin_act = 0, nout_act = 0, rows_in = 0, B = 0;
     long long n0 = 0, hmask = 0;
     int q = 0;                          // block parity: every event and double buffer is indexed by it
-    size_t last = 0;                    // index of the last stage
+    size_t last = 0;                    // index of the stage whole-hop blocks run on (Engine::mPivot): the last one, or the one in front of
+                                        // the extended ladder's rungs
     bool td_any = false, td_check = false, whole_hops = false, entering = false, leaving = false, head_fft = false, td = false;
     bool serial = false, full_matrix = false;
     bool pipe_far = false;              // ... in a run of single-hop blocks (its transforms wait for the block three or four back)

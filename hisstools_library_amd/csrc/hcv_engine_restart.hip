@@ -200,10 +200,9 @@ bool Engine::make_ghost_event(const std::vector<size_t> &pairs)
 }
 
 // spectral_mac + the ghost products of the restarted pairs it reaches (every MAC of a stage goes through here)
-bool Engine::mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream,
-                 bool fuse_reduce)
+bool Engine::mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream)
 {
-    HCV_TRY(launch_spectral_mac(s, pl, st.X, H, Y, st.hv, h_first, check, stream, fuse_reduce ? st.tickets : nullptr));
+    HCV_TRY(launch_spectral_mac(s, pl, st.X, H, Y, st.hv, h_first, check, stream));
     if (st.gh_count && h_first + s.T - 1 >= st.gh_min_hr && h_first - st.gh_max_hr <= (long long) s.P)
         HCV_TRY(launch_ghost_mac(s, H, Y, h_first, st.gh_start, st.gh_ent, nullptr, stream));
     return true;
@@ -222,7 +221,9 @@ bool Engine::retire_pair(size_t pair)
         const long long h_r = mN / st.M;
         const long long P = std::min<long long>(st.pact[pair], h_r);
         if (P <= 0) continue;
-        if (mTailHeadPrev) continue;        // whole-hop mode: every block delivers all it computes, no stage has anything pending
+        // whole-hop mode: every block delivers all it computes, no stage up to the pivot has anything pending (the extended ladder's
+        // rungs behind it keep their one hop of latency)
+        if (mTailHeadPrev && si <= mPivot) continue;
         MacShape sh = mac_shape(st, /* P */ (int) P, /* Pcap */ st.hparts(),
                                 /* nin */ 1, /* nin_alloc */ 1, /* nout */ 1, /* diag */ 0,
                                 /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / st.M));

@@ -701,13 +701,9 @@ bool fft_split_applies(int log2n, int transforms)
     return transforms <= kSplitMaxTransforms;
 }
 
-static int split_radix_log2(int log2n)
-{
-    static const int r14 = std::getenv("HCV_FFT_SPLIT_R14") ? std::atoi(std::getenv("HCV_FFT_SPLIT_R14")) : 4;
-    static const int r12 = std::getenv("HCV_FFT_SPLIT_R12") ? std::atoi(std::getenv("HCV_FFT_SPLIT_R12")) : 3;
-    if (log2n == 14) return (r14 == 3 || r14 == 5) ? r14 : 4;
-    return (r12 == 2 || r12 == 4) ? r12 : 3;
-}
+// log2 of the split radix per transform size (16384 points: 16 residue classes over 9 forward / 8 inverse workgroups; 4096 points: 8
+// over 5 / 4) — radices 8 and 32, 4 and 16 were built and measured beside them in round 3 and are gone
+static int split_radix_log2(int log2n) { return log2n == 14 ? 4 : 3; }
 
 void fft_split_prepare(int log2n)
 {
@@ -732,7 +728,7 @@ hipError_t launch_rfft_frames_direct_split(int log2n, float *hist, long long his
 {
     const int lr = split_radix_log2(log2n);
 #define HCV_SPLIT_F(LN, LR) if (log2n == LN && lr == LR) return launch_rfft_split_t<LN, LR>(hist, hist_stride, hist_mask, in, in_stride, n0, h_first, T, nin, X, R, tw, st)
-    HCV_SPLIT_F(14, 3); HCV_SPLIT_F(14, 4); HCV_SPLIT_F(14, 5); HCV_SPLIT_F(12, 2); HCV_SPLIT_F(12, 3); HCV_SPLIT_F(12, 4);
+    HCV_SPLIT_F(14, 4); HCV_SPLIT_F(12, 3);
 #undef HCV_SPLIT_F
     return hipErrorInvalidValue;
 }
@@ -770,7 +766,7 @@ hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long 
 {
     const int lr = split_radix_log2(log2n);
 #define HCV_SPLIT_I(LN, LR) if (log2n == LN && lr == LR) return launch_rifft_split_t<LN, LR>(Y, ksplit, ks_stride, T, nout, out, out_stride, tw, st)
-    HCV_SPLIT_I(14, 3); HCV_SPLIT_I(14, 4); HCV_SPLIT_I(14, 5); HCV_SPLIT_I(12, 2); HCV_SPLIT_I(12, 3); HCV_SPLIT_I(12, 4);
+    HCV_SPLIT_I(14, 4); HCV_SPLIT_I(12, 3);
 #undef HCV_SPLIT_I
     return hipErrorInvalidValue;
 }

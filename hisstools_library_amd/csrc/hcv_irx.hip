@@ -432,8 +432,7 @@ namespace
             lin_factor = c.zero_center ? 0.0 : (-2.0 * M_PI * (ph - delay_factor));
         }
         const int lm = (int) c.log2n - 1;
-        static const bool allow_fused = !(std::getenv("HCV_IR_FUSED") && std::atoi(std::getenv("HCV_IR_FUSED")) == 0);
-        if (allow_fused && lm <= ir_max_lds_log2m<T>())
+        if (lm <= ir_max_lds_log2m<T>())
         {
             // one kernel: HBM is read once and written once
             const typename Cx2<T>::type *tw = ir_twiddles<T>(device, lm + 1, err);

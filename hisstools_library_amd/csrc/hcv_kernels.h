@@ -117,12 +117,8 @@ namespace hcv
     void mac_plan(const MacShape &s, MacPlan &pl);
     // (dst: where the sum goes; nullptr = slice 0 of Y itself)
     hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st, float2 *dst = nullptr);
-    // tickets (optional): kMacTickets zeroed counters; when the plan allows it (mac_can_fuse_reduce) the launch adds its split-K
-    // slices up into slice 0 itself, in reduce_partials' order, and no reduce_partials launch is needed
-    constexpr int kMacTickets = 1024;
-    bool mac_can_fuse_reduce(const MacPlan &pl);
     hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
-                                   long long h_first, bool check, hipStream_t st, unsigned *tickets = nullptr);
+                                   long long h_first, bool check, hipStream_t st);
 
     // ---- exact per-pair restart (hcv_ghost.hip) ----
     struct GhostEntry

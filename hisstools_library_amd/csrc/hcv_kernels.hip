@@ -404,7 +404,7 @@ __global__ __launch_bounds__(FFTGeom<LOG2M>::THREADS, 4) void rifft_rows_kernel(
 
 // Split-K epilogue: Y[0][e] = sum_ks Y[ks][e].  One float4 per thread, the ksplit strided loads of a thread are
 // independent (issued back to back), neighbouring threads are contiguous: a plain coalesced streaming reduction.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *Y, int ksplit, long long ks_stride4, long long n4, int pin, int fast, float4 *dst)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *Y, int ksplit, long long ks_stride4, long long n4, int pin, float4 *dst)
 {
     int bx = blockIdx.x;
     if (pin >= 0)
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float4 *Y, int ksp
     }
     const long long e = bx * (long long) blockDim.x + threadIdx.x;
     if (e >= n4) return;
-    if (fast && ksplit <= 33)
+    if (ksplit <= 33)
     {
         // few slices (the small engines' launch-bound chains): every slice's load in flight at once — the slices were written a
         // moment ago by workgroups all over the chip and come from the memory side, two microseconds a trip — then the same sums
@@ -807,11 +807,9 @@ void xcd_pin_hint(bool on, int xcd)
 
 int xcd_pin_for(long long workgroups)
 {
-    // HCV_XCD_PIN: 0 never, 1 every tiny launch, unset = the launches of blocks the engine marked (xcd_pin_hint)
-    static const int mode = std::getenv("HCV_XCD_PIN") ? std::atoi(std::getenv("HCV_XCD_PIN")) : -1;
-    static const int limit = std::getenv("HCV_XCD_PIN_MAX") ? std::atoi(std::getenv("HCV_XCD_PIN_MAX")) : 32;
-    if (mode == 0 || workgroups <= 0 || workgroups > limit) return -1;
-    return (mode > 0 || tlsPinHint) ? tlsPinXcd : -1;
+    // the launches of blocks the engine marked (xcd_pin_hint), up to one XCD's worth of workgroups
+    if (!tlsPinHint || workgroups <= 0 || workgroups > 32) return -1;
+    return tlsPinXcd;
 }
 
 template <int L> static inline size_t fft_lds_bytes() { return sizeof(float2) * lds_padded(FFTGeom<L>::M) * FFTGeom<L>::G; }
@@ -945,9 +943,8 @@ hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, lo
     const long long n4 = elems / 2;
     const int grid = (int) ((n4 + 255) / 256);
     const int pin = xcd_pin_for(grid);
-    static const bool fast = !(std::getenv("HCV_REDUCE_FAST") && std::atoi(std::getenv("HCV_REDUCE_FAST")) == 0);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid * (pin >= 0 ? 8 : 1)), dim3(256), 0, st, reinterpret_cast<float4 *>(Y), ksplit, ks_stride / 2, n4, pin,
-                       (int) fast, reinterpret_cast<float4 *>(dst));
+                       reinterpret_cast<float4 *>(dst));
     return hipGetLastError();
 }
 
@@ -967,15 +964,9 @@ static hipError_t launch_fir_otd(const float *hist, long long hist_stride, long 
     return hipGetLastError();
 }
 
-static bool fir_small_on()
-{
-    static const bool on = !(std::getenv("HCV_FIR_SMALL") && std::atoi(std::getenv("HCV_FIR_SMALL")) == 0);
-    return on;
-}
-
 bool fir_head_is_small(int B, int nin, int Lpad, int diag)
 {
-    return fir_small_on() && !diag && B > 0 && B <= 256 && nin >= 1 && Lpad >= 16 && Lpad <= 1024;
+    return !diag && B > 0 && B <= 256 && nin >= 1 && Lpad >= 16 && Lpad <= 1024;
 }
 
 hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,

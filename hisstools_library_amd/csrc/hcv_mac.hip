@@ -40,8 +40,6 @@
 namespace hcv
 {
 
-constexpr int kFuseMaxSlices = 33;       // split-K slices the fused epilogue can hold in registers (1 + 8 groups of four)
-
 __device__ __forceinline__ void cmac2(float4 &acc, const float4 &x, const float4 &h)
 {
     acc.x += x.x * h.x - x.y * h.y;
@@ -50,33 +48,12 @@ __device__ __forceinline__ void cmac2(float4 &acc, const float4 &x, const float4
     acc.w += x.z * h.w + x.w * h.z;
 }
 
-// FUSE: the split-K epilogue inside the launch (small engines, where reduce_partials_kernel is a 4 us link in a chain of four
-// launches): every workgroup publishes its slice, takes a ticket of its bin block, and the one that arrives last adds the slices
-// up into slice 0 IN THE ORDER reduce_partials_kernel uses, so the block's result is bit-identical to the two-launch form.
-// Visibility across CUs and XCDs: the slices are written and read with 8-byte agent-scope relaxed atomics (write-through `sc1`
-// stores, L1-bypassing `sc1` loads: MI355X_MICROARCH.md, "valid forms") and every thread drains its stores before the workgroup's
-// ticket.  (The fence form — plain stores, agent release by 480 workgroups, acquire by the last — measured 3.4 x SLOWER: the
-// 8 -> 1 workload's MAC 7.7 -> 26 us, each release writing an XCD's L2 back.)
-__device__ __forceinline__ void store_agent(float4 *p, const float4 &v)
-{
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
-    __hip_atomic_store(q, ((unsigned long long) __float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, ((unsigned long long) __float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4 load_agent(const float4 *p)
-{
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__uint_as_float((unsigned) a), __uint_as_float((unsigned) (a >> 32)), __uint_as_float((unsigned) b), __uint_as_float((unsigned) (b >> 32)));
-}
-
 //
 // INWG: split-K INSIDE the workgroup, for the engines whose whole reduction is a few hundred terms (8 -> 1 with 5 s IRs: 240):
 // the workgroup is 64 lanes (128 bins, one 1 KiB run per load) x blockDim.y k-slices, one wave each; the slices' sums meet in LDS
 // and are added up in slice order by the first wave, which writes the finished spectrum — no partial sums through memory and no
 // reduce_partials launch (4.4 us of a 27 us chain).
-template <int OT, int TT, bool CHECK, bool NT, bool FUSE = false, bool INWG = false>
+template <int OT, int TT, bool CHECK, bool NT, bool INWG = false>
 __global__ __launch_bounds__(INWG ? 1024 : 256) void spectral_mac_kernel(MacParams a)
 {
     int bx = blockIdx.x;
@@ -261,86 +238,20 @@ __global__ __launch_bounds__(INWG ? 1024 : 256) void spectral_mac_kernel(MacPara
                     if (o0 + j < a.nout)
                     {
                         float4 *d = y + ((long long) (t0 + t) * a.nout + (o0 + j)) * a.M2;
-                        if constexpr (FUSE) store_agent(d, acc[t][j]);
-                        else *d = acc[t][j];
+                        *d = acc[t][j];
                     }
             }
-    }
-
-    if constexpr (FUSE)
-    {
-        // (launched with one hop tile per workgroup row and a one-dimensional tile grid: blockDim.y == 1, gridDim.z == 1)
-        __shared__ int last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's slice has been written through
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            unsigned *tk = a.tickets + (blockIdx.y * a.binblocks + bb);
-            const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = old == (unsigned) a.ksplit - 1u;
-            if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-        }
-        __syncthreads();
-        if (last && binlive)
-        {
-#pragma unroll
-            for (int t = 0; t < TT; t++)
-                if (t < live_t)
-                {
-#pragma unroll
-                    for (int j = 0; j < OT; j++)
-                        if (o0 + j < a.nout)
-                        {
-                            float4 *y0 = a.Y + ((long long) (t0 + t) * a.nout + (o0 + j)) * a.M2 + b4;
-                            // every slice's loads in flight at once (each is a trip past the L1 to the memory side), then the sum
-                            // in reduce_partials' order: slice 0, groups of four, the rest one by one
-                            constexpr int KMAX = kFuseMaxSlices;
-                            float4 v[KMAX];
-#pragma unroll
-                            for (int k = 0; k < KMAX; k++)
-                                if (k < a.ksplit) v[k] = load_agent(y0 + (long long) k * a.ks_stride4);
-                            float4 sum = v[0];
-                            const int quads = (a.ksplit - 1) / 4;
-#pragma unroll
-                            for (int g = 0; g < (KMAX - 1) / 4; g++)
-                                if (g < quads)
-                                {
-                                    const float4 p = v[1 + 4 * g], q = v[2 + 4 * g], r = v[3 + 4 * g], u = v[4 + 4 * g];
-                                    sum.x += (p.x + q.x) + (r.x + u.x);
-                                    sum.y += (p.y + q.y) + (r.y + u.y);
-                                    sum.z += (p.z + q.z) + (r.z + u.z);
-                                    sum.w += (p.w + q.w) + (r.w + u.w);
-                                }
-#pragma unroll
-                            for (int k = 1; k < KMAX; k++)
-                                if (k > 4 * quads && k < a.ksplit)
-                                {
-                                    sum.x += v[k].x; sum.y += v[k].y; sum.z += v[k].z; sum.w += v[k].w;
-                                }
-                            y0[0] = sum;
-                        }
-                }
-        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ launch plan
 
-static int env_int(const char *name, int dflt)
-{
-    const char *v = std::getenv(name);
-    return v ? std::atoi(v) : dflt;
-}
-
 void mac_plan(const MacShape &s, MacPlan &pl)
 {
-    // tuning knobs (read once): HCV_MAC_BLOCKS = workgroups to aim for, HCV_MAC_OT / HCV_MAC_TT = caps on the tile
-    static const int target_blocks = env_int("HCV_MAC_BLOCKS", 768);
-    static const int ot_cap = env_int("HCV_MAC_OT", 8);
-    static const int tt_env = env_int("HCV_MAC_TT", 0);
+    constexpr int target_blocks = 768;      // workgroups to aim for (3 per CU)
     // hop tiling pays through H reuse on long reductions; the short head stages run leaner (fewer registers, so they
     // co-reside with the tail's workgroups)
-    const int tt_cap = tt_env > 0 ? tt_env : (s.P >= 32 ? 8 : 4);
+    const int tt_cap = s.P >= 32 ? 8 : 4;
     const int M2 = s.M / 2;
 
     int tt = 1;
@@ -354,7 +265,6 @@ void mac_plan(const MacShape &s, MacPlan &pl)
         ot = s.nout >= 8 ? 8 : s.nout >= 4 ? 4 : s.nout >= 2 ? 2 : 1;
     else
         ot = s.nout >= 3 ? 4 : 1;                              // TT > 1 kernels exist for OT in {1, 4}
-    while (ot > ot_cap && ot > 1) ot >>= 1;
     if (tt > 1 && ot == 2) ot = 1;
     pl.ot = ot;
 
@@ -369,8 +279,7 @@ void mac_plan(const MacShape &s, MacPlan &pl)
     const long long base = (long long) pl.binblocks * pl.outtiles * pl.tz;
     // workgroups to aim for = what is resident at once: 3 per CU for the single-hop tile (132 registers), 2 per CU for the
     // large hop tiles (4 x 4 and 4 x 8 need 176 - 233): a third, half-empty round of workgroups cost the 4 x 8 tile 8 %
-    static const bool blocks_forced = std::getenv("HCV_MAC_BLOCKS") != nullptr;
-    const long long tgt = s.target_blocks > 0 ? s.target_blocks : (!blocks_forced && pl.ot == 4 && pl.tt >= 4) ? 512 : target_blocks;
+    const long long tgt = s.target_blocks > 0 ? s.target_blocks : (pl.ot == 4 && pl.tt >= 4) ? 512 : target_blocks;
     long long want = std::max<long long>(1, tgt / base);
     long long maxsplit = K / 8;                                 // keep every k-slice at least 8 long
     if (maxsplit < 1) maxsplit = 1;
@@ -380,14 +289,13 @@ void mac_plan(const MacShape &s, MacPlan &pl)
     pl.kper = (int) std::max<long long>(1, (K + want - 1) / want);      // (K = 0: no live input, the launch writes zeros)
     pl.ksplit = (int) ((K + pl.kper - 1) / pl.kper);
     if (pl.ksplit < 1) pl.ksplit = 1;
-    // small engines (HCV_MAC_INWG = 0 switches it off): one hop, one or two outputs, a reduction of 32 .. a few hundred terms whose
+    // small engines: one hop, one or two outputs, a reduction of 32 .. a few hundred terms whose
     // spectra stay in the caches — the k-slices become the waves of one workgroup.  (Hop-tiled launches of such engines — the
     // 1 x 1 / 4096-point workload: four hops per block, 235 partitions — measured SLOWER this way, 0.0185 -> 0.0227 ms per block:
     // sixteen workgroups of eight waves walking 30 partitions each; they keep the hop-tiled kernel and its reduction launch.)
-    static const int inwg_env = env_int("HCV_MAC_INWG", 1);
     pl.inwg = 0;
     const double h_bytes = 8.0 * s.M * (double) K * s.nout;
-    if (inwg_env && pl.tt == 1 && tiles == 1 && pl.ot <= 2 && pl.ksplit > 1 && K >= 32 && K <= 1024 && M2 % 64 == 0 &&
+    if (pl.tt == 1 && tiles == 1 && pl.ot <= 2 && pl.ksplit > 1 && K >= 32 && K <= 1024 && M2 % 64 == 0 &&
         h_bytes <= 32.0 * 1048576.0 && s.target_blocks <= 0)
     {
         int kw = 16;
@@ -402,12 +310,10 @@ void mac_plan(const MacShape &s, MacPlan &pl)
         pl.ksplit = 1;
     }
     // every H element is read exactly once per launch when a single hop tile covers the call: stream it
-    // ... and they outgrow the caches: spectra of at most HCV_MAC_NT_MIN_MB (24) stay in the XCDs' L2s from block to block (workgroup
+    // ... and they outgrow the caches: spectra of at most 24 MB stay in the XCDs' L2s from block to block (workgroup
     // b of every launch lands on the same XCD), where nontemporal loads would push them out (8 -> 1 / 5 s: MAC 7.7 -> 6.6 us)
-    static const int nt_mode = env_int("HCV_MAC_NT", 2);
-    static const double nt_min_mb = (double) env_int("HCV_MAC_NT_MIN_MB", 24);
     const double spectra_mb = 8.0 * s.M * (double) (s.diag ? 1 : s.nin) * s.P * s.nout / 1048576.0;
-    pl.nt = (nt_mode == 1 || (nt_mode == 2 && tiles == 1 && spectra_mb > nt_min_mb)) ? 1 : 0;
+    pl.nt = (tiles == 1 && spectra_mb > 24.0) ? 1 : 0;
 }
 
 template <int OT, int TT>
@@ -415,9 +321,8 @@ static hipError_t launch_mac_tile(const MacParams &a, const MacPlan &pl, bool ch
 {
     dim3 grid(pl.binblocks * pl.ksplit * (a.pin >= 0 ? 8 : 1), pl.outtiles, pl.tz);
     dim3 block(pl.bx, pl.by);
-    // HCV_MAC_PREFETCH (default 1): steady-state launches of the hop-tiled shapes take the software-pipelined kernel
-    // (hcv_mac_tiled.hip, its own translation unit: it is compiled without the SLP vectoriser)
-    static const bool prefetch = !(std::getenv("HCV_MAC_PREFETCH") && std::atoi(std::getenv("HCV_MAC_PREFETCH")) == 0);
+    // steady-state launches of the hop-tiled shapes take the software-pipelined kernel (hcv_mac_tiled.hip, its own translation
+    // unit: it is compiled without the SLP vectoriser)
     if constexpr (OT <= 2 && TT == 1)
     {
         if (pl.inwg > 0)
@@ -425,26 +330,15 @@ static hipError_t launch_mac_tile(const MacParams &a, const MacPlan &pl, bool ch
             const dim3 g2(pl.binblocks * (a.pin >= 0 ? 8 : 1), pl.outtiles, 1), b2(64, pl.inwg);
             const size_t lds = sizeof(float4) * 64 * OT * TT * (size_t) pl.inwg;
             if (check)
-                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, true, false, false, true>), g2, b2, lds, st, a);
+                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, true, false, true>), g2, b2, lds, st, a);
             else if (pl.nt)
-                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, true, false, true>), g2, b2, lds, st, a);
+                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, true, true>), g2, b2, lds, st, a);
             else
-                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, false, false, true>), g2, b2, lds, st, a);
+                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, false, true>), g2, b2, lds, st, a);
             return hipGetLastError();
         }
     }
-    if (TT > 1 && !check && prefetch) return launch_mac_tiled(OT, TT, pl.nt != 0, grid, block, a, st);
-    if constexpr (OT <= 2 && TT == 1)
-    {
-        if (a.tickets)
-        {
-            if (check)
-                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, true, false, true>), grid, block, 0, st, a);
-            else
-                hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, false, true, true>), grid, block, 0, st, a);
-            return hipGetLastError();
-        }
-    }
+    if (TT > 1 && !check) return launch_mac_tiled(OT, TT, pl.nt != 0, grid, block, a, st);
     if (check)
         hipLaunchKernelGGL((spectral_mac_kernel<OT, TT, true, false>), grid, block, 0, st, a);
     else if (pl.nt)
@@ -454,13 +348,8 @@ static hipError_t launch_mac_tile(const MacParams &a, const MacPlan &pl, bool ch
     return hipGetLastError();
 }
 
-bool mac_can_fuse_reduce(const MacPlan &pl)
-{
-    return pl.ot <= 2 && pl.tt == 1 && pl.by == 1 && pl.tz == 1 && pl.ksplit > 1 && pl.ksplit <= kFuseMaxSlices && pl.binblocks * pl.outtiles <= kMacTickets;
-}
-
 hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float2 *X, const float2 *H, float2 *Y, const long long *hv,
-                               long long h_first, bool check, hipStream_t st, unsigned *tickets)
+                               long long h_first, bool check, hipStream_t st)
 {
     if (s.T <= 0 || s.nout <= 0) return hipSuccess;
     MacParams a;
@@ -482,7 +371,6 @@ hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float
     a.kper = pl.kper;
     a.binblocks = pl.binblocks;
     a.ks_stride4 = (long long) s.T * s.nout * (s.M / 2);
-    a.tickets = (tickets && mac_can_fuse_reduce(pl)) ? tickets : nullptr;
     a.pin = (pl.outtiles == 1 && pl.tz == 1) ? xcd_pin_for((long long) pl.binblocks * pl.ksplit * (pl.inwg > 0 ? pl.inwg / 4 : 1)) : -1;
     const int key = pl.ot * 16 + pl.tt;
     switch (key)

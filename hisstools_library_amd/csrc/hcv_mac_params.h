@@ -20,8 +20,6 @@ struct MacParams
     int ksplit, kper;       // k-slices over blockIdx.x and their length
     int binblocks;
     long long ks_stride4;   // float4 stride between k-slices of Y
-    unsigned *tickets;      // fused split-K epilogue (spectral_mac_kernel<.., FUSE = true>): one arrival counter per (bin block, hop) group,
-                            // zero between launches; the workgroup that arrives last adds the slices up into slice 0
     int pin;                // >= 0: grid.x is 8 x the workgroups and only blockIdx.x % 8 == pin work (hcv_kernels.h: xcd_pin_for)
 };
 

@@ -61,10 +61,6 @@ HCV_API int hcv_device_count(void);                       /* number of HIP devic
 HCV_API int hcv_set_default_device(int device);           /* device used by subsequently created objects */
 HCV_API int hcv_get_default_device(void);
 HCV_API const char *hcv_last_error(void);                 /* thread-local text of the last failure */
-/* MI355X extension, measurement aid (no reference analogue): what this box streams from HBM when it does nothing else — a sum over `bytes`
- * of device memory with the loads the multiply-accumulate kernel uses (nontemporal 16-byte loads), best of `reps` timings, in GB/s.
- * bench.py prints it beside the roofline fraction.  device < 0: the default device.  0 on success. */
-HCV_API int hcv_box_read_rate(int device, size_t bytes, int reps, double *gbs);
 
 /* ---------------------------------------------------------------- HISSTools_FFT (float real transforms on the path)
  * hisstools_rfft 5-arg  HISSTools_FFT.cpp:226-230   (zero-padding unzip + real FFT, output x2, vDSP packing)

@@ -100,8 +100,8 @@ def test_bench_line_has_the_contract_fields(tmp_path):
     cfg = d["config"]
     assert "c2_error" not in cfg and "m16l_error" not in cfg, cfg
     assert cfg["c2_msamples_per_s"] > 0 and cfg["c2_ms_per_step"] > 0 and cfg["c2_max_rel_err"] <= 1e-5 and cfg["c2_self_check_ok"] is True
-    assert cfg["c2_cpu_1core"] > 0 and cfg["c2_bound"] == "launch" and cfg["c2_kernel"] == "fused_block_hops_kernel"
-    assert cfg["m16l_bound"] == "hbm" and 0 < cfg["m16l_mac_frac"] < 1 and cfg["m16l_max_rel_err"] <= 1e-5 and cfg["m16l_mac_ms"] <= cfg["m16l_ms_per_step"]
+    assert cfg["c2_cpu_1core"] > 0 and cfg["c2_kernel"] == "fused_block_hops_kernel"
+    assert 0 < cfg["m16l_mac_frac"] < 1 and cfg["m16l_max_rel_err"] <= 1e-5 and cfg["m16l_mac_ms"] <= cfg["m16l_ms_per_step"]
     # the rich record went to the side file
     assert cfg["details_file"] == details
     rich = json.load(open(details))

@@ -2,8 +2,8 @@
 nothing; replaces hisstools_rfft / hisstools_rifft per hop, HISSTools_FFT.cpp:226-248, for blocks of a few transforms).
 
 By default they serve whole-hop blocks of at most 16 transforms of 16384 points (the 1 x 1 and 8 -> 1 engines: BASELINE configs 1
-and 3), so the default suites already run them.  Here every split radix that is built is FORCED for both transform sizes
-(HCV_FFT_SPLIT=1 — read once per process, hence the child processes) and the parity suites that drive whole-hop blocks are run
+and 3), so the default suites already run them.  Here they are FORCED for every block of both transform sizes
+(HCV_FFT_SPLIT=1 — read once per process, hence the child process) and the parity suites that drive whole-hop blocks are run
 under it: oracle, golden vectors and float64 truth, tolerance as stated in those files (2e-6 / 1e-5 of the output peak).
 """
 import os
@@ -20,10 +20,8 @@ SUITE = ["tests/test_small_engine_pipeline_gpu.py", "tests/test_configs_dense_gp
          "tests/test_pair_restart_gpu.py", "tests/test_steady_state_gpu.py::test_dense_irs_16x16_steady_state_vs_oracle"]
 
 
-@pytest.mark.parametrize("env", [{"HCV_FFT_SPLIT_R14": "4", "HCV_FFT_SPLIT_R12": "3"}, {"HCV_FFT_SPLIT_R14": "3", "HCV_FFT_SPLIT_R12": "2"},
-                                 {"HCV_FFT_SPLIT_R14": "5", "HCV_FFT_SPLIT_R12": "4"}])
-def test_parity_suites_with_split_transforms_forced(env):
-    e = dict(os.environ, HCV_FFT_SPLIT="1", **env)
+def test_parity_suites_with_split_transforms_forced():
+    e = dict(os.environ, HCV_FFT_SPLIT="1")
     out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", "mono or config1 or config2 or config3 or pipelined or restart or dense or swap"]
                          + SUITE + ["tests/test_gpu_parity.py"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=e)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

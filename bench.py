@@ -1024,7 +1024,7 @@ def bench_line(args, ctx):
         bytes_per_sample = 8.0 * nin * (nout + 1) * sum_p + 12.0 * nin * n_st + 4.0 * nout * n_st
         ceiling = HBM_PEAK_GBS * 1e9 / bytes_per_sample * nout / 1e6
         line["roofline"]["survey_8d_ceiling_msamples_per_s"] = round(ceiling * world, 1)
-        if bound == "hbm":
+        if bound == "hbm" and hops_per_launch > 0:
             line["roofline"]["whole_step_frac"] = round(alg_bytes / hops_per_launch * (B / Hh) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
             if value / world > ceiling:
                 line["roofline"]["note_ceiling"] = (f"value exceeds SURVEY 8d's {ceiling * world:.0f} Msamples/s ceiling: that figure reads every stage's partitions "

@@ -80,6 +80,7 @@ MacShape Engine::mac_shape(const Stage &st, int P, int Pcap, int nin, int nin_al
     s.T = T;
     s.max_ksplit = max_ksplit;
     s.target_blocks = 0;
+    s.ot_cap = 0;
     return s;
 }
 

@@ -8,6 +8,17 @@
 namespace hcv
 {
 
+// How many launches the deferred accumulation of a hop is spread over: one per partition up to kBgSlices for real-time calls (short
+// launches, evenly through the hop: no call waits long behind one); for hop-sized calls of a long stage — throughput callers, the
+// extended ladder's rungs under 8192-sample blocks — no more than half as many as the hop has calls, so that every slice carries
+// two or three partitions (a 134 MB launch runs at 2 TB/s between its ramps, a 400 MB one at 5).
+static int bg_slice_count(int bg_parts, uint64_t M, uint32_t B)
+{
+    int slices = std::max(1, std::min(kBgSlices, bg_parts));
+    if (B >= 4096 && M >= 8 * (uint64_t) B) slices = std::max(1, std::min<int>(slices, (int) (M / B) / 2));
+    return slices;
+}
+
 // Launch the background slices of `st` that are due: all of them at the hop's boundary, otherwise in proportion to the
 // part of the hop's samples that has arrived with this call.  Slice s covers partitions 1 + [a, b) of hop pre_hop:
 // a (b - a)-partition MAC at hop pre_hop - 1 - a over the spectra shifted by 1 + a partitions.
@@ -37,16 +48,32 @@ bool Engine::advance_background(const Block &blk, Stage &st, bool boundary)
             HCV_TRY(hipMemsetAsync(slot, 0, sizeof(float2) * slot_elems, sS));
             continue;
         }
-        const MacShape sb = mac_shape(st, /* P */ b - a, /* Pcap */ st.hparts(),
-                                      /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) mCfg.nout, /* diag */ mCfg.diag ? 1 : 0,
-                                      /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) mCfg.nout * st.M)));       // (full matrix only)
+        MacShape sb = mac_shape(st, /* P */ b - a, /* Pcap */ st.hparts(),
+                                /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) mCfg.nout, /* diag */ mCfg.diag ? 1 : 0,
+                                /* T */ 1, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) mCfg.nout * st.M)));       // (full matrix only)
         MacPlan pb;
         mac_plan(sb, pb);
+        // A slice of a long stage fills the chip with its bin blocks alone (the extended ladder's rungs: 128 and 1024 bin blocks per
+        // output tile): no k-slices then — partial sums through memory and their reduction launch moved as many bytes again as the
+        // slice's spectra (c5 on the ladder: 34 + 16 us of reduction per 8192-sample block) — and the sums go straight into the slot.
+        const bool direct = pb.ksplit > 1 && (long long) pb.binblocks * pb.outtiles * pb.tz >= 256;
+        if (direct)
+        {
+            sb.max_ksplit = 1;
+            mac_plan(sb, pb);
+            if ((long long) pb.binblocks * pb.outtiles * pb.tz < 512 && pb.ot == 8)
+            {
+                // (one workgroup per CU streams at a third of what two do: four outputs per thread, twice the workgroups; the input
+                // spectra are read twice, a sixteenth of the slice's bytes)
+                sb.ot_cap = 4;
+                mac_plan(sb, pb);
+            }
+        }
         const long long hop = st.pre_hop - 1 - a;
         const bool bcheck = (hop - st.max_hv) < (long long) (b - a) - 1;
         float2 *scratch = st.Yq[0];                             // every use of this stage's scratch is ordered on its stream
-        if (!mac(st, sb, pb, st.Ht() + (size_t) (1 + a) * st.M, scratch, hop, bcheck, sS)) return false;
-        HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS, slot));       // (the sum goes straight into the slot)
+        if (!mac(st, sb, pb, st.Ht() + (size_t) (1 + a) * st.M, pb.ksplit == 1 ? slot : scratch, hop, bcheck, sS)) return false;
+        if (pb.ksplit > 1) HCV_TRY(launch_reduce_partials(scratch, pb.ksplit, slot_elems, slot_elems, sS, slot));       // (the sum goes straight into the slot)
         HCV_TRY(hipEventRecord(st.bg_done, sS));
         st.bg_pending = true;
     }
@@ -127,7 +154,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             // no plan for the hop in progress (the first small call after large ones, or control work dropped it): make it
             // now — the frames it needs are complete — so that the boundary does not pay the whole accumulation inline
             st.bg_parts = (int) std::min<long long>(st.P - 1, h_first);
-            st.bg_slices = std::max(1, std::min(kBgSlices, st.bg_parts));
+            st.bg_slices = bg_slice_count(st.bg_parts, st.M, B);
             st.bg_launched = 0;
             st.pre_hop = h_first;
         }
@@ -431,7 +458,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         // plan the background accumulation for hop h+1: partitions 1 .. min(P-1, h+1) (those that have input), in up to
         // kBgSlices launches that the following calls issue as the hop's samples arrive (advance_background)
         st.bg_parts = (int) std::min<long long>(st.P - 1, h_first + 1);
-        st.bg_slices = std::max(1, std::min(kBgSlices, st.bg_parts));
+        st.bg_slices = bg_slice_count(st.bg_parts, st.M, B);
         st.bg_launched = 0;
         st.pre_hop = st.bg_parts > 0 ? h_first + 1 : -1;
     }
@@ -489,7 +516,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
     constexpr double kSerialMB = 1024.0;
     const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < kSerialMB * 1048576.0;
-    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : small_tail));
+    // (an extended ladder keeps its streams: the rungs' deferred slices run beside the pivot stage's latency-bound chain — c5 on the ladder
+    // 0.147 ms per 8192-sample block on one stream, 0.135 on the stages' own)
+    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : (small_tail && !rungs)));
     Block blk;
     blk.din = din; blk.dout = dout; blk.in_stride = in_stride; blk.out_stride = out_stride;
     blk.nin_act = nin_act; blk.nout_act = nout_act; blk.rows_in = rows_in; blk.B = B;

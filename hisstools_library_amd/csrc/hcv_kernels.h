@@ -104,6 +104,7 @@ namespace hcv
         int T;              // hops in this launch
         int max_ksplit;     // 0 = unlimited (bounded by the Y partial buffer)
         int target_blocks;  // 0 = default; > 0 = aim for this many workgroups (background work keeps a small footprint)
+        int ot_cap;         // 0 = none; > 0 = at most this many outputs per thread (more, smaller workgroups for launches without k-slices)
     };
     struct MacPlan
     {

@@ -265,6 +265,7 @@ void mac_plan(const MacShape &s, MacPlan &pl)
         ot = s.nout >= 8 ? 8 : s.nout >= 4 ? 4 : s.nout >= 2 ? 2 : 1;
     else
         ot = s.nout >= 3 ? 4 : 1;                              // TT > 1 kernels exist for OT in {1, 4}
+    while (s.ot_cap > 0 && ot > s.ot_cap && ot > 1) ot >>= 1;
     if (tt > 1 && ot == 2) ot = 1;
     pl.ot = ot;
 

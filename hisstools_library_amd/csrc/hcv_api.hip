@@ -1500,7 +1500,7 @@ extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
 extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
 {
     if (!out) return -1;
-    out->lock_contended = out->lock_wait_ns_max = out->blocks_muted = out->mailbox_runs = 0;
+    out->lock_contended = out->lock_wait_ns_max = out->blocks_muted = out->mailbox_runs = out->ctl_turns = 0;
     auto add = [&](Engine &e)
     {
         const Engine::RtStats r = e.rt_stats();
@@ -1508,6 +1508,7 @@ extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
         out->lock_wait_ns_max = std::max<uint64_t>(out->lock_wait_ns_max, r.lock_wait_ns_max);
         out->blocks_muted += r.blocks_muted;
         out->mailbox_runs += r.mailbox_runs;
+        out->ctl_turns += r.ctl_turns;
     };
     if (h->sh)
         for (hcv_shard &x : h->sh->s) add(*x.m->engine);

@@ -139,9 +139,9 @@ namespace hcv
         // upload, allocation or device work — only, at most, for the short host-only section in which a control call swaps
         // its staged result in.  These count what that cost: calls that found the engine lock taken, the longest such wait,
         // and blocks given up as silence after kAudioLockBudgetNs (never observed; the reference mutes the pair instead).
-        struct RtStats { uint64_t lock_contended, lock_wait_ns_max, blocks_muted, mailbox_runs; };
-        RtStats rt_stats() const { return { mLockContended.load(), mLockWaitNsMax.load(), mBlocksMuted.load(), mMailboxRuns.load() }; }
-        void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; }
+        struct RtStats { uint64_t lock_contended, lock_wait_ns_max, blocks_muted, mailbox_runs, ctl_turns; };
+        RtStats rt_stats() const { return { mLockContended.load(), mLockWaitNsMax.load(), mBlocksMuted.load(), mMailboxRuns.load(), mCtlTurns.load() }; }
+        void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; mMailboxRuns = 0; mCtlTurns = 0; }
 
         void set_profiling(bool on);
         bool stage_stats(size_t s, StageStats *out);
@@ -175,6 +175,16 @@ namespace hcv
         // lock taken by a set / resize / reset (MemorySwap::attempt never waits either, MemorySwap.h:182-185; the reference mutes
         // the pair meanwhile, here the pair plays its previous IR until the swap).  With no stream running the control thread takes
         // the lock itself.  Control calls are serialised by mSetMutex, so one slot suffices.
+        //
+        // Control TURNS (round 4).  The section is a few dozen HIP calls — retiring kernels, device-to-device copies, the restart's
+        // fence and ghost spectra: 0.1 - 0.3 ms of host time that the mailbox puts into an audio call.  A PACED stream (a real-time
+        // host: the calls' period leaves the engine lock free for most of it — mAudioPeriodNs, mAudioHoldNs) gets them off its thread
+        // altogether: the control thread waits for the audio thread to release the lock at the end of its next enqueue
+        // (mEnqueueSeq), takes the lock right behind it and runs the section AND the restart it raises itself, in the gap before
+        // the next call — at the same block boundary, on the same streams, as the audio thread would have at the start of that
+        // call.  The audio thread's part is nothing.  Should the section overrun the gap (a preempted control thread) the next call
+        // polls for the lock like any contended call, bounded, and is counted (rt_stats); a stream without gaps (back-to-back
+        // asynchronous calls) keeps the mailbox.
         struct CtlJob
         {
             std::function<bool()> fn;
@@ -187,7 +197,13 @@ namespace hcv
         std::atomic<long long> mLastAudioNs { 0 };
         std::atomic<size_t> mAudioThread { 0 };             // (hash of) the thread that made the last process call
         std::atomic<uint64_t> mMailboxRuns { 0 };           // sections the audio thread ran for control threads
+        std::atomic<uint64_t> mCtlTurns { 0 };              // sections control threads ran themselves between two calls of a paced stream
+        std::atomic<uint64_t> mEnqueueSeq { 0 };            // process calls that have released the engine lock
+        std::atomic<long long> mAudioPeriodNs { 0 }, mAudioHoldNs { 0 };    // smoothed: start-to-start of the calls, lock held per call
+        long long mCallStartNs = 0;                         // (audio thread) start of the call in progress
+        void audio_leave(std::unique_lock<std::mutex> &lk); // audio thread: end of a call's enqueue — stamp, release the lock, announce it
         bool apply_pending_resets();
+        void apply_resets_in_a_turn();
         bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
         struct Block;
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
@@ -297,4 +313,8 @@ namespace hcv
     };
 
     const float2 *twiddles(int device, int log2n, std::string *err);   // cached per (device, size)
+    // who counts as "the audio thread" for the calling thread's process calls (hcv_engine.hip): a shard's enqueue thread takes the identity
+    // of the user thread that posted the block
+    void set_thread_audio_identity(size_t id);
+    size_t current_thread_identity();
 }

@@ -828,7 +828,14 @@ static inline long long steady_ns()
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static inline size_t this_thread_hash() { return std::hash<std::thread::id>()(std::this_thread::get_id()) | 1; }
+// Who the audio thread is: the calling thread — or, on a shard's enqueue thread (hcv_shard_pool.h), the user thread that posted the
+// block, so that a single-threaded user (process, then set) is recognised on every shard's engine and not only on the first
+static thread_local size_t tlsAudioIdentity = 0;
+void set_thread_audio_identity(size_t id) { tlsAudioIdentity = id; }
+size_t current_thread_identity() { return std::hash<std::thread::id>()(std::this_thread::get_id()) | 1; }
+static inline size_t this_thread_hash() { return tlsAudioIdentity ? tlsAudioIdentity : current_thread_identity(); }
+
+constexpr long long kTurnMinGapNs = 350000;             // a paced stream: the lock is free for at least this long per call period
 
 bool Engine::run_exclusive(std::function<bool()> fn)
 {
@@ -839,7 +846,42 @@ bool Engine::run_exclusive(std::function<bool()> fn)
     {
         if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_acquire) < kStreamingWindowNs)
         {
-            // a stream is running: hand the section to the audio thread's next call and wait for it (this is the control thread)
+            const long long period = mAudioPeriodNs.load(std::memory_order_relaxed), hold = mAudioHoldNs.load(std::memory_order_relaxed);
+            if (period > 0 && period - hold >= kTurnMinGapNs)
+            {
+                // a paced stream: a control TURN — behind the audio thread's next release of the lock, in the gap before its next call
+                uint64_t seq = mEnqueueSeq.load(std::memory_order_acquire);
+                const long long t0 = steady_ns();
+                int spins = 0;
+                bool stopped = false;
+                for (;;)
+                {
+                    const uint64_t now_seq = mEnqueueSeq.load(std::memory_order_acquire);
+                    if (now_seq != seq)
+                    {
+                        std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
+                        if (lk.owns_lock())
+                        {
+                            bool ok = fn();
+                            // the restart the section raised (set() always ends in reset()) is applied here too, at this very block
+                            // boundary: what the audio thread would otherwise do at the start of its next call
+                            ok = ok && apply_pending_resets();
+                            mCtlTurns++;
+                            return ok;
+                        }
+                        seq = now_seq;                      // (the next call is in already: behind that one, then)
+                    }
+                    if ((++spins & 63) == 0)
+                    {
+                        const long long waited = steady_ns() - t0;
+                        if (waited > 2 * kStreamingWindowNs) { stopped = true; break; }
+                        if (waited > 3000000) std::this_thread::sleep_for(std::chrono::microseconds(30));     // (a slow stream: stop burning the core)
+                    }
+                    cpu_relax();
+                }
+                if (stopped) continue;                      // no call came: the stream has stopped — look at the clock again
+            }
+            // a stream without gaps: hand the section to the audio thread's next call and wait for it (this is the control thread)
             CtlJob job;
             job.fn = fn;
             mMailbox.store(&job, std::memory_order_release);
@@ -872,7 +914,18 @@ bool Engine::run_exclusive(std::function<bool()> fn)
 // audio thread, engine lock held, before it looks at the engine's state
 void Engine::audio_enter()
 {
-    mLastAudioNs.store(steady_ns(), std::memory_order_release);
+    const long long now = steady_ns();
+    const long long since = now - mCallStartNs;
+    if (mCallStartNs && since > 0 && since < kStreamingWindowNs)
+    {
+        // start-to-start of the calls, smoothed (1/8): what a control thread reads to tell a paced stream from back-to-back calls
+        const long long p = mAudioPeriodNs.load(std::memory_order_relaxed);
+        mAudioPeriodNs.store(p ? p + (since - p) / 8 : since, std::memory_order_relaxed);
+    }
+    else if (since >= kStreamingWindowNs)
+        mAudioPeriodNs.store(0, std::memory_order_relaxed);         // (a new stream: no estimate yet)
+    mCallStartNs = now;
+    mLastAudioNs.store(now, std::memory_order_release);
     mAudioThread.store(this_thread_hash(), std::memory_order_release);
     if (mMailbox.load(std::memory_order_acquire))
     {
@@ -885,16 +938,55 @@ void Engine::audio_enter()
     }
 }
 
+// audio thread, end of a call's enqueue: the lock goes back and control threads waiting for a turn hear of it
+void Engine::audio_leave(std::unique_lock<std::mutex> &lk)
+{
+    const long long now = steady_ns();
+    const long long held = now - mCallStartNs;
+    const long long h = mAudioHoldNs.load(std::memory_order_relaxed);
+    mAudioHoldNs.store(h ? h + (held - h) / 8 : held, std::memory_order_relaxed);
+    mLastAudioNs.store(now, std::memory_order_release);
+    if (mMailbox.load(std::memory_order_acquire))
+    {
+        // (a section posted while this call was being enqueued: between this block and the next, as at the start of a call)
+        if (CtlJob *job = mMailbox.exchange(nullptr, std::memory_order_acq_rel))
+        {
+            job->ok = job->fn();
+            mMailboxRuns++;
+            job->done.store(true, std::memory_order_release);
+        }
+    }
+    if (lk.owns_lock()) lk.unlock();
+    mEnqueueSeq.fetch_add(1, std::memory_order_release);
+}
+
 // (flag writes, no lock: consumed — exchanged — by the next block's apply_pending_resets)
 void Engine::reset_pair(uint32_t in, uint32_t out)
 {
     if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return;
     __atomic_store_n(&mPending[pair_index(in, out)], (uint8_t) 1, __ATOMIC_RELEASE);
+    apply_resets_in_a_turn();
 }
 
 void Engine::reset_all()
 {
     for (size_t p = 0; p < mPending.size(); p++) __atomic_store_n(&mPending[p], (uint8_t) 1, __ATOMIC_RELEASE);
+    apply_resets_in_a_turn();
+}
+
+// A control thread resetting pairs of a PACED stream applies the restart itself, in a control turn (its fence, retiring kernels and
+// ghost spectra are device work the audio thread need not enqueue); everywhere else the flags wait for the next block, as the
+// reference's reset flags do (MonoConvolve.cpp:148-152).
+void Engine::apply_resets_in_a_turn()
+{
+    if (mAudioThread.load(std::memory_order_acquire) == this_thread_hash()) return;
+    if (steady_ns() - mLastAudioNs.load(std::memory_order_acquire) >= kStreamingWindowNs) return;
+    const long long period = mAudioPeriodNs.load(std::memory_order_relaxed), hold = mAudioHoldNs.load(std::memory_order_relaxed);
+    if (!(period > 0 && period - hold >= kTurnMinGapNs)) return;
+    std::unique_lock<std::mutex> gs(mSetMutex, std::try_to_lock);       // (control calls are serialised; one in progress applies the flags itself)
+    if (!gs.owns_lock()) return;
+    DeviceGuard dg(mDevice);
+    (void) run_exclusive([]() -> bool { return true; });
 }
 
 // Every loaded pair restarts: clear the rings and restart the hop clock.  The input-spectrum rings are not

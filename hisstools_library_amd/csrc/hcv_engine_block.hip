@@ -782,7 +782,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
     }
     HCV_TRY(hipEventRecord(mEvHostDone, mStream));
-    audio_enter();                      // (stamp the clock at the end of the enqueue too, and serve a section posted meanwhile)
+    audio_leave(lk);                    // (the clock, a section posted meanwhile, the lock back and a waiting control thread's turn)
     return true;
 }
 
@@ -869,7 +869,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
             HCV_TRY(hipMemcpy2DAsync(outs_host + pos, sizeof(float) * (size_t) out_stride, mDevOut, sizeof(float) * B, sizeof(float) * B, nout_act,
                                      hipMemcpyDeviceToHost, mStream));
         HCV_TRY(hipEventRecord(mEvHostDone, mStream));
-        lk.unlock();
+        audio_leave(lk);
         HCV_TRY(hipEventSynchronize(mEvHostDone));
     }
     if (mProfiling) collect_events();
@@ -907,8 +907,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
             if (!enqueue_chunk(ins + pos, in_stride, outs + pos, out_stride, nin_act, nout_act, B)) return false;
         }
-        mLastAudioNs.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
-                           std::memory_order_release);
+        audio_leave(lk);
     }
     if (sync) return synchronize();
     return true;

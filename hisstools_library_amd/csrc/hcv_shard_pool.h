@@ -2,10 +2,14 @@
 // calls of one process() block — a dozen launches, records and waits per engine, 15-100 us of host time each (DESIGN section 8's
 // price list) — are issued side by side on the shards' devices instead of one shard after the other from the caller's thread.
 //
-// The caller's (audio) thread posts a job by bumping each worker's sequence number, runs shard 0 itself and then spins until
-// every worker has reported; it never sleeps and takes no lock.  A worker spins for about 100 us after its last job — back-to-back
-// blocks find it awake — and then sleeps on a futex; the Dekker pair (post: store seq, load asleep | worker: store asleep, futex
-// re-checks seq in the kernel) makes a lost wake-up impossible.
+// The caller's (audio) thread posts a job by bumping each worker's sequence number, runs shard 0 itself and then waits until every
+// worker has reported: a bounded spin, then yields (it never sleeps and takes no lock).  A worker spins after its last job for about
+// one and a half times the interval between the last two jobs (at least 100 us, at most 3 ms) — the next callback of a paced stream
+// finds it awake, without a futex wake and the scheduler's latency per shard — and then sleeps on a futex; the Dekker pair (post:
+// store seq, load asleep | worker: store asleep, futex re-checks seq in the kernel) makes a lost wake-up impossible.  Workers take
+// the poster's scheduling class and priority when they see them change (a SCHED_FIFO audio thread would otherwise starve the very
+// threads it waits for; where the process may not raise them, the yields above are what is left) and its identity as "the audio
+// thread" of their engines (hcv_engine.h: set_thread_audio_identity).
 #pragma once
 
 #include "hcv_engine.h"
@@ -19,6 +23,8 @@
 #include <vector>
 
 #include <linux/futex.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -61,6 +67,17 @@ namespace hcv
         {
             mFn = fn;
             mCtx = ctx;
+            mPoster = current_thread_identity();
+            {
+                // (two syscall-free reads on glibc; published with the jobs' sequence numbers)
+                int policy = SCHED_OTHER;
+                sched_param sp {};
+                if (pthread_getschedparam(pthread_self(), &policy, &sp) == 0)
+                {
+                    mPolicy = policy;
+                    mPriority = sp.sched_priority;
+                }
+            }
             uint32_t target[64];
             for (int k = 1; k < mN; k++)
             {
@@ -75,7 +92,12 @@ namespace hcv
             {
                 if (!(mask >> k & 1)) continue;
                 Worker &w = *mWorkers[(size_t) k - 1];
-                while (w.done.load(std::memory_order_acquire) != target[k]) cpu_relax();
+                int spins = 0;
+                while (w.done.load(std::memory_order_acquire) != target[k])
+                {
+                    cpu_relax();
+                    if (++spins > 20000) sched_yield();     // (~100 us of spinning: from here on the core is offered to whoever is runnable)
+                }
                 ok = ok && w.ok;
             }
             return ok;
@@ -100,6 +122,9 @@ namespace hcv
         {
             (void) hipSetDevice(w.device);
             uint32_t seen = 0;
+            int policy = SCHED_OTHER, priority = 0;
+            auto last_job = std::chrono::steady_clock::now();
+            std::chrono::nanoseconds window(100000);
             for (;;)
             {
                 // spin, then sleep
@@ -109,7 +134,7 @@ namespace hcv
                 while ((s = w.seq.load(std::memory_order_acquire)) == seen)
                 {
                     cpu_relax();
-                    if ((++polls & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100))
+                    if ((++polls & 255) == 0 && std::chrono::steady_clock::now() - t0 > window)
                     {
                         w.asleep.store(1, std::memory_order_seq_cst);
                         while ((s = w.seq.load(std::memory_order_seq_cst)) == seen)
@@ -120,6 +145,22 @@ namespace hcv
                 }
                 if (mQuit.load()) return;
                 seen = s;
+                {
+                    // the idle spin covers the stream's period (1.5 x the last interval, 100 us .. 3 ms)
+                    const auto now = std::chrono::steady_clock::now();
+                    const auto gap = std::chrono::duration_cast<std::chrono::nanoseconds>(now - last_job);
+                    last_job = now;
+                    window = std::min(std::chrono::nanoseconds(3000000), std::max(std::chrono::nanoseconds(100000), gap + gap / 2));
+                }
+                if (mPolicy != policy || mPriority != priority)
+                {
+                    policy = mPolicy;
+                    priority = mPriority;
+                    sched_param sp {};
+                    sp.sched_priority = priority;
+                    (void) pthread_setschedparam(pthread_self(), policy, &sp);      // (refused without the privilege: the poster's yields remain)
+                }
+                set_thread_audio_identity(mPoster);
                 w.ok = mFn(mCtx, index);
                 w.done.store(s, std::memory_order_release);
             }
@@ -128,6 +169,8 @@ namespace hcv
         int mN = 0;
         Fn mFn = nullptr;
         void *mCtx = nullptr;
+        size_t mPoster = 0;                 // (plain fields: published by the release store of each worker's sequence number)
+        int mPolicy = SCHED_OTHER, mPriority = 0;
         std::atomic<bool> mQuit { false };
         std::vector<std::unique_ptr<Worker>> mWorkers;
     };

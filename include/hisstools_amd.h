@@ -191,7 +191,8 @@ HCV_API int hcv_host_unregister(void *ptr);
 typedef struct hcv_rt_stats
 {
     uint64_t lock_contended, lock_wait_ns_max, blocks_muted;
-    uint64_t mailbox_runs;      /* swap sections of control calls that the audio thread ran between two of its blocks (running stream) */
+    uint64_t mailbox_runs;      /* swap sections of control calls that the audio thread ran between two of its blocks (a stream without gaps) */
+    uint64_t ctl_turns;         /* swap sections control threads ran themselves, in the gap between two calls of a paced stream */
 } hcv_rt_stats;
 HCV_API int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out);
 

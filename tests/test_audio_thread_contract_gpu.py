@@ -1,11 +1,14 @@
 """The audio-thread contract of the reference (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:118-140,181-183):
 `process` never waits for a control thread's `set` / `resize` — not for the IR upload, not for an allocation, not for the
 device.  The reference mutes the pair being replaced for the blocks processed meanwhile; here the pair keeps playing its
-previous IR until the staged spectra are swapped in (engine.h: set_ir phases A / B).  STRUCTURALLY: while a stream is running
-(a process call within the last 20 ms) no control call takes the engine lock at all — its swap section is posted to the
-engine's mailbox and the audio thread runs it itself at the start of its next call (hcv_engine.h: CtlJob) — so a process call of
-a running stream cannot find the lock taken by a set / resize / reset: `lock_contended` and `lock_wait_ns_max` are exactly 0, not
-small, and `mailbox_runs` counts the sections the audio thread ran.
+previous IR until the staged spectra are swapped in (engine.h: set_ir phases A / B).  The swap section itself — retiring kernels,
+device-to-device copies, the restart's fence and ghost spectra: a few dozen HIP calls — is not the audio thread's work either
+(round 4, hcv_engine.h "Control TURNS"): beside a PACED stream the control thread waits for the audio thread to release the
+engine lock at the end of its next enqueue, takes the lock right behind it and runs the section, and the restart it raises, in
+the gap before the next call — `ctl_turns` counts them; the audio thread's part is nothing, `mailbox_runs` (sections the audio
+thread ran itself: the form kept for streams without gaps) stays near zero, and a call finds the lock taken only if a section
+overruns the gap (a preempted control thread): `lock_contended` is expected 0 and tolerated up to 2 short waits, no block is ever
+given up.
 
 A control thread loops set(resize=True) with GROWING 10 s-class IRs on a 16x16 zero-latency engine — every growth re-strides the
 tail stage's whole spectrum store — while the audio thread issues paced 128-sample calls.  Asserted: the calls stay inside the
@@ -51,11 +54,11 @@ def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
 
 def test_process_never_waits_for_set_or_regrow_at_32_samples_per_call(H, oracle):
     """The same contract at the smallest block size hosts use: 32-sample calls (0.67 ms budget), 4200 of them (2.8 s of audio), beside
-    ~800 set(resize) calls.  The structural criteria are the same (lock never found taken, no block given up, one mailbox section per
-    set); of the wall-clock ones p99 stays below 3/4 of the budget (measured 0.36 ms), and the calls that run a swap section with its
-    retiring kernels may exceed 0.67 ms: 1 - 5 of 4200 do (0.7 - 1.1 ms; up to 6 ms when a regrow has the driver map new device
-    memory) — at most 12 are tolerated."""
-    _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200, over_max=12)
+    ~700 set(resize) calls.  The same criteria (no block given up, the sections in control turns); of the wall-clock ones p99 stays
+    below 3/4 of the budget.  Measured with the sections in control turns: p50 0.056, p99 0.163, max 0.316 ms, none of 4200 over
+    budget (round 3, sections on the audio thread: 1 - 5 calls at 0.7 - 1.1 ms); two are tolerated — the caller is a Python thread on a
+    shared host, and a regrow that has the driver map new device memory stalls every HIP call of the process."""
+    _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200, over_max=2)
 
 
 def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=4):
@@ -127,12 +130,14 @@ def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=4):
     print(f"[{entry}] over budget: {int((ts > 1e3 * RB / fs).sum())} of {ncalls} calls, slowest five {np.sort(ts)[-5:].round(3).tolist()}")
     print(f"[{entry}] {sets['n']} set(resize) calls (worst {sets['worst_ms']:.1f} ms each) beside {ncalls} paced calls: p50 {np.percentile(ts, 50):.3f} "
           f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); lock contended {rt['lock_contended']}x, longest wait "
-          f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}, sections run by the audio thread {rt['mailbox_runs']}")
+          f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}, sections run by control threads in their turns "
+          f"{rt['ctl_turns']}, by the audio thread {rt['mailbox_runs']}")
     assert not sets["errors"] and sets["n"] >= 8                         # every length was loaded at least once: the stage regrew
-    # STRUCTURAL: the stream never stopped, so every swap section went through the mailbox — the audio thread never found the
-    # engine lock taken, never waited for it, never gave a block up; and it ran at least one section per set()
-    assert rt["lock_contended"] == 0 and rt["lock_wait_ns_max"] == 0 and rt["blocks_muted"] == 0, rt
-    assert rt["mailbox_runs"] >= sets["n"] - 1, (rt, sets["n"])
+    # the stream never stopped and is paced: every swap section ran in a control turn between two calls (at least one per set();
+    # a regrow's pointer swap is one more), next to none on the audio thread; no block was given up, and the lock was found taken
+    # at most twice, briefly (a section that overran the gap)
+    assert rt["blocks_muted"] == 0 and rt["lock_contended"] <= 2 and rt["lock_wait_ns_max"] < 1_000_000, rt
+    assert rt["ctl_turns"] + rt["mailbox_runs"] >= sets["n"] - 1 and rt["mailbox_runs"] <= max(2, sets["n"] // 20), (rt, sets["n"])
     # The wall-clock side is measured from a Python thread on a shared host, where a preempted caller shows up as one slow call:
     # all but a handful of the 1400 calls inside the budget, none that looks like a stall behind an upload or a regrow (tens to
     # hundreds of milliseconds in round 1), p99 well inside it

@@ -203,6 +203,9 @@ namespace hcv
         long long mCallStartNs = 0;                         // (audio thread) start of the call in progress
         void audio_leave(std::unique_lock<std::mutex> &lk); // audio thread: end of a call's enqueue — stamp, release the lock, announce it
         bool apply_pending_resets();
+        std::atomic<uint32_t> mResetAllGen { 0 };           // reset_all() calls so far
+        uint32_t mResetAllSeen = 0;                         // ... applied so far (audio side)
+        std::vector<uint8_t> mTaken;                        // apply_pending_resets: the flags taken this block (no allocation on the audio thread)
         void apply_resets_in_a_turn();
         bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
         struct Block;

@@ -970,7 +970,9 @@ void Engine::reset_pair(uint32_t in, uint32_t out)
 
 void Engine::reset_all()
 {
-    for (size_t p = 0; p < mPending.size(); p++) __atomic_store_n(&mPending[p], (uint8_t) 1, __ATOMIC_RELEASE);
+    // (ONE atomic generation count, not a flag per pair raised one after the other: the block that sees it restarts EVERY pair at the
+    // same sample — a block racing the loop used to restart some pairs now and the rest one block later)
+    mResetAllGen.fetch_add(1, std::memory_order_release);
     apply_resets_in_a_turn();
 }
 

@@ -312,14 +312,19 @@ bool Engine::apply_pending_resets()
 {
     // (reset_pair / reset_all write the flags from other threads without the lock: a cheap look first, then every flag is TAKEN —
     // exchanged with 0 — so that one raised after this point waits for the next block instead of being wiped)
-    bool any = false;
+    const uint32_t gen = mResetAllGen.load(std::memory_order_acquire);
+    const bool reset_all_seen = gen != mResetAllSeen;
+    bool any = reset_all_seen;
     for (size_t p = 0; p < mPending.size() && !any; p++) any = __atomic_load_n(&mPending[p], __ATOMIC_ACQUIRE) != 0;
     if (!any) return true;
-    std::vector<uint8_t> taken(mPending.size());
+    mResetAllSeen = gen;
+    std::vector<uint8_t> &taken = mTaken;
+    if (taken.size() != mPending.size()) taken.assign(mPending.size(), 0);
     bool all = true;
     for (size_t p = 0; p < mPending.size(); p++)
     {
         taken[p] = __atomic_exchange_n(&mPending[p], (uint8_t) 0, __ATOMIC_ACQ_REL);
+        if (reset_all_seen) taken[p] = 1;           // (reset_all: every pair restarts at this sample)
         if (mLoaded[p] && !taken[p]) all = false;
     }
     if (!fence_background(!all && exact_restart())) return false;

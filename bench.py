@@ -458,7 +458,8 @@ def flat_scalars(line):
     ex = cfg.get("extended_layout") or {}
     if ex:
         out.update({"extended_tail_ratio": ex.get("tail_ratio"), "extended_msamples_per_s": ex.get("msamples_per_s"), "extended_ms_per_step": ex.get("ms_per_step"),
-                    "extended_step_frac": (ex.get("roofline_step") or {}).get("frac"), "extended_max_rel_err": (ex.get("self_check") or {}).get("max_rel_err"),
+                    "extended_step_frac": (ex.get("roofline_step") or {}).get("frac"), "extended_step_traffic": (ex.get("roofline_step") or {}).get("traffic"),
+                    "extended_max_rel_err": (ex.get("self_check") or {}).get("max_rel_err"),
                     "extended_error": ex.get("error")})
     for d in cfg.get("also") or []:
         if not d:
@@ -573,7 +574,7 @@ def digest_of(d):
         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
                                             "launches", "steady_launches", "traffic", "traffic_source", "profiled_ms_per_step", "box_read_GBps",
                                             "achieved_over_box_read", "box_copy_GBps", "avg_launch_source", "kernel_share_of_step", "whole_step_frac",
-                                            "note_ceiling") if k in rf},
+                                            "note_ceiling", "survey_8d_ceiling_msamples_per_s") if k in rf},
         "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches", "error") if k in sc},
         "cpu_baseline": {k: (d.get("cpu_baseline") or {}).get(k) for k in ("value", "unit", "cores", "kind", "flags", "block", "best_of", "b2048",
                                                                            "wide_b512", "wide_b2048")},
@@ -882,6 +883,13 @@ def bench_line(args, ctx):
             extended["roofline_step"] = {"bound": "hbm", "achieved": round(e_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(e_gbs / 8000.0, 4),
                                          "alg_bytes_per_step": int(e_bytes), "sum_partitions": int(e_sum_p),
                                          "note": "whole step (every stage's kernels, transforms included) against SURVEY 8d's bytes for this ladder"}
+            try:
+                tl = json.load(open(os.path.join(ROOT, "profiles", f"traffic_{args.workload}_ladder.json")))
+                extended["roofline_step"]["traffic"] = tl.get("hbm_bytes_per_step")
+                extended["roofline_step"]["traffic_source"] = (f"static: profiles/traffic_{args.workload}_ladder.json (rocprofv3 --pmc passes of bench.py --tail-ratio "
+                                                                f"{args.extended_ratio} on one stream, tools/pmc_ladder.sh), not measured in this run")
+            except Exception:
+                extended["roofline_step"]["traffic"] = None
             extended["note"] = ("MI355X extension, not the reference's partitioning: reported beside the headline, never as it; parity at this scale: "
                                 "tests/test_steady_state_gpu.py::test_config5_extended_ladder_full_depth")
             del e_conv

@@ -280,7 +280,9 @@ namespace
         // (hop largest/2) is capped where a `ratio` times larger FFT can take over, and so on up to 2^20.  The sum is
         // the same convolution; the far tail just moves ratio x fewer bytes per sample per rung.  Only rungs the IR can
         // reach (maxLength) are created.
-        void extend_tail(uint64_t maxLength, uint32_t ratio)
+        // boundaryBytes > 0 (the automatic rule): no rung whose hop boundary would have to stream more than that for its first
+        // partition alone (8 bytes x bins x pairs, all of it inside ONE process call, beside the rung's forward and inverse transforms)
+        void extend_tail(uint64_t maxLength, uint32_t ratio, uint64_t pairs = 0, uint64_t boundaryBytes = 0)
         {
             if (ratio < 2) return;
             const uint64_t latency = zeroLatency ? 0 : sizes[0] >> 1;
@@ -290,6 +292,7 @@ namespace
             {
                 const uint64_t next = cur * ratio, nextOffset = (next >> 1) - latency;
                 if (nextOffset >= maxLength) break;
+                if (boundaryBytes && 8 * (next >> 1) * pairs > boundaryBytes) break;
                 StageCfg st;
                 st.fft_size = (uint32_t) cur;
                 st.offset = curOffset;
@@ -324,6 +327,11 @@ namespace
     // over the matrix (c5 703 partitions / 11.8 GB: 8.8 x faster on the ladder, 64 x 64 with 10 s IRs 58 / 15.7 GB: 2.5 x; 64 x 64 with
     // 2 s IRs, 11 partitions, and the cache-resident one-output engines, which run as ONE launch per block, are faster as they are).
     constexpr uint64_t kLadderMinParts = 32, kLadderMinBytes = uint64_t(1) << 30;
+    // ... and no rung whose hop boundary — its big transforms and its first partition's multiply-accumulate, all in the ONE call that
+    // completes the hop — would hold a real-time caller up for more than about a millisecond: 16 x 16 takes both rungs (the 2^20-point
+    // rung's boundary call: 0.85 ms once per 5.5 s), 64 x 64 the 131072-point rung only (0.5 - 1.0 ms once per 1.4 s; a 2^20-point
+    // rung's boundary would stream 17 GB).  HCV_TAIL_RATIO and the explicit constructors are not bound by it.
+    constexpr uint64_t kLadderBoundaryBytes = 2500000000ull;
 
     struct Matrix
     {
@@ -366,6 +374,10 @@ namespace
             return true;
         }
 
+        // (the boundary bound applies where the RULE chose the ladder)
+        uint64_t boundary_bound() const { return (ladder == kLadderAuto && env_tail_ratio() == kLadderAuto) ? kLadderBoundaryBytes : 0; }
+        uint64_t pair_count() const { return (uint64_t) nout * (diag ? 1 : nin); }
+
         uint32_t ratio_for(uint64_t length) const
         {
             if (ladder != kLadderAuto) return ladder;
@@ -392,7 +404,7 @@ namespace
             const uint32_t ratio = ratio_for(length);
             Layout nl;
             if (!nl.build(args.zero, args.A, args.B, args.C, args.D)) return;
-            nl.extend_tail(length, ratio);
+            nl.extend_tail(length, ratio, pair_count(), boundary_bound());
             laidFor = length;
             if (nl.fixedStages.size() == layout.fixedStages.size()) return;            // the same stage list
             uint64_t cap = length;
@@ -534,7 +546,7 @@ namespace
         m->nin = parallel ? numOuts : numIns;
         m->nout = numOuts;
         m->diag = parallel;
-        m->layout.extend_tail(maxLength, m->ratio_for(maxLength));
+        m->layout.extend_tail(maxLength, m->ratio_for(maxLength), m->pair_count(), m->boundary_bound());
         if (!m->build(numIns, numOuts, parallel, maxLength, device, maxBlock))
         {
             if (err) *err = tlsError;

@@ -85,7 +85,10 @@ def test_the_automatic_rule_on_the_baseline_shapes(H, oracle):
     cache resident, one launch per block as it is).  The stage list is laid when the first IR arrives."""
     if os.environ.get("HCV_TAIL_RATIO"):
         pytest.skip("HCV_TAIL_RATIO is set")
+    # (32 x 32 with 700 000-sample IRs: the 2^20-point rung is within reach of the IR, but its hop boundary would stream 4.3 GB inside one
+    #  process call — the rule stops at the 131072-point rung)
     for (nin, nout, L, want) in ((16, 16, 5760000, [256, 1024, 4096, 16384, 131072, 1 << 20]), (64, 64, 480000, [256, 1024, 4096, 16384, 131072]),
+                                 (32, 32, 700000, [256, 1024, 4096, 16384, 131072]),
                                  (64, 64, 96000, [256, 1024, 4096, 16384]), (8, 1, 240000, [256, 1024, 4096, 16384])):
         c = H.Convolver(nin, nout, 0)
         assert [s["fft_size"] for s in c.stage_stats()] == [256, 1024, 4096, 16384]

@@ -15,7 +15,8 @@ w, B = sys.argv[1], int(sys.argv[2])
 hops = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 nin, nout, L, fs, layout = bench.WORKLOADS[w]
 dev = torch.device("cuda", 0)
-conv = H.Convolver(nin, nout, 0, device=0, maxBlock=max(B, 8192), custom=(L, *layout))
+TAIL_RATIO = int(os.environ.get("TAIL_RATIO", "0"))       # the same workload on the extended far-tail ladder
+conv = H.Convolver(nin, nout, 0, device=0, maxBlock=max(B, 8192), custom=(L, *layout), tailRatio=TAIL_RATIO)
 g = torch.Generator(device=dev)
 decay = torch.pow(torch.tensor(10.0, device=dev), -3.0 * torch.arange(L, device=dev, dtype=torch.float32) / L)
 for o in range(nout):
@@ -26,7 +27,7 @@ for o in range(nout):
         torch.cuda.synchronize()
         assert conv.set_dev(i, o, h.data_ptr(), L, True) == 0
 tail = [s for s in layout[1:] if s][-1]
-ncalls = hops * (tail // 2) // B
+ncalls = min(hops * (tail // 2) // B, int(os.environ.get("MAX_CALLS", "1000000")))
 xs = torch.rand((nin, B), device=dev) * 2 - 1
 ys = torch.zeros((nout, B), device=dev)
 torch.cuda.synchronize()
@@ -54,7 +55,7 @@ for k in range(ncalls):
     conv.process_dev(xs.data_ptr(), B, ys.data_ptr(), B, nin, nout, B, sync=True)
     ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e3
-print(f"{w} block={B} paced={int(paced)} defer={os.environ.get('HCV_DEFER','1')}: calls={ncalls} mean={ts.mean():.3f} p50={np.percentile(ts,50):.3f} p99={np.percentile(ts,99):.3f} "
+print(f"{w}{' ladder x' + str(TAIL_RATIO) if TAIL_RATIO else ''} block={B} paced={int(paced)} defer={os.environ.get('HCV_DEFER','1')}: calls={ncalls} mean={ts.mean():.3f} p50={np.percentile(ts,50):.3f} p99={np.percentile(ts,99):.3f} "
       f"max={ts.max():.3f} ms | budget {1e3*B/fs:.3f} ms | sum={ts.sum():.1f} ms for {1e3*ncalls*B/fs:.1f} ms of audio")
 thr = float(os.environ.get("SLOW_MS", "0.6"))
 slow = [(i, round(float(t), 3)) for i, t in enumerate(ts) if t > thr]

@@ -635,15 +635,43 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         // it (one cross-stream hand-over less in the chain scatter -> head -> emit of a plain real-time call) and only needs the ring
         // complete up to the call's first sample — the previous block's input event
         const bool head_direct = fir_head_is_small((int) B, (int) nin_act, (int) mTdLpad, mCfg.diag ? 1 : 0) && !direct_in;
-        HCV_TRY(wt(sTd, mEvInput[head_direct ? (q ^ 1) : q]));
-        // (the previous block's input event is older than this call's control work — new taps, reset fences, an upload of the
-        // block itself, a foreign `after` event — which this block's own input event would have put in front of the head)
-        if (head_direct && ctl_was_dirty && sTd != mStream) HCV_TRY(wt(sTd, mEvCtl));
-        HCV_TRY(wt(sTd, mEvEmit[q]));      // emit(k-2) has consumed tdout[q]
-        const bool check = td_check;
-        HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
-                                n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, sTd, head_direct ? din : nullptr, in_stride));
-        HCV_TRY(rec(mEvTd[q], sTd));
+        // A PLAIN small call — it completes no hop of any stage (three calls in four at 32 samples per call) — has nothing to wait
+        // for but its head: the head kernel then delivers the block itself, on the main stream (the stages' timelines added and
+        // cleared as emit would: launch_fir_head's `emit`), and the emit launch with its hand-over from the head stream goes:
+        // scatter || head + emit instead of scatter || head -> emit.
+        bool plain = head_direct && !leaving && !blk.direct_out && !serial;
+        for (size_t si = 0; plain && si < mStages.size(); si++) plain = (n0 + B) / mStages[si]->M == n0 / mStages[si]->M;
+        if (plain)
+        {
+            EmitSources all;
+            all.count = 0;
+            for (Stage *st : mStages)
+            {
+                all.timeline[all.count] = st->timeline;
+                all.stride[all.count] = st->tl_len;
+                all.mask[all.count] = st->tl_len - 1;
+                all.count++;
+            }
+            // (the main stream is behind the previous block's emit and this call's control work already; the ring up to the call's
+            // first sample is the previous block's input event)
+            HCV_TRY(wt(mStream, mEvInput[q ^ 1]));
+            HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, 0, n0, (int) B,
+                                    mTdValid, td_check, dout, out_stride, mStream, din, in_stride, &all));
+            HCV_TRY(rec(mEvTd[q], mStream));
+            blk.emitted = true;
+        }
+        else
+        {
+            HCV_TRY(wt(sTd, mEvInput[head_direct ? (q ^ 1) : q]));
+            // (the previous block's input event is older than this call's control work — new taps, reset fences, an upload of the
+            // block itself, a foreign `after` event — which this block's own input event would have put in front of the head)
+            if (head_direct && ctl_was_dirty && sTd != mStream) HCV_TRY(wt(sTd, mEvCtl));
+            HCV_TRY(wt(sTd, mEvEmit[q]));      // emit(k-2) has consumed tdout[q]
+            const bool check = td_check;
+            HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, mCfg.diag ? 1 : 0,
+                                    n0, (int) B, mTdValid, check, mTdOut[q], mMaxBlock, sTd, head_direct ? din : nullptr, in_stride));
+            HCV_TRY(rec(mEvTd[q], sTd));
+        }
     }
 
     // Tail gate: when this block carries a hop of a long, bandwidth-bound tail stage, the shorter stages' MACs are held
@@ -699,7 +727,13 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     }
     xcd_pin_hint(false);
 
-    if (!blk.direct_out)
+    if (blk.emitted)
+    {
+        // (the head kernel delivered the block; the main stream still ends behind the scatter)
+        HCV_TRY(wt(mStream, mEvInput[q]));
+        HCV_TRY(rec(mEvEmit[q], mStream));
+    }
+    else if (!blk.direct_out)
     {
         if (td) HCV_TRY(wt(mStream, mEvTd[q]));
         HCV_TRY(wt(mStream, mEvInput[q]));       // a block with no live stage still orders after its scatter

@@ -104,7 +104,8 @@ struct Engine::Stage
     unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
     unsigned long long coop_seq = 0;        // fused blocks launched so far
-    bool coop_off = false;              // a fused launch was refused by the runtime: this stage takes the separate kernels from then on
+    bool coop_off = false;
+             // a fused launch was refused by the runtime: this stage takes the separate kernels from then on
     // exact per-pair restart: device table of the live ghost entries of this stage, grouped by output
     int *gh_start = nullptr;            // [nout + 1]
     GhostEntry *gh_ent = nullptr;       // [pairs]
@@ -155,6 +156,7 @@ struct Engine::Block
     bool pipe2 = false;                 // serial whole-hop block with its forward transforms on the pipe stream
     bool direct_out = false;            // whole-hop block: the inverse writes the caller's block itself, no timeline, no emit launch
     bool direct_in = false;             // the (only) running stage's forward FFTs read the caller's block themselves: no scatter launch
+    bool emitted = false;               // a plain small call: the head kernel has delivered the block itself (no emit launch)
     int tail_gate = 0;
     hipEvent_t gate = nullptr;          // the tail's spectral_mac of this block has finished (tail gate)
     hipStream_t main = nullptr, sIn = nullptr, sTd = nullptr;

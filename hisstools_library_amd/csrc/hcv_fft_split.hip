@@ -23,6 +23,7 @@
 
 #include "hcv_engine.h"
 #include "hcv_fft_device.h"
+#include "hcv_fused_sync.h"
 
 #include <cstdlib>
 #include <string>
@@ -142,32 +143,6 @@ namespace
         const float4 *src = reinterpret_cast<const float4 *>(tws);
         float4 *dst = reinterpret_cast<float4 *>(tl);
         for (int e = tid; e < V; e += TG) dst[e] = src[e];
-    }
-
-    // AGENT = the value is handed to other workgroups of the SAME launch (the fused block kernel): written through with
-    // agent-scope relaxed atomics instead of plain stores (MI355X_MICROARCH.md: 8-byte agent atomics on both sides)
-    template <bool AGENT> __device__ __forceinline__ void put2(float2 *p, float2 v)
-    {
-        if constexpr (AGENT)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long) __float_as_uint(v.y) << 32) | __float_as_uint(v.x),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-            *p = v;
-    }
-    template <bool AGENT> __device__ __forceinline__ void put1(float *p, float v)
-    {
-        if constexpr (AGENT) __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *p = v;
-    }
-    template <bool AGENT> __device__ __forceinline__ float2 get2(const float2 *p)
-    {
-        if constexpr (AGENT)
-        {
-            const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return make_float2(__uint_as_float((unsigned) a), __uint_as_float((unsigned) (a >> 32)));
-        }
-        else
-            return *p;
     }
 
     // forward: bin R k + r (and its mirror) of the packed half spectrum
@@ -429,15 +404,6 @@ __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__r
 //     that got onto the chip early does the producers' work instead of idling).  The task's own workgroup, placed late, repeats
 //     it (same values) and is the only one counted in `bar`, so the counters' running totals stay exact.
 // HCV_COOP_SPIN = polls before helping (default 64; 0 = help at once: the tests run the whole parity suite that way).
-struct FusedSync
-{
-    unsigned *bar;                       // [2] arrival counters: forward transforms, multiply-accumulate
-    unsigned long long *flagF, *flagM;   // per task: sequence number of the launch that last completed it
-    unsigned long long seq;              // this launch
-    unsigned targetA, targetB;           // what the two counters read when this launch's producers have all arrived
-    int spin;
-};
-
 struct FusedBlockParams
 {
     float *hist;
@@ -452,132 +418,6 @@ struct FusedBlockParams
     int Rring, P, hmac_mod;     // hmac_mod = (hop the MAC's partition 0 reads) mod Rring
     int pin;
 };
-
-// (every helper takes the thread index from its caller: a workitem-id read inside the out-of-line slow path would make the kernel
-// keep the packed ids alive in a register of their own up to the call — one register too many for the 128 of the multi-hop kernel)
-// thread 0's value, to every thread of the workgroup
-__device__ __forceinline__ int wg_broadcast(int tid, int v, int *slot)
-{
-    __syncthreads();
-    if (tid == 0) *slot = v;
-    __syncthreads();
-    return *slot;
-}
-// publish a finished task: every thread's agent-scope stores have been written through, then one lane sets the task's flag and
-// — the task's own workgroup only (counter != nullptr) — counts the workgroup in
-__device__ __forceinline__ void grid_publish(int tid, unsigned long long *flag, unsigned long long seq, unsigned *counter)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-    {
-        __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (counter) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-// bounded wait: true when the counter reached `target` within `spin` polls.  FRESH: `slot` has not been read since the
-// workgroup's last barrier (the ordinary path gives each of its two waits a slot of its own), which saves the barrier in front
-template <bool FRESH = false> __device__ __forceinline__ bool grid_wait_bounded(int tid, unsigned *counter, unsigned target, int spin, int *slot)
-{
-    int ok = 0;
-    if (tid == 0)
-        for (int k = 0; k < spin; k++)
-        {
-            ok = (int) (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
-            if (ok) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-    if constexpr (FRESH)
-    {
-        if (tid == 0) *slot = ok;
-        __syncthreads();
-        return *slot != 0;
-    }
-    else
-        return wg_broadcast(tid, ok, slot) != 0;
-}
-__device__ __forceinline__ bool task_done(int tid, const unsigned long long *flag, unsigned long long seq, int *slot)
-{
-    int d = 0;
-    if (tid == 0) d = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq;
-    return wg_broadcast(tid, d, slot) != 0;
-}
-
-// What a multiply-accumulate workgroup does once one of its waits has run out (`from_mac_wait`: the second one).  Kept OUT OF
-// LINE and entered as the last thing the kernel does, so that the ordinary path — straight-line code, the bodies inlined once —
-// pays nothing for it: no registers held across it, no scratch, no extra copies of the transforms in its instruction stream (a
-// helping loop around the inlined bodies was measured against exactly that: hoisted loop invariants took the 1 x 1 kernel from
-// 98 to 222 registers and put the other two into scratch).  `Bodies` provides forward(task), mac_old(m) — the part of
-// multiply-accumulate task m that needs nothing of this launch —, mac_new(m) — the rest, the reduction and the store of Y — and
-// inverse(j).  Helpers start at different tasks and skip what has been completed meanwhile: they share the work instead of
-// repeating it.
-template <class Bodies>
-__device__ __forceinline__ void fused_slow_path(Bodies &b, const FusedSync &sy, int m, int nfwd, int nmac, int ninv, bool from_mac_wait, int *slot)
-{
-    if (!from_mac_wait)
-    {
-        // the forward tasks nobody has completed, then this workgroup's own multiply-accumulate from the start (nothing was kept)
-        const int first = (int) ((long long) m * nfwd / nmac);
-        for (int k = 0; k < nfwd; k++)
-        {
-            int task = first + k;
-            if (task >= nfwd) task -= nfwd;
-            if (task_done(b.tid, sy.flagF + task, sy.seq, slot)) continue;
-            b.forward(task);
-            grid_publish(b.tid, sy.flagF + task, sy.seq, nullptr);
-        }
-        b.mac_old(m);
-        b.mac_new(m);
-        grid_publish(b.tid, sy.flagM + m, sy.seq, sy.bar + 1);
-        if (m >= ninv) return;
-        if (grid_wait_bounded(b.tid, sy.bar + 1, sy.targetB, sy.spin, slot))
-        {
-            b.inverse(m);
-            return;
-        }
-    }
-    // the multiply-accumulate tasks nobody has completed (the forward transforms are known to be in), then the inverse
-    const int first = m * (nmac / ninv) + 1;
-    for (int k = 0; k < nmac; k++)
-    {
-        int task = first + k;
-        if (task >= nmac) task -= nmac;
-        if (task_done(b.tid, sy.flagM + task, sy.seq, slot)) continue;
-        b.mac_old(task);
-        b.mac_new(task);
-        grid_publish(b.tid, sy.flagM + task, sy.seq, nullptr);
-    }
-    b.inverse(m);
-}
-
-// The ordinary path of one workgroup of a fused launch: workgroup w < nfwd runs forward task w; workgroup nfwd + m runs
-// multiply-accumulate task m and, for m < ninv, the inverse.  `Slow` = the kernel's out-of-line entry to fused_slow_path.
-template <class Bodies, class Slow>
-__device__ __forceinline__ void fused_roles(Bodies &b, const FusedSync &sy, int w, int nfwd, int ninv, bool mac_needs_fwd, int *slot, const Slow &slow)
-{
-    if (w < nfwd)
-    {
-        b.forward(w);
-        grid_publish(b.tid, sy.flagF + w, sy.seq, sy.bar);
-        return;
-    }
-    const int m = w - nfwd;
-    b.mac_old(m);
-    if (mac_needs_fwd && !grid_wait_bounded<true>(b.tid, sy.bar, sy.targetA, sy.spin, slot))
-    {
-        slow(m, false);
-        return;
-    }
-    b.mac_new(m);
-    grid_publish(b.tid, sy.flagM + m, sy.seq, sy.bar + 1);
-    if (m >= ninv) return;
-    if (!grid_wait_bounded<true>(b.tid, sy.bar + 1, sy.targetB, sy.spin, slot + 1))
-    {
-        slow(m, true);
-        return;
-    }
-    b.inverse(m);
-}
 
 // Workgroups 0 .. R/2: the forward transform's residue classes; the next R: multiply-accumulate (512 bins each), of which the
 // first R/2 go on to the inverse.  A lone stage (`lone`: its partitions read X[h-1] and older, PartitionedConvolve's one hop of
@@ -1084,41 +924,6 @@ __global__ __launch_bounds__(1024) void fused_block_hops_kernel(FusedHopsParams 
     FusedHopsBodies<LOG2N, LOG2R, TMAX> b = { a, dyn, (int) threadIdx.x };
     fused_roles(b, a.sy, (int) blockIdx.x, a.T * NF, a.T * (R / 2), true, slot_b, [&](int m, bool from_mac_wait)
                 { fused_hops_slow<LOG2N, LOG2R, TMAX>((const FusedHopsParams *) __builtin_amdgcn_kernarg_segment_ptr(), dyn, b.tid, m, from_mac_wait, slot_b); });
-}
-
-// The host's running totals of the two counters and the launch sequence number move only once the runtime has accepted the
-// launch: a refused launch leaves the device counters where they were, and totals that ran ahead of them would make every later
-// launch wait (boundedly — and then redo everything by helping) for arrivals that never come.
-struct FusedHostState
-{
-    unsigned *arrived;          // [2]
-    unsigned long long *seq;
-};
-static int fused_spin()
-{
-    static const int s = std::getenv("HCV_COOP_SPIN") ? std::max(0, std::atoi(std::getenv("HCV_COOP_SPIN"))) : 64;
-    return s;
-}
-static FusedSync fused_sync(unsigned *bar, unsigned long long *flags, const unsigned *arrived, unsigned long long seq, unsigned producers, unsigned macs)
-{
-    FusedSync sy;
-    sy.bar = bar;
-    sy.flagM = flags;                       // [kFusedMacTasks]
-    sy.flagF = flags + kFusedMacTasks;      // [kFusedFwdTasks]
-    sy.seq = seq + 1;
-    sy.targetA = arrived[0] + producers;
-    sy.targetB = arrived[1] + macs;
-    sy.spin = fused_spin();
-    return sy;
-}
-static hipError_t fused_launched(unsigned *arrived, unsigned long long *seq, unsigned producers, unsigned macs)
-{
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    arrived[0] += producers;
-    arrived[1] += macs;
-    *seq += 1;
-    return hipSuccess;
 }
 
 bool fused_block_1x1_applies(int log2n)

@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "hcv_fused_sync.h"
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -36,7 +38,8 @@ template <int TG> __device__ __forceinline__ int wave_uniform_group()
 // Real post-pass of the forward transform (the maths of pass_real_trig_table<false>,
 // HISSTools_FFT_Core.h:934-988): s holds Z = FFT_M(x_even + i x_odd); writes the packed, doubled half
 // spectrum to dst[0..M).
-template <int LOG2M, int TG>
+// (AGENT: the spectrum is handed to other workgroups of the same launch — written through, hcv_fused_sync.h: put2)
+template <int LOG2M, int TG, bool AGENT = false>
 __device__ __forceinline__ void real_post_store(LdsBuf<float2> s, int tid, const float2 *__restrict__ tw, float2 *__restrict__ dst)
 {
     constexpr int M = 1 << LOG2M;
@@ -46,7 +49,7 @@ __device__ __forceinline__ void real_post_store(LdsBuf<float2> s, int tid, const
         {
             float2 z = s[0];
             float t1 = z.x + z.y, t2 = z.x - z.y;
-            dst[0] = make_float2(t1 + t1, t2 + t2);
+            put2<AGENT>(dst, make_float2(t1 + t1, t2 + t2));
         }
         else
         {
@@ -56,8 +59,8 @@ __device__ __forceinline__ void real_post_store(LdsBuf<float2> s, int tid, const
             float r3 = z1.x + z2.x, i3 = z1.y + z2.y, r4 = z1.x - z2.x, i4 = z1.y - z2.y;
             float u1 = (w.x * i3) + (w.y * r4);
             float u2 = (w.y * i3) - (w.x * r4);
-            dst[k] = make_float2(r3 + u1, u2 + i4);
-            dst[m] = make_float2(r3 - u1, u2 - i4);
+            put2<AGENT>(dst + k, make_float2(r3 + u1, u2 + i4));
+            put2<AGENT>(dst + m, make_float2(r3 - u1, u2 - i4));
         }
     }
 }
@@ -253,7 +256,7 @@ struct PreLoad
 
 // Packed spectrum (the sum of `ksplit` partials) of one transform into LDS: every thread first issues all of its loads,
 // then adds and stores — under a saturated HBM a load costs microseconds, so they must not queue behind one another.
-template <int LOG2M, int TG>
+template <int LOG2M, int TG, bool AGENT = false>
 __device__ __forceinline__ void stage_spectrum(LdsBuf<float2> s, int tid, const float2 *__restrict__ src, int ksplit, long long ks_stride, bool live)
 {
     constexpr int M = 1 << LOG2M, EPT = (M + TG - 1) / TG;
@@ -262,7 +265,7 @@ __device__ __forceinline__ void stage_spectrum(LdsBuf<float2> s, int tid, const 
     for (int e = 0; e < EPT; e++)
     {
         const int k = tid + e * TG;
-        v[e] = (live && (M % TG == 0 || k < M)) ? src[k] : make_float2(0.f, 0.f);
+        v[e] = (live && (M % TG == 0 || k < M)) ? get2<AGENT>(src + k) : make_float2(0.f, 0.f);
     }
     for (int ks = 1; ks < ksplit; ks++)
     {
@@ -271,7 +274,7 @@ __device__ __forceinline__ void stage_spectrum(LdsBuf<float2> s, int tid, const 
         for (int e = 0; e < EPT; e++)
         {
             const int k = tid + e * TG;
-            b[e] = (live && (M % TG == 0 || k < M)) ? src[ks * ks_stride + k] : make_float2(0.f, 0.f);
+            b[e] = (live && (M % TG == 0 || k < M)) ? get2<AGENT>(src + ks * ks_stride + k) : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int e = 0; e < EPT; e++)
@@ -582,12 +585,15 @@ __global__ __launch_bounds__(FIR_THREADS) void fir_head_kernel(const float *__re
 // TimeDomainConvolve.cpp:100-163.
 constexpr int FIRS_THREADS = 512, FIRS_SAMPLES = 32, FIRS_SLICES = FIRS_THREADS / FIRS_SAMPLES;
 
-template <bool CHECK>
+// EMIT: the call completes no hop of any stage (three calls in four at 32 samples per call) — the head's samples are then the last
+// thing the call computes, and this kernel delivers the block itself: out = head + what the stages' timelines hold for these samples
+// (cleared as they are read, as emit_kernel does).  One launch and one cross-stream hand-over less in the chain of a plain real-time call.
+template <bool CHECK, bool EMIT>
 __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const float *__restrict__ hist, long long hist_stride, long long hist_mask,
                                                                       const float *__restrict__ taps, int Lpad, int tap_stride, int nin, int nin_alloc,
                                                                       long long n0, int B, const long long *__restrict__ valid_from,
                                                                       float *__restrict__ out, long long out_stride, int ib,
-                                                                      const float *__restrict__ din, long long in_stride)
+                                                                      const float *__restrict__ din, long long in_stride, EmitSources src)
 {
     extern __shared__ __attribute__((aligned(16))) float firs_lds[];
     const int W = FIRS_SAMPLES + Lpad;                     // x[nblk - Lpad .. nblk + 32) of one input
@@ -642,6 +648,17 @@ __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const floa
         float s = acc;
 #pragma unroll
         for (int q = 1; q < FIRS_SLICES; q++) s += red[q * FIRS_SAMPLES + n];
+        if constexpr (EMIT)
+        {
+#pragma unroll
+            for (int k = 0; k < kMaxStages; k++)
+                if (k < src.count)
+                {
+                    float *p = src.timeline[k] + (long long) o * src.stride[k] + ((n0 + nb + n) & src.mask[k]);
+                    s += *p;
+                    *p = 0.f;
+                }
+        }
         out[(long long) o * out_stride + nb + n] = s;
     }
 }
@@ -971,9 +988,10 @@ bool fir_head_is_small(int B, int nin, int Lpad, int diag)
 
 hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                            int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
-                           long long out_stride, hipStream_t st, const float *din, long long in_stride)
+                           long long out_stride, hipStream_t st, const float *din, long long in_stride, const EmitSources *emit)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
+    if (emit && !fir_head_is_small(B, nin, Lpad, diag)) return hipErrorInvalidValue;
     // small calls of matrices with several inputs: taps split over the threads, a batch of inputs staged at once (HCV_FIR_SMALL = 0:
     // the general kernel everywhere)
     if (fir_head_is_small(B, nin, Lpad, diag))
@@ -984,14 +1002,20 @@ hipError_t launch_fir_head(const float *hist, long long hist_stride, long long h
         const int ib = (nin + batches - 1) / batches;
         const size_t lds = sizeof(float) * ((size_t) ib * per_input + FIRS_THREADS);
         const dim3 grid((B + FIRS_SAMPLES - 1) / FIRS_SAMPLES, nout);
-        hipError_t ea = check ? allow_lds(fir_head_small_kernel<true>, lds) : allow_lds(fir_head_small_kernel<false>, lds);
-        if (ea != hipSuccess) return ea;
-        if (check)
-            hipLaunchKernelGGL((fir_head_small_kernel<true>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
-                               nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride);
-        else
-            hipLaunchKernelGGL((fir_head_small_kernel<false>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, nin,
-                               nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride);
+        EmitSources none;
+        none.count = 0;
+#define HCV_FIRS(CHK, EM)                                                                                                                              \
+        {                                                                                                                                              \
+            const hipError_t ea = allow_lds(fir_head_small_kernel<CHK, EM>, lds);                                                                      \
+            if (ea != hipSuccess) return ea;                                                                                                           \
+            hipLaunchKernelGGL((fir_head_small_kernel<CHK, EM>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, \
+                               nin, nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride, emit ? *emit : none);                           \
+        }
+        if (check && emit) HCV_FIRS(true, true)
+        else if (check) HCV_FIRS(true, false)
+        else if (emit) HCV_FIRS(false, true)
+        else HCV_FIRS(false, false)
+#undef HCV_FIRS
         return hipGetLastError();
     }
     // widest output tile that still leaves >= 2 workgroups per CU

@@ -612,25 +612,103 @@ __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const floa
     {
         const int nbi = min(ib, nin - i0);
         __syncthreads();
-        for (int e = tid; e < nbi * W; e += FIRS_THREADS)
+        // the windows, four samples per load where the window starts on a multiple of four (every call of a host with a fixed block
+        // size), and a thread's loads of a round all in flight before the first of them is stored: one load after the other — 20 round
+        // trips to the L2 per thread — was most of the kernel's 22 us
+        const bool quads = ((nabs - Lpad) & 3) == 0 && (hist_stride & 3) == 0;
+        if (quads)
         {
-            const int i = e / W, j = e - i * W;
-            const long long pos = nabs - Lpad + j;
-            // the call's own samples straight from the caller's block (din != nullptr): the kernel then does not wait for the scatter
-            // that files them in the ring, only for the ring's older contents
-            float v;
-            if (din && pos >= n0) v = pos - n0 < B ? din[(long long) (i0 + i) * in_stride + (pos - n0)] : 0.f;
-            else v = hist[(long long) (i0 + i) * hist_stride + (pos & hist_mask)];
-            if (CHECK)
+            const int W4 = W / 4, total = nbi * W4;
+            for (int base = 0; base < total; base += 4 * FIRS_THREADS)
             {
-                if (pos < valid_from[(long long) o * nin_alloc + (i0 + i)]) v = 0.f;
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const int e = base + u * FIRS_THREADS + tid;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < total)
+                    {
+                        const int i = e / W4, j4 = e - i * W4;
+                        const long long pos = nabs - Lpad + 4 * j4;
+                        if (din && pos >= n0)
+                        {
+                            // the call's own samples straight from the caller's block (rows of any alignment)
+                            const float *src = din + (long long) (i0 + i) * in_stride + (pos - n0);
+                            const long long left = (long long) B - (pos - n0);
+                            v[u].x = left > 0 ? src[0] : 0.f;
+                            v[u].y = left > 1 ? src[1] : 0.f;
+                            v[u].z = left > 2 ? src[2] : 0.f;
+                            v[u].w = left > 3 ? src[3] : 0.f;
+                        }
+                        else if (din && pos + 3 >= n0)
+                        {
+                            // (a group straddling the start of the call: n0 is not a multiple of four)
+                            float t[4];
+#pragma unroll
+                            for (int c = 0; c < 4; c++)
+                            {
+                                const long long q = pos + c;
+                                t[c] = q >= n0 ? (q - n0 < B ? din[(long long) (i0 + i) * in_stride + (q - n0)] : 0.f)
+                                               : hist[(long long) (i0 + i) * hist_stride + (q & hist_mask)];
+                            }
+                            v[u] = make_float4(t[0], t[1], t[2], t[3]);
+                        }
+                        else
+                            v[u] = *reinterpret_cast<const float4 *>(hist + (long long) (i0 + i) * hist_stride + (pos & hist_mask));
+                        if (CHECK)
+                        {
+                            const long long vf = valid_from[(long long) o * nin_alloc + (i0 + i)];
+                            if (pos < vf) v[u].x = 0.f;
+                            if (pos + 1 < vf) v[u].y = 0.f;
+                            if (pos + 2 < vf) v[u].z = 0.f;
+                            if (pos + 3 < vf) v[u].w = 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                {
+                    const int e = base + u * FIRS_THREADS + tid;
+                    if (e < total) reinterpret_cast<float4 *>(xs)[e] = v[u];
+                }
             }
-            xs[e] = v;
         }
-        for (int e = tid; e < nbi * L4; e += FIRS_THREADS)
+        else
+            for (int e = tid; e < nbi * W; e += FIRS_THREADS)
+            {
+                const int i = e / W, j = e - i * W;
+                const long long pos = nabs - Lpad + j;
+                // the call's own samples straight from the caller's block (din != nullptr): the kernel then does not wait for the scatter
+                // that files them in the ring, only for the ring's older contents
+                float v;
+                if (din && pos >= n0) v = pos - n0 < B ? din[(long long) (i0 + i) * in_stride + (pos - n0)] : 0.f;
+                else v = hist[(long long) (i0 + i) * hist_stride + (pos & hist_mask)];
+                if (CHECK)
+                {
+                    if (pos < valid_from[(long long) o * nin_alloc + (i0 + i)]) v = 0.f;
+                }
+                xs[e] = v;
+            }
+        for (int base = 0; base < nbi * L4; base += 4 * FIRS_THREADS)
         {
-            const int i = e / L4, k4 = e - i * L4;
-            reinterpret_cast<float4 *>(hs)[e] = *reinterpret_cast<const float4 *>(taps + ((long long) o * nin_alloc + (i0 + i)) * tap_stride + 4 * k4);
+            float4 h4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int e = base + u * FIRS_THREADS + tid;
+                if (e < nbi * L4)
+                {
+                    const int i = e / L4, k4 = e - i * L4;
+                    h4[u] = *reinterpret_cast<const float4 *>(taps + ((long long) o * nin_alloc + (i0 + i)) * tap_stride + 4 * k4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int e = base + u * FIRS_THREADS + tid;
+                if (e < nbi * L4) reinterpret_cast<float4 *>(hs)[e] = h4[u];
+            }
         }
         __syncthreads();
         for (int i = 0; i < nbi; i++)

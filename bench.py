@@ -449,8 +449,7 @@ def flat_scalars(line):
     rt = cfg.get("realtime") or {}
     if "host_pointers" in rt:
         out.update({"rt128_host_p50_ms": rt["host_pointers"].get("p50_ms"), "rt128_host_p99_ms": rt["host_pointers"].get("p99_ms"),
-                    "rt128_over_budget": rt["host_pointers"].get("over_budget"), "rt128_dev_p99_ms": (rt.get("device_pointers") or {}).get("p99_ms"),
-                    "host_pointer_step_msamples_per_s": (rt.get("host_pointer_steps") or {}).get("msamples_per_s")})
+                    "rt128_over_budget": rt["host_pointers"].get("over_budget"), "rt128_dev_p99_ms": (rt.get("device_pointers") or {}).get("p99_ms")})
     if cfg.get("batched"):
         out["batched_block"] = cfg["batched"].get("block")
         out["batched_msamples_per_s"] = cfg["batched"].get("msamples_per_s")
@@ -482,6 +481,10 @@ def flat_scalars(line):
             out[k + "_kernel_share_of_step"] = rf.get("kernel_share_of_step")
         if rf.get("note_ceiling"):
             out[k + "_note"] = f"above SURVEY 8d's {rf.get('survey_8d_ceiling_msamples_per_s')} ceiling: whole-hop calls fold the stages' sum P into lead + tail partitions"
+        ex = d.get("extended_layout") or {}
+        if ex and not ex.get("error"):
+            out[k + "_extended_msamples_per_s"] = ex.get("msamples_per_s")
+            out[k + "_extended_max_rel_err"] = (ex.get("self_check") or {}).get("max_rel_err")
         sb = (d.get("realtime") or {}).get("small_blocks") or {}
         hp = (d.get("realtime") or {}).get("host_pointers") or {}
         if hp:
@@ -582,6 +585,9 @@ def digest_of(d):
     rt = d.get("config", {}).get("realtime")
     if rt:
         out["realtime"] = rt
+    ex = d.get("config", {}).get("extended_layout")
+    if ex:
+        out["extended_layout"] = ex
     return out
 
 
@@ -1095,8 +1101,9 @@ def also_leg(workload, device, steps=40, warmup=5, timeout=420):
     reference CPU leg): the digest of the child's bench line.  The two 64x64 shapes also run the paced real-time legs (128-, 64-
     and 32-sample calls).  Never takes the headline down."""
     rt = ["--realtime-block", "128", "--realtime-extra", "64,32"] if workload in ("ns64", "c4") else ["--realtime-block", "0"]
+    # (the north-star shape also on the extended ladder: what an unchanged caller of the reference API gets for it, hcv_api.hip's rule)
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "", "--leg",
-           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "0"] + rt
+           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "8" if workload == "ns64" else "0"] + rt
     env = dict(os.environ, LOCAL_RANK=str(device), RANK="0", WORLD_SIZE="1")     # the same GPU as the headline
     t0 = time.perf_counter()
     try:

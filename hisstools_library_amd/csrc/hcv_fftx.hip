@@ -668,6 +668,364 @@ namespace
         FX_COUNT(7);
     }
 
+    // -------------------------------------------------------------------------------------------- four-step passes, register tiles
+    //
+    // The tile of a pass — 16384 complex values: LN lines of P = 2^L points — held in the REGISTERS of a 1024-thread workgroup
+    // (sixteen values per thread) from its global loads to its global stores; LDS is only the medium of the one or two exchanges
+    // between the radix-16 / radix-16 / radix-(P / 256) passes.  The workgroup is persistent and software-pipelined: the NEXT
+    // tile's sixteen loads per thread are issued into a second register set before the current tile is transformed, and the
+    // current tile's stores drain behind it — what the LDS-staged passes above do strictly in sequence per tile (load 8 us,
+    // transform 8 us, store 4.5 us for 128 KiB) here overlaps within the one workgroup a CU holds.
+    //
+    // A thread's elements: first pass n = t + TG r (r < 16, TG = P / 16 threads per line), last pass k = t' + TG m.  The two thread
+    // maps — line-fast (line = tid % LN: adjacent lanes on adjacent lines, for the strided side of a pass) and line-slow
+    // (t = tid % TG: adjacent lanes on adjacent elements of a line, for the contiguous side) — are chosen per pass; the exchange
+    // through LDS makes the change of map free.
+    template <int L> struct RegTile
+    {
+        static constexpr int P = 1 << L, TG = P / 16, LN = 1024 / TG;
+        // two sixteen-element "virtual threads" (vtid = tid + NT h) per thread: 512 threads with 256 registers each hold the two
+        // tiles (64 + 64 registers) and leave the butterflies their working set; 1024 threads with 128 spilled 18 - 62 of them
+        static constexpr int VT = 2, NT = 1024 / VT;
+        static constexpr int R3 = P / 256;                              // radix of the third pass (1: none)
+        // line pitch in LDS (complex elements): the padded line plus what makes lanes on adjacent lines with 64 / LN consecutive
+        // elements each land on 64 different 8-byte slots (two wavefront halves per bank pair: the floor of an 8-byte access)
+        static constexpr int PITCH = P + P / 16 + (TG / 16 > 1 ? TG / 16 : 1);
+        static constexpr size_t LDS_BYTES = sizeof(float2) * ((size_t) LN * PITCH + P);      // the tile + the P-th roots
+        static_assert(L >= 8 && L <= 10, "register tiles: 256-, 512- and 1024-point lines");
+    };
+
+    __device__ __forceinline__ int rt_pad(int i) { return i + (i >> 4); }
+
+    // first pass: sixteen-point transforms of u[r] = x[t + TG r], bins to positions 16 t + q of the line
+    template <int L> __device__ __forceinline__ void rt_pass_a(float2 *u, float2 *line, int t)
+    {
+        dft16<true>(u, float2(), float2(), float2());
+        float2 *bp = line + 17 * t;                                      // rt_pad(16 t + q) = 17 t + q
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+            for (int q1 = 0; q1 < 4; q1++) bp[q1 + 4 * q2] = u[4 * q1 + q2];
+    }
+
+    template <int L> __device__ __forceinline__ void rt_read_b(float2 *u, const float2 *line, int t)
+    {
+        typedef RegTile<L> G;
+        const float2 *bp = line + rt_pad(t);
+#pragma unroll
+        for (int r = 0; r < 16; r++) u[r] = bp[r * (G::TG + G::TG / 16)];
+    }
+
+    // second pass (p = 16): twiddles exp(-2 pi i k r / 256), k = t & 15, from the P-th roots in LDS.  LAST: the results stay in
+    // u, u[m] = bin t + TG m (P = 256); else they go to positions j + 16 q, j = (t >> 4) * 256 + k
+    template <int L, bool LAST> __device__ __forceinline__ void rt_pass_b(float2 *u, float2 *line, const float2 *rootP, int t)
+    {
+        typedef RegTile<L> G;
+        const int k = t & 15, step = k * (G::P / 256);
+        const float2 w1 = rootP[step], w2 = rootP[2 * step], w3 = rootP[3 * step], w4 = rootP[4 * step], w8 = rootP[8 * step], w12 = rootP[12 * step];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+            u[4 + c] = cmul(u[4 + c], w4);
+            u[8 + c] = cmul(u[8 + c], w8);
+            u[12 + c] = cmul(u[12 + c], w12);
+        }
+        dft16<false>(u, w1, w2, w3);
+        if constexpr (LAST)
+        {
+            float2 v[16];
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) v[q1 + 4 * q2] = u[4 * q1 + q2];
+#pragma unroll
+            for (int m = 0; m < 16; m++) u[m] = v[m];
+        }
+        else
+        {
+            const int j = ((t - k) << 4) + k;
+            float2 *bp = line + rt_pad(j);                                  // rt_pad(j + 16 q) = rt_pad(j) + 17 q
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++)
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) bp[17 * (q1 + 4 * q2)] = u[4 * q1 + q2];
+        }
+    }
+
+    // third pass (p = 256, radix R3 = P / 256): butterflies i = t + TG b, b < 16 / R3, inputs at i + 256 r, twiddle exp(-2 pi i i r / P);
+    // on return u[m] = bin t + TG m
+    template <int L> __device__ __forceinline__ void rt_pass_c(float2 *u, const float2 *line, const float2 *rootP, int t)
+    {
+        typedef RegTile<L> G;
+        constexpr int R3 = G::R3 > 1 ? G::R3 : 2, NBT = 16 / R3;
+        float2 x[NBT][R3];
+        const float2 *bp = line + rt_pad(t);
+#pragma unroll
+        for (int b = 0; b < NBT; b++)
+#pragma unroll
+            for (int r = 0; r < R3; r++) x[b][r] = bp[b * (G::TG + G::TG / 16) + r * 272];
+#pragma unroll
+        for (int b = 0; b < NBT; b++)
+        {
+            const int i = t + b * G::TG;
+            if constexpr (R3 == 4)
+            {
+                x[b][1] = cmul(x[b][1], rootP[i]);
+                x[b][2] = cmul(x[b][2], rootP[2 * i]);
+                x[b][3] = cmul(x[b][3], rootP[3 * i]);
+                radix4(x[b][0], x[b][1], x[b][2], x[b][3]);
+            }
+            else
+            {
+                const float2 o = cmul(x[b][1], rootP[i]), e = x[b][0];
+                x[b][0] = make_float2(e.x + o.x, e.y + o.y);
+                x[b][1] = make_float2(e.x - o.x, e.y - o.y);
+            }
+#pragma unroll
+            for (int r = 0; r < R3; r++) u[b + NBT * r] = x[b][r];          // bin i + 256 r = t + TG (b + (256 / TG) r)
+        }
+    }
+
+    // The thread maps of a pass, for virtual thread h of thread tid: line-fast (FAST: adjacent lanes on adjacent PAIRS of lines, the
+    // thread's two virtual threads on the two lines of a pair — the strided side of a pass: one 8- or 16-byte access covers both)
+    // or line-slow (adjacent lanes on adjacent elements of a line — the contiguous side)
+    template <int L, bool FAST> struct RtMap
+    {
+        typedef RegTile<L> G;
+        static_assert(G::VT == 2, "line pairs");
+        int line0, t0;
+        __device__ __forceinline__ explicit RtMap(int tid) : line0(FAST ? 2 * (tid % (G::LN / 2)) : tid / G::TG), t0(FAST ? tid / (G::LN / 2) : tid % G::TG) {}
+        __device__ __forceinline__ int line(int h) const { return FAST ? line0 + h : line0 + h * (G::NT / G::TG); }
+        __device__ __forceinline__ int t(int) const { return t0; }
+    };
+
+    // the transform of the tile in u (first-pass map A) to u (last-pass map B)
+    template <int L, class MapA, class MapB> __device__ __forceinline__ void rt_transform(float2 (*u)[16], float2 *lds, const float2 *rootP, const MapA &ma, const MapB &mb)
+    {
+        typedef RegTile<L> G;
+#pragma unroll
+        for (int h = 0; h < G::VT; h++) rt_pass_a<L>(u[h], lds + ma.line(h) * G::PITCH, ma.t(h));
+        __syncthreads();
+        if constexpr (G::R3 == 1)
+        {
+#pragma unroll
+            for (int h = 0; h < G::VT; h++) rt_read_b<L>(u[h], lds + mb.line(h) * G::PITCH, mb.t(h));
+            __syncthreads();                                                // (the next tile's first pass writes the lines again)
+#pragma unroll
+            for (int h = 0; h < G::VT; h++) rt_pass_b<L, true>(u[h], nullptr, rootP, mb.t(h));
+        }
+        else
+        {
+#pragma unroll
+            for (int h = 0; h < G::VT; h++) rt_read_b<L>(u[h], lds + ma.line(h) * G::PITCH, ma.t(h));
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < G::VT; h++) rt_pass_b<L, false>(u[h], lds + ma.line(h) * G::PITCH, rootP, ma.t(h));
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < G::VT; h++) rt_pass_c<L>(u[h], lds + mb.line(h) * G::PITCH, rootP, mb.t(h));
+            __syncthreads();
+        }
+    }
+
+    // the P-th roots exp(-2 pi i m / P), m < P, from the table of the 2P-th roots' first half
+    template <int L> __device__ __forceinline__ void rt_roots(float2 *rootP, const float2 *__restrict__ tw2P)
+    {
+        typedef RegTile<L> G;
+        for (int m = threadIdx.x; m < G::P; m += G::NT)
+        {
+            const float2 w = tw2P[(2 * m) & (G::P - 1)];
+            rootP[m] = m < G::P / 2 ? w : make_float2(-w.x, -w.y);
+        }
+    }
+
+    // tile `it` of persistent workgroup w of `wgs`: the workgroups an XCD runs at one time (w % 8 equal) take NEIGHBOURING tiles,
+    // so that the two halves of the 128-byte lines their strided runs share meet in that XCD's L2
+    __device__ __forceinline__ int rt_tile_of(int w, int wgs, int it)
+    {
+        if ((wgs & 7) == 0) return (it * 8 + (w & 7)) * (wgs >> 3) + (w >> 3);
+        return it * wgs + w;
+    }
+
+    // The loop of both passes is ONE basic block from the next tile's loads to the hand-over copy behind the current tile's
+    // stores (the load and store kinds are template parameters, the last iteration loads a single cache line instead of
+    // branching): the compiler's wait counts are then exact — the copy waits for the loads and leaves the stores in flight, the
+    // first pass waits for nothing.  With a branch in between, its counts at the join are the merge of both ways in, and the
+    // first butterflies waited for the loads just issued.
+
+    // cols: for every n2 a P-point transform over n1 (P = M1), times W_M^(n2 k1), into the scratch at k1 M2 + n2
+    // SPLIT_IN: split arrays whose transforms start on 8-byte boundaries (the two lines of a thread as one load)
+    template <int L1, bool SPLIT_IN>
+    __global__ __launch_bounds__(RegTile<L1>::NT) void fx_cols_tile_kernel(FxK<float> a0, float2 *__restrict__ work, int M2, int M, long long q0, int nb,
+                                                                           const float2 *__restrict__ tw1, const float2 *__restrict__ twN)
+    {
+        typedef RegTile<L1> G;
+        constexpr int TG = G::TG, LN = G::LN, VT = G::VT;
+        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
+        float2 *lds = reinterpret_cast<float2 *>(fx_raw), *rootP = lds + LN * G::PITCH;
+        rt_roots<L1>(rootP, tw1);
+        const RtMap<L1, true> map((int) threadIdx.x);
+        const int line = map.line(0), t = map.t(0);
+        const int per = M2 / LN;                                            // tiles per transform
+        const int total = per * nb, sh = __builtin_ctz(per);                 // (tiles per transform: a power of two; divisions would put branches into the loop)
+        const unsigned lane_io = (unsigned) (t * M2 + line);
+        // the second line's four-step twiddles from the first line's: W^((n2 + 1) k1) = W^(n2 k1) W^k1, k1 = t + TG m
+        const float2 wt = fx_twiddle(twN, 2 * t, M);
+        float2 cur[VT][16], nxt[VT][16];
+        // (`lane`: lane_io, or 0 for the load that only keeps the last iteration's code straight)
+        auto load = [&](float2 (*u)[16], int tile, unsigned lane)
+        {
+            const FxK<float> a = fx_at(a0, q0 + (tile >> sh));
+            const int c0 = (tile & (per - 1)) * LN;
+            if constexpr (SPLIT_IN)
+            {
+                // (a uniform pointer per element index and ONE 32-bit lane offset: sixteen 64-bit lane addresses per virtual
+                // thread, loop invariants all, would be kept in registers beside the two tiles)
+                const float *re = static_cast<const float *>(a.sa) + c0, *im = a.sb + c0;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const long long idx = (long long) (TG * r) * M2;          // (uniform)
+                    const float2 vr = *reinterpret_cast<const float2 *>(re + idx + lane), vi = *reinterpret_cast<const float2 *>(im + idx + lane);
+                    u[0][r] = make_float2(vr.x, vi.x);
+                    u[1][r] = make_float2(vr.y, vi.y);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int h = 0; h < VT; h++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) u[h][r] = fx_load<float, float2>(a, 0, (TG * r) * M2 + c0 + (int) lane + h, M, twN);
+            }
+        };
+        int tile = rt_tile_of(blockIdx.x, gridDim.x, 0);
+        if (tile >= total) return;
+        load(nxt, tile, lane_io);
+#pragma unroll
+        for (int h = 0; h < VT; h++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
+        __builtin_amdgcn_s_waitcnt(0);                                      // (nothing in flight on the way into the loop: see above)
+        __syncthreads();                                                    // (the roots)
+        for (int it = 0; tile < total; it++)
+        {
+            const int next = rt_tile_of(blockIdx.x, gridDim.x, it + 1);
+            const bool more = next < total;
+            load(nxt, more ? next : tile, more ? lane_io : 0u);
+            rt_transform<L1>(cur, lds, rootP, map, map);
+            // the four-step twiddles W^(n2 (t + TG m)) = W^(n2 t) S^m, S = W^(n2 TG): the first and S, S^2, S^4, S^8 each from
+            // sincospi of an exactly reduced argument, applied to the values factor by factor (a table of the sixteen products
+            // would be thirty-two registers beside the two tiles): at most six factors per value, each within 2 ulp
+            const int c0 = (tile & (per - 1)) * LN, n2 = c0 + line;
+            {
+                const float2 w0 = fx_twiddle(twN, 2 * n2 * t, M), w1 = cmul(w0, wt);
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                {
+                    cur[0][m] = cmul(cur[0][m], w0);
+                    cur[1][m] = cmul(cur[1][m], w1);
+                }
+            }
+#pragma unroll
+            for (int bit = 1; bit < 16; bit *= 2)
+            {
+                const float2 s0 = fx_twiddle(twN, 2 * n2 * TG * bit, M), s1 = cmul(s0, fx_twiddle(twN, 2 * TG * bit, M));
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                    if (m & bit)
+                    {
+                        cur[0][m] = cmul(cur[0][m], s0);
+                        cur[1][m] = cmul(cur[1][m], s1);
+                    }
+            }
+            float2 *out = work + (tile >> sh) * (long long) M + c0;
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                *reinterpret_cast<float4 *>(out + (long long) (TG * m) * M2 + lane_io) = make_float4(cur[0][m].x, cur[0][m].y, cur[1][m].x, cur[1][m].y);
+#pragma unroll
+            for (int h = 0; h < VT; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
+            tile = next;
+        }
+    }
+
+    // rows: for every k1 a P-point transform over n2 (P = M2); element k2 of row k1 is bin k1 + M1 k2
+    // STORE: S_SPLIT = split arrays whose transforms start on 8-byte boundaries, S_POST = the scratch of the real post pass, else any
+    template <int L2, int STORE>
+    __global__ __launch_bounds__(RegTile<L2>::NT) void fx_rows_tile_kernel(const float2 *__restrict__ work, FxK<float> a0, float2 *__restrict__ post, int M1, int M,
+                                                                           long long q0, int nb, const float2 *__restrict__ tw2)
+    {
+        typedef RegTile<L2> G;
+        constexpr int TG = G::TG, LN = G::LN, M2 = G::P, VT = G::VT;
+        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
+        float2 *lds = reinterpret_cast<float2 *>(fx_raw), *rootP = lds + LN * G::PITCH;
+        rt_roots<L2>(rootP, tw2);
+        const RtMap<L2, false> ma((int) threadIdx.x);                        // loads: adjacent lanes on adjacent elements of a row
+        const RtMap<L2, true> mb((int) threadIdx.x);                         // stores: adjacent lanes on adjacent rows (adjacent bins)
+        const int per = M1 / LN;
+        const int total = per * nb, sh = __builtin_ctz(per);
+        const unsigned lane_in = (unsigned) (ma.line(0) * M2 + ma.t(0)), lane_out = (unsigned) (mb.line(0) + M1 * mb.t(0));
+        float2 cur[VT][16], nxt[VT][16];
+        auto load = [&](float2 (*u)[16], int tile, unsigned lane)
+        {
+            const float2 *in = work + (tile >> sh) * (long long) M + ((tile & (per - 1)) * LN) * (long long) M2;
+#pragma unroll
+            for (int h = 0; h < VT; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) u[h][r] = (in + (h * (G::NT / TG) * M2 + TG * r))[lane];
+        };
+        int tile = rt_tile_of(blockIdx.x, gridDim.x, 0);
+        if (tile >= total) return;
+        load(nxt, tile, lane_in);
+#pragma unroll
+        for (int h = 0; h < VT; h++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
+        __builtin_amdgcn_s_waitcnt(0);                                      // (nothing in flight on the way into the loop: see above)
+        __syncthreads();
+        for (int it = 0; tile < total; it++)
+        {
+            const int next = rt_tile_of(blockIdx.x, gridDim.x, it + 1);
+            const bool more = next < total;
+            load(nxt, more ? next : tile, more ? lane_in : 0u);
+            rt_transform<L2>(cur, lds, rootP, ma, mb);
+            const FxK<float> a = fx_at(a0, q0 + (tile >> sh));
+            const int k0 = (tile & (per - 1)) * LN;                         // (uniform)
+            if constexpr (STORE == S_SPLIT)
+            {
+                float *re = (a.swap_out ? a.db : a.da) + k0, *im = (a.swap_out ? a.da : a.db) + k0;
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                {
+                    const long long k = (long long) M1 * (TG * m);          // (uniform)
+                    *reinterpret_cast<float2 *>(re + k + lane_out) = make_float2(cur[0][m].x, cur[1][m].x);
+                    *reinterpret_cast<float2 *>(im + k + lane_out) = make_float2(cur[0][m].y, cur[1][m].y);
+                }
+            }
+            else if constexpr (STORE == S_POST)
+            {
+                float2 *out = post + (tile >> sh) * (long long) M + k0;
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                    *reinterpret_cast<float4 *>(out + (long long) M1 * (TG * m) + lane_out) = make_float4(cur[0][m].x, cur[0][m].y, cur[1][m].x, cur[1][m].y);
+            }
+            else
+            {
+#pragma unroll
+                for (int h = 0; h < VT; h++)
+#pragma unroll
+                    for (int m = 0; m < 16; m++) fx_store<float, float2>(a, 0, k0 + mb.line(h) + M1 * (mb.t(h) + TG * m), cur[h][m]);
+            }
+#pragma unroll
+            for (int h = 0; h < VT; h++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
+            tile = next;
+        }
+    }
+
     template <class T>
     __global__ void fx_post_kernel(const typename Cx<T>::type *__restrict__ Z, FxK<T> a, int M, long long q0, const typename Cx<T>::type *__restrict__ twN)
     {
@@ -858,6 +1216,54 @@ namespace
         return hipGetLastError();
     }
 
+    // the register-tile passes (float, 256- to 1024-point lines): persistent workgroups, one per CU
+    inline int fx_tile_wgs(int device, long long tiles)
+    {
+        static std::mutex m;
+        static std::map<int, int> cus;
+        std::lock_guard<std::mutex> g(m);
+        auto it = cus.find(device);
+        if (it == cus.end())
+        {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+            it = cus.emplace(device, n).first;
+        }
+        return (int) std::min<long long>(tiles, it->second);
+    }
+    inline bool fx_tile_on()
+    {
+        static const bool on = !(std::getenv("HCV_FX_TILE") && std::atoi(std::getenv("HCV_FX_TILE")) == 0);
+        return on;
+    }
+
+    template <int L1> hipError_t launch_cols_tile(int device, const FxK<float> &k, float2 *work, int M2, int M, long long q0, int nb, const float2 *tw1,
+                                                  const float2 *twN, hipStream_t st)
+    {
+        typedef RegTile<L1> G;
+        void (*kernel)(FxK<float>, float2 *, int, int, long long, int, const float2 *, const float2 *) =
+            (k.load == L_SPLIT && (reinterpret_cast<uintptr_t>(k.sa) & 7) == 0 && (reinterpret_cast<uintptr_t>(k.sb) & 7) == 0 && k.sstride % 2 == 0)
+                ? fx_cols_tile_kernel<L1, true> : fx_cols_tile_kernel<L1, false>;
+        hipError_t e = allow_big_lds(kernel, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        const long long tiles = (long long) (M2 / G::LN) * nb;
+        hipLaunchKernelGGL(kernel, dim3(fx_tile_wgs(device, tiles)), dim3(G::NT), G::LDS_BYTES, st, k, work, M2, M, q0, nb, tw1, twN);
+        return hipGetLastError();
+    }
+    template <int L2> hipError_t launch_rows_tile(int device, const float2 *work, const FxK<float> &k, float2 *post, int M1, int M, long long q0, int nb,
+                                                  const float2 *tw2, hipStream_t st)
+    {
+        typedef RegTile<L2> G;
+        void (*kernel)(const float2 *, FxK<float>, float2 *, int, int, long long, int, const float2 *) =
+            (k.store == S_SPLIT && (reinterpret_cast<uintptr_t>(k.da) & 7) == 0 && (reinterpret_cast<uintptr_t>(k.db) & 7) == 0 && k.dstride % 2 == 0)
+                ? fx_rows_tile_kernel<L2, S_SPLIT> : k.store == S_POST ? fx_rows_tile_kernel<L2, S_POST> : fx_rows_tile_kernel<L2, S_ZIP>;
+        hipError_t e = allow_big_lds(kernel, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        const long long tiles = (long long) (M1 / G::LN) * nb;
+        hipLaunchKernelGGL(kernel, dim3(fx_tile_wgs(device, tiles)), dim3(G::NT), G::LDS_BYTES, st, work, k, post, M1, M, q0, nb, tw2);
+        return hipGetLastError();
+    }
+
     template <class T> hipError_t run_big(int device, int lm, const FxK<T> &k, hipStream_t st, std::string *err)
     {
         typedef typename Cx<T>::type C;
@@ -869,7 +1275,8 @@ namespace
         if (!twN || !tw1 || !tw2) return hipErrorOutOfMemory;
         // scratch for up to 64 MiB of transforms per pass
         const size_t per = sizeof(C) * (size_t) M;
-        const long long chunk = std::max<long long>(1, std::min<long long>(k.batch, (long long) ((size_t(64) << 20) / per)));
+        static const size_t chunk_mb = std::getenv("HCV_FX_CHUNK_MB") ? (size_t) std::atoll(std::getenv("HCV_FX_CHUNK_MB")) : 64;      // (experiment)
+        const long long chunk = std::max<long long>(1, std::min<long long>(k.batch, (long long) ((chunk_mb << 20) / per)));
         Scratch s;
         hipError_t e = scratch(device, per * (size_t) chunk, s);
         if (e != hipSuccess) return e;
@@ -877,7 +1284,19 @@ namespace
         for (long long q0 = 0; q0 < k.batch; q0 += chunk)
         {
             const int nb = (int) std::min<long long>(chunk, k.batch - q0);
-            switch (l1)
+            bool tiled = false;
+            if constexpr (sizeof(T) == 4)
+                if (fx_tile_on() && l1 >= 8 && l1 <= 10 && M2 % RegTile<8>::LN == 0)
+                {
+                    tiled = true;
+                    switch (l1)
+                    {
+                        case 8: e = launch_cols_tile<8>(device, k, work, M2, M, q0, nb, tw1, twN, st); break;
+                        case 9: e = launch_cols_tile<9>(device, k, work, M2, M, q0, nb, tw1, twN, st); break;
+                        default: e = launch_cols_tile<10>(device, k, work, M2, M, q0, nb, tw1, twN, st); break;
+                    }
+                }
+            if (!tiled) switch (l1)
             {
 #define FX_CASE(L) case L: e = launch_cols<T, L>(k, work, M2, M, q0, nb, tw1, twN, st); break;
                 FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)
@@ -885,7 +1304,19 @@ namespace
                 default: e = hipErrorInvalidValue;
             }
             if (e != hipSuccess) return e;
-            switch (l2)
+            tiled = false;
+            if constexpr (sizeof(T) == 4)
+                if (fx_tile_on() && l2 >= 8 && l2 <= 10 && M1 % RegTile<8>::LN == 0)
+                {
+                    tiled = true;
+                    switch (l2)
+                    {
+                        case 8: e = launch_rows_tile<8>(device, work, k, post, M1, M, q0, nb, tw2, st); break;
+                        case 9: e = launch_rows_tile<9>(device, work, k, post, M1, M, q0, nb, tw2, st); break;
+                        default: e = launch_rows_tile<10>(device, work, k, post, M1, M, q0, nb, tw2, st); break;
+                    }
+                }
+            if (!tiled) switch (l2)
             {
 #define FX_CASE(L) case L: e = launch_rows<T, L>(work, k, post, M1, M, q0, nb, tw2, st); break;
                 FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)

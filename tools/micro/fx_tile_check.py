@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--sizes", default="15,16,17,18,19,20,21,22")
     ap.add_argument("--batch", type=int, default=3)
     ap.add_argument("--tol", type=float, default=2e-6)
+    ap.add_argument("--min-tiles", type=int, default=0, help="batch of at least this many 16384-point tiles (the one-launch batch takes >= 4 per CU)")
     args = ap.parse_args()
     st = torch.cuda.current_stream().cuda_stream
     P = F.Precision.F32
@@ -32,7 +33,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(5)
     for lm in [int(x) for x in args.sizes.split(",")]:
         m = 1 << lm
-        nb = args.batch
+        nb = max(args.batch, -(-args.min_tiles // max(1, m >> 14)))
         a = torch.rand(nb * m, device="cuda", generator=g) * 2 - 1
         b = torch.rand(nb * m, device="cuda", generator=g) * 2 - 1
         z = torch.complex(a.double(), b.double()).view(nb, m)

@@ -69,6 +69,7 @@ WORKLOADS = {
     "ns64": (64, 64, 480000,  48000, (True, 256, 1024, 4096, 16384)),
     "m16":  (16, 16, 96000,   48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 2 s IRs (not a BASELINE config)
     "m16l": (16, 16, 480000,  48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 10 s IRs (not a BASELINE config)
+    "c4s8": (64, 8,  96000,   48000, (True, 256, 1024, 4096, 16384)),   # one rank's share of c4 strong-scaled over 8 GPUs (rows split): DESIGN section 6
 }
 
 

@@ -17,7 +17,6 @@
 #include "hcv_fftx.h"
 #include "hcv_engine.h"
 #include "hcv_fft_device.h"
-#include "hcv_fused_sync.h"
 
 #include <algorithm>
 #include <cmath>
@@ -35,7 +34,6 @@ namespace
     template <> struct Cx<double> { typedef double2 type; };
 
     enum { L_SPLIT = 0, L_ZIP = 1, L_PRE = 2 };
-    constexpr int kFxStreamRing = 512;      // ring slots of the one-launch four-step batch (fx_stream_kernel) at most
     enum { S_SPLIT = 0, S_ZIP = 1, S_POST = 2 };
 
     template <class T> struct FxK
@@ -670,643 +668,6 @@ namespace
         FX_COUNT(7);
     }
 
-    // -------------------------------------------------------------------------------------------- four-step passes, register tiles
-    //
-    // The tile of a pass — 16384 complex values: LN lines of P = 2^L points — held in the REGISTERS of a 1024-thread workgroup
-    // (sixteen values per thread) from its global loads to its global stores; LDS is only the medium of the one or two exchanges
-    // between the radix-16 / radix-16 / radix-(P / 256) passes.  The workgroup is persistent and software-pipelined: the NEXT
-    // tile's sixteen loads per thread are issued into a second register set before the current tile is transformed, and the
-    // current tile's stores drain behind it — what the LDS-staged passes above do strictly in sequence per tile (load 8 us,
-    // transform 8 us, store 4.5 us for 128 KiB) here overlaps within the one workgroup a CU holds.
-    //
-    // A thread's elements: first pass n = t + TG r (r < 16, TG = P / 16 threads per line), last pass k = t' + TG m.  The two thread
-    // maps — line-fast (line = tid % LN: adjacent lanes on adjacent lines, for the strided side of a pass) and line-slow
-    // (t = tid % TG: adjacent lanes on adjacent elements of a line, for the contiguous side) — are chosen per pass; the exchange
-    // through LDS makes the change of map free.
-    template <int L> struct RegTile
-    {
-        static constexpr int P = 1 << L, TG = P / 16, LN = 1024 / TG;
-        // two sixteen-element "virtual threads" (vtid = tid + NT h) per thread: 512 threads with 256 registers each hold the two
-        // tiles (64 + 64 registers) and leave the butterflies their working set; 1024 threads with 128 spilled 18 - 62 of them
-        static constexpr int VT = 2, NT = 1024 / VT;
-        static constexpr int R3 = P / 256;                              // radix of the third pass (1: none)
-        // line pitch in LDS (complex elements): the padded line plus what makes lanes on adjacent lines with 64 / LN consecutive
-        // elements each land on 64 different 8-byte slots (two wavefront halves per bank pair: the floor of an 8-byte access)
-        static constexpr int PITCH = P + P / 16 + (TG / 16 > 1 ? TG / 16 : 1);
-        static constexpr size_t LDS_BYTES = sizeof(float2) * ((size_t) LN * PITCH + P);      // the tile + the P-th roots
-        static_assert(L >= 8 && L <= 10, "register tiles: 256-, 512- and 1024-point lines");
-    };
-
-    __device__ __forceinline__ int rt_pad(int i) { return i + (i >> 4); }
-
-    // first pass: sixteen-point transforms of u[r] = x[t + TG r], bins to positions 16 t + q of the line
-    template <int L> __device__ __forceinline__ void rt_pass_a(float2 *u, float2 *line, int t)
-    {
-        dft16<true>(u, float2(), float2(), float2());
-        float2 *bp = line + 17 * t;                                      // rt_pad(16 t + q) = 17 t + q
-#pragma unroll
-        for (int q2 = 0; q2 < 4; q2++)
-#pragma unroll
-            for (int q1 = 0; q1 < 4; q1++) bp[q1 + 4 * q2] = u[4 * q1 + q2];
-    }
-
-    template <int L> __device__ __forceinline__ void rt_read_b(float2 *u, const float2 *line, int t)
-    {
-        typedef RegTile<L> G;
-        const float2 *bp = line + rt_pad(t);
-#pragma unroll
-        for (int r = 0; r < 16; r++) u[r] = bp[r * (G::TG + G::TG / 16)];
-    }
-
-    // second pass (p = 16): twiddles exp(-2 pi i k r / 256), k = t & 15, from the P-th roots in LDS.  LAST: the results stay in
-    // u, u[m] = bin t + TG m (P = 256); else they go to positions j + 16 q, j = (t >> 4) * 256 + k
-    template <int L, bool LAST> __device__ __forceinline__ void rt_pass_b(float2 *u, float2 *line, const float2 *rootP, int t)
-    {
-        typedef RegTile<L> G;
-        const int k = t & 15, step = k * (G::P / 256);
-        const float2 w1 = rootP[step], w2 = rootP[2 * step], w3 = rootP[3 * step], w4 = rootP[4 * step], w8 = rootP[8 * step], w12 = rootP[12 * step];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-            u[4 + c] = cmul(u[4 + c], w4);
-            u[8 + c] = cmul(u[8 + c], w8);
-            u[12 + c] = cmul(u[12 + c], w12);
-        }
-        dft16<false>(u, w1, w2, w3);
-        if constexpr (LAST)
-        {
-            float2 v[16];
-#pragma unroll
-            for (int q2 = 0; q2 < 4; q2++)
-#pragma unroll
-                for (int q1 = 0; q1 < 4; q1++) v[q1 + 4 * q2] = u[4 * q1 + q2];
-#pragma unroll
-            for (int m = 0; m < 16; m++) u[m] = v[m];
-        }
-        else
-        {
-            const int j = ((t - k) << 4) + k;
-            float2 *bp = line + rt_pad(j);                                  // rt_pad(j + 16 q) = rt_pad(j) + 17 q
-#pragma unroll
-            for (int q2 = 0; q2 < 4; q2++)
-#pragma unroll
-                for (int q1 = 0; q1 < 4; q1++) bp[17 * (q1 + 4 * q2)] = u[4 * q1 + q2];
-        }
-    }
-
-    // third pass (p = 256, radix R3 = P / 256): butterflies i = t + TG b, b < 16 / R3, inputs at i + 256 r, twiddle exp(-2 pi i i r / P);
-    // on return u[m] = bin t + TG m
-    template <int L> __device__ __forceinline__ void rt_pass_c(float2 *u, const float2 *line, const float2 *rootP, int t)
-    {
-        typedef RegTile<L> G;
-        constexpr int R3 = G::R3 > 1 ? G::R3 : 2, NBT = 16 / R3;
-        float2 x[NBT][R3];
-        const float2 *bp = line + rt_pad(t);
-#pragma unroll
-        for (int b = 0; b < NBT; b++)
-#pragma unroll
-            for (int r = 0; r < R3; r++) x[b][r] = bp[b * (G::TG + G::TG / 16) + r * 272];
-#pragma unroll
-        for (int b = 0; b < NBT; b++)
-        {
-            const int i = t + b * G::TG;
-            if constexpr (R3 == 4)
-            {
-                x[b][1] = cmul(x[b][1], rootP[i]);
-                x[b][2] = cmul(x[b][2], rootP[2 * i]);
-                x[b][3] = cmul(x[b][3], rootP[3 * i]);
-                radix4(x[b][0], x[b][1], x[b][2], x[b][3]);
-            }
-            else
-            {
-                const float2 o = cmul(x[b][1], rootP[i]), e = x[b][0];
-                x[b][0] = make_float2(e.x + o.x, e.y + o.y);
-                x[b][1] = make_float2(e.x - o.x, e.y - o.y);
-            }
-#pragma unroll
-            for (int r = 0; r < R3; r++) u[b + NBT * r] = x[b][r];          // bin i + 256 r = t + TG (b + (256 / TG) r)
-        }
-    }
-
-    // The thread maps of a pass, for virtual thread h of thread tid: line-fast (FAST: adjacent lanes on adjacent PAIRS of lines, the
-    // thread's two virtual threads on the two lines of a pair — the strided side of a pass: one 8- or 16-byte access covers both)
-    // or line-slow (adjacent lanes on adjacent PAIRS of elements of a line, the two virtual threads on the two elements — the
-    // contiguous side: one 16-byte access covers both)
-    template <int L, bool FAST> struct RtMap
-    {
-        typedef RegTile<L> G;
-        static_assert(G::VT == 2, "pairs");
-        int line0, t0;
-        __device__ __forceinline__ explicit RtMap(int tid) : line0(FAST ? 2 * (tid % (G::LN / 2)) : tid / (G::TG / 2)), t0(FAST ? tid / (G::LN / 2) : 2 * (tid % (G::TG / 2))) {}
-        __device__ __forceinline__ int line(int h) const { return FAST ? line0 + h : line0; }
-        __device__ __forceinline__ int t(int h) const { return FAST ? t0 : t0 + h; }
-    };
-
-    // the transform of the tile in u (first-pass map A) to u (last-pass map B)
-    template <int L, class MapA, class MapB> __device__ __forceinline__ void rt_transform(float2 (*u)[16], float2 *lds, const float2 *rootP, const MapA &ma, const MapB &mb)
-    {
-        typedef RegTile<L> G;
-#pragma unroll
-        for (int h = 0; h < G::VT; h++) rt_pass_a<L>(u[h], lds + ma.line(h) * G::PITCH, ma.t(h));
-        __syncthreads();
-        if constexpr (G::R3 == 1)
-        {
-#pragma unroll
-            for (int h = 0; h < G::VT; h++) rt_read_b<L>(u[h], lds + mb.line(h) * G::PITCH, mb.t(h));
-            __syncthreads();                                                // (the next tile's first pass writes the lines again)
-#pragma unroll
-            for (int h = 0; h < G::VT; h++) rt_pass_b<L, true>(u[h], nullptr, rootP, mb.t(h));
-        }
-        else
-        {
-#pragma unroll
-            for (int h = 0; h < G::VT; h++) rt_read_b<L>(u[h], lds + ma.line(h) * G::PITCH, ma.t(h));
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < G::VT; h++) rt_pass_b<L, false>(u[h], lds + ma.line(h) * G::PITCH, rootP, ma.t(h));
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < G::VT; h++) rt_pass_c<L>(u[h], lds + mb.line(h) * G::PITCH, rootP, mb.t(h));
-            __syncthreads();
-        }
-    }
-
-    // the P-th roots exp(-2 pi i m / P), m < P, from the table of the 2P-th roots' first half
-    template <int L> __device__ __forceinline__ void rt_roots(float2 *rootP, const float2 *__restrict__ tw2P)
-    {
-        typedef RegTile<L> G;
-        for (int m = threadIdx.x; m < G::P; m += G::NT)
-        {
-            const float2 w = tw2P[(2 * m) & (G::P - 1)];
-            rootP[m] = m < G::P / 2 ? w : make_float2(-w.x, -w.y);
-        }
-    }
-
-    // tile `it` of persistent workgroup w of `wgs`: the workgroups an XCD runs at one time (w % 8 equal) take NEIGHBOURING tiles,
-    // so that the two halves of the 128-byte lines their strided runs share meet in that XCD's L2
-    __device__ __forceinline__ int rt_tile_of(int w, int wgs, int it)
-    {
-        if ((wgs & 7) == 0) return (it * 8 + (w & 7)) * (wgs >> 3) + (w >> 3);
-        return it * wgs + w;
-    }
-
-    // The loop of both passes is ONE basic block from the next tile's loads to the hand-over copy behind the current tile's
-    // stores (the load and store kinds are template parameters, the last iteration loads a single cache line instead of
-    // branching): the compiler's wait counts are then exact — the copy waits for the loads and leaves the stores in flight, the
-    // first pass waits for nothing.  With a branch in between, its counts at the join are the merge of both ways in, and the
-    // first butterflies waited for the loads just issued.
-
-    // cols: for every n2 a P-point transform over n1 (P = M1), times W_M^(n2 k1), into the scratch at k1 M2 + n2
-    // SPLIT_IN: split arrays whose transforms start on 8-byte boundaries (the two lines of a thread as one load)
-    template <int L1, bool SPLIT_IN>
-    __global__ __launch_bounds__(RegTile<L1>::NT) void fx_cols_tile_kernel(FxK<float> a0, float2 *__restrict__ work, int M2, int M, long long q0, int nb,
-                                                                           const float2 *__restrict__ tw1, const float2 *__restrict__ twN)
-    {
-        typedef RegTile<L1> G;
-        constexpr int TG = G::TG, LN = G::LN, VT = G::VT;
-        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
-        float2 *lds = reinterpret_cast<float2 *>(fx_raw), *rootP = lds + LN * G::PITCH;
-        rt_roots<L1>(rootP, tw1);
-        const RtMap<L1, true> map((int) threadIdx.x);
-        const int line = map.line(0), t = map.t(0);
-        const int per = M2 / LN;                                            // tiles per transform
-        const int total = per * nb, sh = __builtin_ctz(per);                 // (tiles per transform: a power of two; divisions would put branches into the loop)
-        const unsigned lane_io = (unsigned) (t * M2 + line);
-        // the second line's four-step twiddles from the first line's: W^((n2 + 1) k1) = W^(n2 k1) W^k1, k1 = t + TG m
-        const float2 wt = fx_twiddle(twN, 2 * t, M);
-        float2 cur[VT][16], nxt[VT][16];
-        // (`lane`: lane_io, or 0 for the load that only keeps the last iteration's code straight)
-        auto load = [&](float2 (*u)[16], int tile, unsigned lane)
-        {
-            const FxK<float> a = fx_at(a0, q0 + (tile >> sh));
-            const int c0 = (tile & (per - 1)) * LN;
-            if constexpr (SPLIT_IN)
-            {
-                // (a uniform pointer per element index and ONE 32-bit lane offset: sixteen 64-bit lane addresses per virtual
-                // thread, loop invariants all, would be kept in registers beside the two tiles)
-                const float *re = static_cast<const float *>(a.sa) + c0, *im = a.sb + c0;
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                {
-                    const long long idx = (long long) (TG * r) * M2;          // (uniform)
-                    const float2 vr = *reinterpret_cast<const float2 *>(re + idx + lane), vi = *reinterpret_cast<const float2 *>(im + idx + lane);
-                    u[0][r] = make_float2(vr.x, vi.x);
-                    u[1][r] = make_float2(vr.y, vi.y);
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int h = 0; h < VT; h++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) u[h][r] = fx_load<float, float2>(a, 0, (TG * r) * M2 + c0 + (int) lane + h, M, twN);
-            }
-        };
-        int tile = rt_tile_of(blockIdx.x, gridDim.x, 0);
-        if (tile >= total) return;
-        load(nxt, tile, lane_io);
-#pragma unroll
-        for (int h = 0; h < VT; h++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-        __builtin_amdgcn_s_waitcnt(0);                                      // (nothing in flight on the way into the loop: see above)
-        __syncthreads();                                                    // (the roots)
-        for (int it = 0; tile < total; it++)
-        {
-            const int next = rt_tile_of(blockIdx.x, gridDim.x, it + 1);
-            const bool more = next < total;
-            load(nxt, more ? next : tile, more ? lane_io : 0u);
-            rt_transform<L1>(cur, lds, rootP, map, map);
-            // the four-step twiddles W^(n2 (t + TG m)) = W^(n2 t) S^m, S = W^(n2 TG): the first and S, S^2, S^4, S^8 each from
-            // sincospi of an exactly reduced argument, applied to the values factor by factor (a table of the sixteen products
-            // would be thirty-two registers beside the two tiles): at most six factors per value, each within 2 ulp
-            const int c0 = (tile & (per - 1)) * LN, n2 = c0 + line;
-            {
-                const float2 w0 = fx_twiddle(twN, 2 * n2 * t, M), w1 = cmul(w0, wt);
-#pragma unroll
-                for (int m = 0; m < 16; m++)
-                {
-                    cur[0][m] = cmul(cur[0][m], w0);
-                    cur[1][m] = cmul(cur[1][m], w1);
-                }
-            }
-#pragma unroll
-            for (int bit = 1; bit < 16; bit *= 2)
-            {
-                const float2 s0 = fx_twiddle(twN, 2 * n2 * TG * bit, M), s1 = cmul(s0, fx_twiddle(twN, 2 * TG * bit, M));
-#pragma unroll
-                for (int m = 0; m < 16; m++)
-                    if (m & bit)
-                    {
-                        cur[0][m] = cmul(cur[0][m], s0);
-                        cur[1][m] = cmul(cur[1][m], s1);
-                    }
-            }
-            float2 *out = work + (tile >> sh) * (long long) M + c0;
-#pragma unroll
-            for (int m = 0; m < 16; m++)
-                *reinterpret_cast<float4 *>(out + (long long) (TG * m) * M2 + lane_io) = make_float4(cur[0][m].x, cur[0][m].y, cur[1][m].x, cur[1][m].y);
-#pragma unroll
-            for (int h = 0; h < VT; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-            tile = next;
-        }
-    }
-
-    // rows: for every k1 a P-point transform over n2 (P = M2); element k2 of row k1 is bin k1 + M1 k2
-    // STORE: S_SPLIT = split arrays whose transforms start on 8-byte boundaries, S_POST = the scratch of the real post pass, else any
-    template <int L2, int STORE>
-    __global__ __launch_bounds__(RegTile<L2>::NT) void fx_rows_tile_kernel(const float2 *__restrict__ work, FxK<float> a0, float2 *__restrict__ post, int M1, int M,
-                                                                           long long q0, int nb, const float2 *__restrict__ tw2)
-    {
-        typedef RegTile<L2> G;
-        constexpr int TG = G::TG, LN = G::LN, M2 = G::P, VT = G::VT;
-        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
-        float2 *lds = reinterpret_cast<float2 *>(fx_raw), *rootP = lds + LN * G::PITCH;
-        rt_roots<L2>(rootP, tw2);
-        const RtMap<L2, false> ma((int) threadIdx.x);                        // loads: adjacent lanes on adjacent elements of a row
-        const RtMap<L2, true> mb((int) threadIdx.x);                         // stores: adjacent lanes on adjacent rows (adjacent bins)
-        const int per = M1 / LN;
-        const int total = per * nb, sh = __builtin_ctz(per);
-        const unsigned lane_in = (unsigned) (ma.line(0) * M2 + ma.t(0)), lane_out = (unsigned) (mb.line(0) + M1 * mb.t(0));
-        float2 cur[VT][16], nxt[VT][16];
-        auto load = [&](float2 (*u)[16], int tile, unsigned lane)
-        {
-            const float2 *in = work + (tile >> sh) * (long long) M + ((tile & (per - 1)) * LN) * (long long) M2;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const float4 v = *reinterpret_cast<const float4 *>(in + TG * r + lane);
-                u[0][r] = make_float2(v.x, v.y);
-                u[1][r] = make_float2(v.z, v.w);
-            }
-        };
-        int tile = rt_tile_of(blockIdx.x, gridDim.x, 0);
-        if (tile >= total) return;
-        load(nxt, tile, lane_in);
-#pragma unroll
-        for (int h = 0; h < VT; h++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-        __builtin_amdgcn_s_waitcnt(0);                                      // (nothing in flight on the way into the loop: see above)
-        __syncthreads();
-        for (int it = 0; tile < total; it++)
-        {
-            const int next = rt_tile_of(blockIdx.x, gridDim.x, it + 1);
-            const bool more = next < total;
-            load(nxt, more ? next : tile, more ? lane_in : 0u);
-            rt_transform<L2>(cur, lds, rootP, ma, mb);
-            const FxK<float> a = fx_at(a0, q0 + (tile >> sh));
-            const int k0 = (tile & (per - 1)) * LN;                         // (uniform)
-            if constexpr (STORE == S_SPLIT)
-            {
-                float *re = (a.swap_out ? a.db : a.da) + k0, *im = (a.swap_out ? a.da : a.db) + k0;
-#pragma unroll
-                for (int m = 0; m < 16; m++)
-                {
-                    const long long k = (long long) M1 * (TG * m);          // (uniform)
-                    *reinterpret_cast<float2 *>(re + k + lane_out) = make_float2(cur[0][m].x, cur[1][m].x);
-                    *reinterpret_cast<float2 *>(im + k + lane_out) = make_float2(cur[0][m].y, cur[1][m].y);
-                }
-            }
-            else if constexpr (STORE == S_POST)
-            {
-                float2 *out = post + (tile >> sh) * (long long) M + k0;
-#pragma unroll
-                for (int m = 0; m < 16; m++)
-                    *reinterpret_cast<float4 *>(out + (long long) M1 * (TG * m) + lane_out) = make_float4(cur[0][m].x, cur[0][m].y, cur[1][m].x, cur[1][m].y);
-            }
-            else
-            {
-#pragma unroll
-                for (int h = 0; h < VT; h++)
-#pragma unroll
-                    for (int m = 0; m < 16; m++) fx_store<float, float2>(a, 0, k0 + mb.line(h) + M1 * (mb.t(h) + TG * m), cur[h][m]);
-            }
-#pragma unroll
-            for (int h = 0; h < VT; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-            tile = next;
-        }
-    }
-
-    // -------------------------------------------------------------------------------------------- four-step, both passes in one launch
-    //
-    // A batch of four-step transforms as ONE launch of persistent workgroups (one per CU), each taking tickets from a device counter.
-    // Ticket t = the column tile t of the batch AND the row tile t - D: the row pass of a transform follows its column pass at a
-    // distance of D tiles, so the scratch between them is a RING of a few transforms that never leaves the Infinity Cache, neither
-    // pass has launch ramps of its own (two launches per 64 MiB chunk spent a third of their time filling and draining 256 CUs with
-    // two tiles each), and every workgroup alternates column tile, row tile, ... in one straight loop, the next tile's loads in
-    // flight while the current one is transformed (register tiles above).
-    //
-    // Hand-overs inside the launch: the scratch is written and read with agent-scope 8-byte accesses; per ring slot one counter of
-    // finished column tiles and one of finished row tiles.  A row tile waits until its transform's column tiles are all counted;
-    // a column tile waits, before it stores, until the row tiles of the transform that used its slot RING transforms earlier are.
-    // Both are counted only when the workgroup's stores have completed (a tile later: the wait is free by then), both are polled a
-    // tile ahead by one lane, and D and RING are chosen so that in the ordinary case nothing ever waits.
-    // Forward progress by construction: tickets are handed out in order to workgroups that are RUNNING, and a tile depends only on
-    // tiles with smaller tickets — whoever holds those is on the chip and waits, in turn, only for still smaller ones.
-    struct FxStreamCtl
-    {
-        unsigned ticket, exited, pad[2];
-        unsigned cols_done[kFxStreamRing], rows_done[kFxStreamRing];
-    };
-
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    constexpr int kWaitVm32 = 0x8F70, kWaitVm16 = 0x4F70;      // s_waitcnt vmcnt(32) / vmcnt(16) alone (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-    __device__ __forceinline__ unsigned fx_poll(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-    template <int L1, int L2>
-    __global__ __launch_bounds__(RegTile<L1>::NT) void fx_stream_kernel(FxK<float> a0, float2 *__restrict__ ring, FxStreamCtl *__restrict__ ctl, int M, int nb, int D, int RING,
-                                                                        const float2 *__restrict__ tw1, const float2 *__restrict__ tw2, const float2 *__restrict__ twN)
-    {
-        typedef RegTile<L1> G1;
-        typedef RegTile<L2> G2;
-        constexpr int VT = G1::VT, NT = G1::NT, M1 = G1::P, M2 = G2::P;
-        constexpr int TILE_ELEMS = (G1::LN * G1::PITCH > G2::LN * G2::PITCH) ? G1::LN * G1::PITCH : G2::LN * G2::PITCH;
-        extern __shared__ __attribute__((aligned(16))) unsigned char fx_raw[];
-        float2 *lds = reinterpret_cast<float2 *>(fx_raw), *root1 = lds + TILE_ELEMS, *root2 = (L1 == L2) ? root1 : root1 + M1;
-        int *slots = reinterpret_cast<int *>(root2 + M2);                    // [0] ticket after next, [1] early polls, [2] spin result
-        rt_roots<L1>(root1, tw1);
-        if (L1 != L2) rt_roots<L2>(root2, tw2);
-        const int tid = (int) threadIdx.x;
-        const int per = M >> 14, sh = __builtin_ctz(per);                    // tiles per transform and pass (16384 elements each)
-        const int T = nb * per, END = T + D;
-        const __amdgpu_buffer_rsrc_t ring_rsrc = __builtin_amdgcn_make_buffer_rsrc(ring, 0, (int) ((long long) (RING + 1) * M * sizeof(float2)), 0x00020000);
-        float2 *dump = ring + (long long) RING * M;                          // where the halves of tickets without a tile store
-        float2 cur[VT][16], nxt[VT][16];
-
-        auto load_cols = [&](float2 (*u)[16], int ct, bool valid, unsigned lane_c)
-        {
-            const int q = valid ? ct >> sh : 0, c0 = valid ? (ct & (per - 1)) * G1::LN : 0;
-            const unsigned lane = valid ? lane_c : 0u;
-            const FxK<float> a = fx_at(a0, q);
-            const float *re = static_cast<const float *>(a.sa) + c0, *im = a.sb + c0;
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const long long idx = (long long) (G1::TG * r) * M2;         // (uniform)
-                // (streamed once: not kept in the caches the ring lives in)
-                const v2f vr = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(re + idx + lane)), vi = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(im + idx + lane));
-                u[0][r] = make_float2(vr.x, vi.x);
-                u[1][r] = make_float2(vr.y, vi.y);
-            }
-        };
-        auto load_rows = [&](float2 (*u)[16], int rt, bool valid, unsigned lane_ri)
-        {
-            const int q = valid ? rt >> sh : 0, r0 = valid ? (rt & (per - 1)) * G2::LN : 0;
-            const unsigned lane = valid ? lane_ri : 0u;
-            const unsigned base = (unsigned) (((long long) (q % RING) * M + (long long) r0 * M2) * sizeof(float2));
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-            {
-                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(ring_rsrc, lane * (unsigned) sizeof(float2), base + (unsigned) (G2::TG * r * sizeof(float2)), /* sc1 */ 16);
-                u[0][r] = make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-                u[1][r] = make_float2(__uint_as_float(v.z), __uint_as_float(v.w));
-            }
-        };
-        // one lane's view of the two conditions of ticket t (bit 0: its row tile may be loaded, bit 1: its column tile may be stored),
-        // in two halves: the counters are read now, looked at later (a tile later for the early poll: nothing waits for the reads)
-        struct Polled { unsigned cols, rows; };
-        auto poll_issue = [&](int t) -> Polled
-        {
-            Polled p = { 0u, 0u };
-            const int rt = t - D;
-            if (rt >= 0 && rt < T) p.cols = fx_poll(&ctl->cols_done[(rt >> sh) % RING]);
-            if (t < T) p.rows = fx_poll(&ctl->rows_done[(t >> sh) % RING]);
-            return p;
-        };
-        auto poll_eval = [&](int t, Polled p) -> int
-        {
-            int ok = 0;
-            const int rt = t - D;
-            if (rt < 0 || rt >= T || (int) (p.cols - (unsigned) (((rt >> sh) / RING + 1) * per)) >= 0) ok |= 1;
-            if (t >= T || (int) (p.rows - (unsigned) (((t >> sh) / RING) * per)) >= 0) ok |= 2;
-            return ok;
-        };
-        auto poll = [&](int t) -> int { return poll_eval(t, poll_issue(t)); };
-        // Before a workgroup starts to wait it counts in the row tile it has finished and not yet counted (normally counted a tile
-        // later, when its stores have completed for free): a tile's count must never depend on its workgroup getting past a wait of
-        // a LATER ticket — that later ticket may itself be waiting for the workgroup that needs this count.  With that, a waiting
-        // workgroup has published everything below its ticket, and the lowest waiting ticket depends only on running workgroups.
-        // (A wait that outlasts a million polls — seconds — is a fault of the scheme, never of the load: trap rather than hang.)
-        auto wait_for = [&](int t, int have, int bit, int &unpublished_rows_slot)
-        {
-            if (have & bit) return;
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (tid == 0 && unpublished_rows_slot >= 0) __hip_atomic_fetch_add(&ctl->rows_done[unpublished_rows_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unpublished_rows_slot = -1;
-            for (int spins = 0; !(have & bit); spins++)
-            {
-                if (spins >= (1 << 20)) __builtin_trap();
-                if (tid == 0)
-                {
-                    if (spins) __builtin_amdgcn_s_sleep(8);
-                    slots[2] = poll(t);
-                }
-                __syncthreads();
-                have = __builtin_amdgcn_readfirstlane(slots[2]);
-                __syncthreads();
-            }
-        };
-
-        if (tid == 0)
-        {
-            slots[0] = (int) __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            slots[1] = (int) __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();                                                    // (and the roots)
-        // (what the workgroup reads back from LDS is uniform, and the compiler has to be told: every tile address hangs off these)
-        int tk = __builtin_amdgcn_readfirstlane(slots[0]), tk1 = __builtin_amdgcn_readfirstlane(slots[1]), flags = 0, prev_rows_slot = -1;
-        __syncthreads();
-        if (tk < END)
-        {
-            const RtMap<L1, true> mc0(tid);
-            load_cols(nxt, tk, tk < T, (unsigned) (mc0.t(0) * M2 + mc0.line(0)));
-#pragma unroll
-            for (int h = 0; h < VT; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-            __builtin_amdgcn_s_waitcnt(0);                                  // (nothing in flight on the way into the loop: see the passes above)
-        }
-        while (tk < END)
-        {
-            // (the thread maps and everything derived from them — sixteen LDS and lane addresses — are worked out again every tile
-            // from a copy of the thread index the compiler cannot see through: hoisted out of the loop they were the registers
-            // that spilled, and a spilled register's reload waits for every load in flight)
-            int tid_now = tid;
-            asm volatile("" : "+v"(tid_now));
-            const RtMap<L1, true> mc(tid_now);                               // column tiles: adjacent lanes on adjacent columns, in and out
-            const RtMap<L2, false> ma(tid_now);                              // row tiles in: adjacent lanes on adjacent elements of a row
-            const RtMap<L2, true> mb(tid_now);                               // row tiles out: adjacent lanes on adjacent rows (bins)
-            const unsigned lane_c = (unsigned) (mc.t(0) * M2 + mc.line(0));
-            const unsigned lane_ri = (unsigned) (ma.line(0) * M2 + ma.t(0)), lane_ro = (unsigned) (mb.line(0) + M1 * mb.t(0));
-            // ---- the column tile of this ticket; its row tile's loads go first
-            // (the ticket after next, used a tile from now.  As an asm statement: the compiler counts a returning atomic of its own as
-            // in flight at the loop header — whatever waits the loop holds — and drains every store before the register is written
-            // again; the explicit vmcnt(32) in front of the last barrier below is this statement's wait)
-            unsigned tk2 = 0;
-            if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk2) : "v"(0u), "v"(1u), "s"(&ctl->ticket) : "memory");
-            const int rt = tk - D;
-            const bool cols_valid = tk < T, rows_valid = rt >= 0 && rt < T;
-            wait_for(tk, flags, 1, prev_rows_slot);
-            load_rows(nxt, rt, rows_valid, lane_ri);
-            rt_transform<L1>(cur, lds, root1, mc, mc);
-            {
-                // the four-step twiddles W^(n2 (t + TG m)), as in the column pass above
-                const int c0 = (tk & (per - 1)) * G1::LN, n2 = c0 + mc.line(0);
-                {
-                    // (the second line's factors from sincospi as well: kept as products of the first line's, their constants were ten
-                    // registers held across the loop — beside the two tiles that is what spilled)
-                    const float2 w0 = fx_twiddle(twN, 2 * n2 * mc.t(0), M), w1 = fx_twiddle(twN, 2 * (n2 + 1) * mc.t(0), M);
-#pragma unroll
-                    for (int m = 0; m < 16; m++)
-                    {
-                        cur[0][m] = cmul(cur[0][m], w0);
-                        cur[1][m] = cmul(cur[1][m], w1);
-                    }
-                }
-#pragma unroll
-                for (int bit = 1; bit < 16; bit *= 2)
-                {
-                    const float2 s0 = fx_twiddle(twN, 2 * n2 * G1::TG * bit, M), s1 = fx_twiddle(twN, 2 * (n2 + 1) * G1::TG * bit, M);
-#pragma unroll
-                    for (int m = 0; m < 16; m++)
-                        if (m & bit)
-                        {
-                            cur[0][m] = cmul(cur[0][m], s0);
-                            cur[1][m] = cmul(cur[1][m], s1);
-                        }
-                }
-                wait_for(tk, flags, 2, prev_rows_slot);
-                // (16-byte write-through stores through a buffer descriptor — an agent-scope atomic store is 8 bytes at most, and
-                // 8-byte write-through stores are one fabric write each: 2.7 times the time per byte)
-                const int q = tk >> sh;
-                const unsigned base = cols_valid ? (unsigned) (((long long) (q % RING) * M + c0) * sizeof(float2)) : (unsigned) ((long long) RING * M * sizeof(float2));
-#pragma unroll
-                for (int m = 0; m < 16; m++)
-                {
-                    const v4u v = { __float_as_uint(cur[0][m].x), __float_as_uint(cur[0][m].y), __float_as_uint(cur[1][m].x), __float_as_uint(cur[1][m].y) };
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ring_rsrc, lane_c * (unsigned) sizeof(float2), base + (unsigned) (G1::TG * m * M2 * sizeof(float2)), /* sc1 */ 16);
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < VT; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-            // ---- the row tile; the next ticket's column tile's loads go first.  The previous row tile's stores have completed once
-            // the loads issued behind them have (the wait is spelled out: the compiler may fold the copy above into the first
-            // butterflies and wait only there; the 16 column stores issued since may stay in flight): count it
-            __builtin_amdgcn_s_waitcnt(kWaitVm16);
-            __syncthreads();
-            Polled early = { 0u, 0u };
-            if (tid == 0)
-            {
-                if (prev_rows_slot >= 0) __hip_atomic_fetch_add(&ctl->rows_done[prev_rows_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tk1 < END) early = poll_issue(tk1);                        // (looked at a tile from now)
-            }
-            load_cols(nxt, tk1, tk1 < T, lane_c);
-            rt_transform<L2>(cur, lds, root2, ma, mb);
-            {
-                const int q = rows_valid ? rt >> sh : 0, k0 = rows_valid ? (rt & (per - 1)) * G2::LN : 0;
-                const FxK<float> a = fx_at(a0, q);
-                float *re = rows_valid ? (a.swap_out ? a.db : a.da) + k0 : reinterpret_cast<float *>(dump);
-                float *im = rows_valid ? (a.swap_out ? a.da : a.db) + k0 : reinterpret_cast<float *>(dump) + M;
-#pragma unroll
-                for (int m = 0; m < 16; m++)
-                {
-                    const long long k = (long long) M1 * (G2::TG * m);      // (uniform)
-                    __builtin_nontemporal_store(v2f{ cur[0][m].x, cur[1][m].x }, reinterpret_cast<v2f *>(re + k + lane_ro));
-                    __builtin_nontemporal_store(v2f{ cur[0][m].y, cur[1][m].y }, reinterpret_cast<v2f *>(im + k + lane_ro));
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < VT; h++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) cur[h][r] = nxt[h][r];
-            // ---- the column tile's stores have completed (issued before the loads this copy waits for; the 32 row stores since
-            // may stay in flight): count it, and hand the ticket after next and the early polls to the workgroup
-            __builtin_amdgcn_s_waitcnt(kWaitVm32);
-            __syncthreads();
-            // (the results of the lane's ticket and polls are taken up by EVERY lane, outside the branch: a result waited for only
-            // inside a divergent branch still counts as in flight at the loop header, and the next tile's first write to its
-            // register then waits for every store in flight)
-            const int tk2_u = __builtin_amdgcn_readfirstlane((int) tk2);
-            const Polled early_u = { (unsigned) __builtin_amdgcn_readfirstlane((int) early.cols), (unsigned) __builtin_amdgcn_readfirstlane((int) early.rows) };
-            if (tid == 0)
-            {
-                if (cols_valid) __hip_atomic_fetch_add(&ctl->cols_done[(tk >> sh) % RING], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                slots[0] = tk2_u;
-                slots[1] = tk1 < END ? poll_eval(tk1, early_u) : 3;
-            }
-            __syncthreads();
-            prev_rows_slot = rows_valid ? (rt >> sh) % RING : -1;
-            tk = tk1;
-            tk1 = __builtin_amdgcn_readfirstlane(slots[0]);
-            flags = __builtin_amdgcn_readfirstlane(slots[1]);
-        }
-        // the last row tile's stores, then out; the last workgroup out leaves the counters as it found them
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (tid == 0)
-        {
-            if (prev_rows_slot >= 0) __hip_atomic_fetch_add(&ctl->rows_done[prev_rows_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(&ctl->exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
-            {
-                for (int i = 0; i < kFxStreamRing; i++)
-                {
-                    __hip_atomic_store(&ctl->cols_done[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&ctl->rows_done[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctl->exited, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-
     template <class T>
     __global__ void fx_post_kernel(const typename Cx<T>::type *__restrict__ Z, FxK<T> a, int M, long long q0, const typename Cx<T>::type *__restrict__ twN)
     {
@@ -1355,7 +716,7 @@ namespace
     struct Scratch
     {
         void *a = nullptr, *b = nullptr;
-        size_t bytes = 0;
+        size_t bytes = 0, bytes_b = 0;
     };
     std::map<int, Scratch> gScratch;
 
@@ -1390,26 +751,25 @@ namespace
     template <> const float2 *fx_twiddles<float>(int device, int log2n, std::string *err) { return twiddles(device, log2n, err); }
     template <> const double2 *fx_twiddles<double>(int device, int log2n, std::string *err) { return twiddles_f64(device, log2n, err); }
 
-    // grow-only per-device scratch for the four-step path (two buffers of `bytes`)
-    hipError_t scratch(int device, size_t bytes, Scratch &out)
+    // grow-only per-device scratch for the four-step path: `bytes` between the passes and, for the real forward transform
+    // (`with_post`), as much again in front of its post pass
+    hipError_t scratch(int device, size_t bytes, bool with_post, Scratch &out)
     {
         std::lock_guard<std::mutex> g(gFxMutex);
         Scratch &s = gScratch[device];
-        if (s.bytes < bytes)
+        auto grow = [&](void *&p, size_t &have) -> hipError_t
         {
-            if (s.a) (void) hipFree(s.a);                           // hipFree waits for work that still uses the old buffers
-            if (s.b) (void) hipFree(s.b);
-            s = Scratch();
-            hipError_t e = hipMalloc(&s.a, bytes);
-            if (e == hipSuccess) e = hipMalloc(&s.b, bytes);
-            if (e != hipSuccess)
-            {
-                if (s.a) (void) hipFree(s.a);
-                s = Scratch();
-                return e;
-            }
-            s.bytes = bytes;
-        }
+            if (have >= bytes) return hipSuccess;
+            if (p) (void) hipFree(p);                                   // hipFree waits for work that still uses the old buffer
+            p = nullptr;
+            have = 0;
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e == hipSuccess) have = bytes;
+            return e;
+        };
+        hipError_t e = grow(s.a, s.bytes);
+        if (e == hipSuccess && with_post) e = grow(s.b, s.bytes_b);
+        if (e != hipSuccess) return e;
         out = s;
         return hipSuccess;
     }
@@ -1497,121 +857,6 @@ namespace
         return hipGetLastError();
     }
 
-    // the register-tile passes (float, 256- to 1024-point lines): persistent workgroups, one per CU
-    inline int fx_tile_wgs(int device, long long tiles)
-    {
-        static std::mutex m;
-        static std::map<int, int> cus;
-        std::lock_guard<std::mutex> g(m);
-        auto it = cus.find(device);
-        if (it == cus.end())
-        {
-            int n = 0;
-            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
-            it = cus.emplace(device, n).first;
-        }
-        return (int) std::min<long long>(tiles, it->second);
-    }
-    inline bool fx_tile_on()
-    {
-        static const bool on = !(std::getenv("HCV_FX_TILE") && std::atoi(std::getenv("HCV_FX_TILE")) == 0);
-        return on;
-    }
-
-    template <int L1> hipError_t launch_cols_tile(int device, const FxK<float> &k, float2 *work, int M2, int M, long long q0, int nb, const float2 *tw1,
-                                                  const float2 *twN, hipStream_t st)
-    {
-        typedef RegTile<L1> G;
-        void (*kernel)(FxK<float>, float2 *, int, int, long long, int, const float2 *, const float2 *) =
-            (k.load == L_SPLIT && (reinterpret_cast<uintptr_t>(k.sa) & 7) == 0 && (reinterpret_cast<uintptr_t>(k.sb) & 7) == 0 && k.sstride % 2 == 0)
-                ? fx_cols_tile_kernel<L1, true> : fx_cols_tile_kernel<L1, false>;
-        hipError_t e = allow_big_lds(kernel, G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        const long long tiles = (long long) (M2 / G::LN) * nb;
-        hipLaunchKernelGGL(kernel, dim3(fx_tile_wgs(device, tiles)), dim3(G::NT), G::LDS_BYTES, st, k, work, M2, M, q0, nb, tw1, twN);
-        return hipGetLastError();
-    }
-    template <int L2> hipError_t launch_rows_tile(int device, const float2 *work, const FxK<float> &k, float2 *post, int M1, int M, long long q0, int nb,
-                                                  const float2 *tw2, hipStream_t st)
-    {
-        typedef RegTile<L2> G;
-        void (*kernel)(const float2 *, FxK<float>, float2 *, int, int, long long, int, const float2 *) =
-            (k.store == S_SPLIT && (reinterpret_cast<uintptr_t>(k.da) & 7) == 0 && (reinterpret_cast<uintptr_t>(k.db) & 7) == 0 && k.dstride % 2 == 0)
-                ? fx_rows_tile_kernel<L2, S_SPLIT> : k.store == S_POST ? fx_rows_tile_kernel<L2, S_POST> : fx_rows_tile_kernel<L2, S_ZIP>;
-        hipError_t e = allow_big_lds(kernel, G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        const long long tiles = (long long) (M1 / G::LN) * nb;
-        hipLaunchKernelGGL(kernel, dim3(fx_tile_wgs(device, tiles)), dim3(G::NT), G::LDS_BYTES, st, work, k, post, M1, M, q0, nb, tw2);
-        return hipGetLastError();
-    }
-
-    // the one-launch batch (fx_stream_kernel): complex float transforms of 2^16 ... 2^20 points between split arrays on 8-byte
-    // boundaries, batches of at least four tiles per CU; the ring (and the dump slot behind it) and the counters live with the
-    // device's scratch
-    struct StreamBuf
-    {
-        void *ring = nullptr, *ctl = nullptr;
-        size_t bytes = 0;
-    };
-    std::map<int, StreamBuf> gStream;
-
-    inline bool fx_stream_on()
-    {
-        static const bool on = !(std::getenv("HCV_FX_STREAM") && std::atoi(std::getenv("HCV_FX_STREAM")) == 0);
-        return on;
-    }
-
-    template <int L1, int L2> hipError_t launch_stream(int device, const FxK<float> &k, int lm, const float2 *tw1, const float2 *tw2, const float2 *twN, hipStream_t st)
-    {
-        typedef RegTile<L1> G1;
-        typedef RegTile<L2> G2;
-        const int M = 1 << lm, per = M >> 14, wgs = fx_tile_wgs(device, 1 << 30);
-        // the row tile of a ticket lags its column tile by a transform plus what the chip holds in flight (LAG quarters of a
-        // tile per workgroup); a slot is written again when the rows that read it are twice that far behind
-        static const int lag4 = std::getenv("HCV_FX_LAG") ? std::atoi(std::getenv("HCV_FX_LAG")) : 4;       // (experiment)
-        const int D = per + lag4 * wgs / 4, RING = 2 + (D + 2 * wgs + per - 1) / per;
-        if (RING > kFxStreamRing) return hipErrorInvalidValue;
-        const size_t bytes = sizeof(float2) * (size_t) M * (size_t) (RING + 1);
-        StreamBuf b;
-        {
-            std::lock_guard<std::mutex> g(gFxMutex);
-            StreamBuf &sb = gStream[device];
-            if (!sb.ctl)
-            {
-                hipError_t e = hipMalloc(&sb.ctl, sizeof(FxStreamCtl));
-                if (e == hipSuccess) e = hipMemset(sb.ctl, 0, sizeof(FxStreamCtl));
-                if (e != hipSuccess) { sb.ctl = nullptr; return e; }
-            }
-            if (sb.bytes < bytes)
-            {
-                if (sb.ring) (void) hipFree(sb.ring);                       // (hipFree waits for work that still uses the old ring)
-                sb.ring = nullptr;
-                sb.bytes = 0;
-                hipError_t e = hipMalloc(&sb.ring, bytes);
-                if (e != hipSuccess) return e;
-                sb.bytes = bytes;
-            }
-            b = sb;
-        }
-        constexpr size_t tile = (size_t) std::max(G1::LN * G1::PITCH, G2::LN * G2::PITCH);
-        constexpr size_t lds = sizeof(float2) * (tile + G1::P + (L1 == L2 ? 0 : G2::P)) + 16;
-        hipError_t e = allow_big_lds(fx_stream_kernel<L1, L2>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fx_stream_kernel<L1, L2>), dim3(wgs), dim3(G1::NT), lds, st, k, static_cast<float2 *>(b.ring), static_cast<FxStreamCtl *>(b.ctl), M, (int) k.batch, D, RING,
-                           tw1, tw2, twN);
-        return hipGetLastError();
-    }
-
-    template <class T> bool fx_stream_fits(int device, int lm, const FxK<T> &k)
-    {
-        if constexpr (sizeof(T) != 4) return false;
-        if (!fx_stream_on() || lm < 16 || lm > 20 || k.load != L_SPLIT || k.store != S_SPLIT) return false;
-        const uintptr_t bits = reinterpret_cast<uintptr_t>(k.sa) | reinterpret_cast<uintptr_t>(k.sb) | reinterpret_cast<uintptr_t>(k.da) | reinterpret_cast<uintptr_t>(k.db);
-        if ((bits & 7) || (k.sstride & 1) || (k.dstride & 1)) return false;
-        const long long tiles = k.batch * (long long) ((1 << lm) >> 14);
-        return tiles >= 4LL * fx_tile_wgs(device, 1 << 30) && tiles < (1LL << 30);
-    }
-
     template <class T> hipError_t run_big(int device, int lm, const FxK<T> &k, hipStream_t st, std::string *err)
     {
         typedef typename Cx<T>::type C;
@@ -1621,40 +866,20 @@ namespace
         const C *tw1 = fx_twiddles<T>(device, l1 + 1, err);
         const C *tw2 = fx_twiddles<T>(device, l2 + 1, err);
         if (!twN || !tw1 || !tw2) return hipErrorOutOfMemory;
-        if constexpr (sizeof(T) == 4)
-            if (fx_stream_fits<T>(device, lm, k))
-                switch (lm)
-                {
-                    case 16: return launch_stream<8, 8>(device, k, lm, tw1, tw2, twN, st);
-                    case 17: return launch_stream<8, 9>(device, k, lm, tw1, tw2, twN, st);
-                    case 18: return launch_stream<9, 9>(device, k, lm, tw1, tw2, twN, st);
-                    case 19: return launch_stream<9, 10>(device, k, lm, tw1, tw2, twN, st);
-                    default: return launch_stream<10, 10>(device, k, lm, tw1, tw2, twN, st);
-                }
-        // scratch for up to 64 MiB of transforms per pass
+        // Scratch for up to 1 GiB of transforms per pass.  (Round 1 to 3 kept a chunk at 64 MiB so that the scratch between the passes
+        // stays in the Infinity Cache.  Measured in round 4: the passes are bound by what a CU's memory pipeline moves — four times
+        // the batch through ~10 bytes per cycle and CU, wherever the bytes come from — and a launch of 512 tiles on 256 CUs spends
+        // a third of its time filling and draining; 1 GiB chunks: complex 2^16 2.10 -> 2.72, 2^20 1.57 -> 2.06 TB/s)
         const size_t per = sizeof(C) * (size_t) M;
-        static const size_t chunk_mb = std::getenv("HCV_FX_CHUNK_MB") ? (size_t) std::atoll(std::getenv("HCV_FX_CHUNK_MB")) : 64;      // (experiment)
-        const long long chunk = std::max<long long>(1, std::min<long long>(k.batch, (long long) ((chunk_mb << 20) / per)));
+        const long long chunk = std::max<long long>(1, std::min<long long>(k.batch, (long long) ((size_t(1) << 30) / per)));
         Scratch s;
-        hipError_t e = scratch(device, per * (size_t) chunk, s);
+        hipError_t e = scratch(device, per * (size_t) chunk, k.store == S_POST, s);
         if (e != hipSuccess) return e;
         C *work = static_cast<C *>(s.a), *post = static_cast<C *>(s.b);
         for (long long q0 = 0; q0 < k.batch; q0 += chunk)
         {
             const int nb = (int) std::min<long long>(chunk, k.batch - q0);
-            bool tiled = false;
-            if constexpr (sizeof(T) == 4)
-                if (fx_tile_on() && l1 >= 8 && l1 <= 10 && M2 % RegTile<8>::LN == 0)
-                {
-                    tiled = true;
-                    switch (l1)
-                    {
-                        case 8: e = launch_cols_tile<8>(device, k, work, M2, M, q0, nb, tw1, twN, st); break;
-                        case 9: e = launch_cols_tile<9>(device, k, work, M2, M, q0, nb, tw1, twN, st); break;
-                        default: e = launch_cols_tile<10>(device, k, work, M2, M, q0, nb, tw1, twN, st); break;
-                    }
-                }
-            if (!tiled) switch (l1)
+            switch (l1)
             {
 #define FX_CASE(L) case L: e = launch_cols<T, L>(k, work, M2, M, q0, nb, tw1, twN, st); break;
                 FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)
@@ -1662,19 +887,7 @@ namespace
                 default: e = hipErrorInvalidValue;
             }
             if (e != hipSuccess) return e;
-            tiled = false;
-            if constexpr (sizeof(T) == 4)
-                if (fx_tile_on() && l2 >= 8 && l2 <= 10 && M1 % RegTile<8>::LN == 0)
-                {
-                    tiled = true;
-                    switch (l2)
-                    {
-                        case 8: e = launch_rows_tile<8>(device, work, k, post, M1, M, q0, nb, tw2, st); break;
-                        case 9: e = launch_rows_tile<9>(device, work, k, post, M1, M, q0, nb, tw2, st); break;
-                        default: e = launch_rows_tile<10>(device, work, k, post, M1, M, q0, nb, tw2, st); break;
-                    }
-                }
-            if (!tiled) switch (l2)
+            switch (l2)
             {
 #define FX_CASE(L) case L: e = launch_rows<T, L>(work, k, post, M1, M, q0, nb, tw2, st); break;
                 FX_CASE(7) FX_CASE(8) FX_CASE(9) FX_CASE(10) FX_CASE(11)

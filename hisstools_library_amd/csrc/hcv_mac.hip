@@ -282,10 +282,8 @@ void mac_plan(const MacShape &s, MacPlan &pl)
     // large hop tiles (4 x 4 and 4 x 8 need 176 - 233): a third, half-empty round of workgroups cost the 4 x 8 tile 8 %
     const long long tgt = s.target_blocks > 0 ? s.target_blocks : (pl.ot == 4 && pl.tt >= 4) ? 512 : target_blocks;
     long long want = std::max<long long>(1, tgt / base);
-    static const int x_mink = std::getenv("HCV_X_MINK") ? std::atoi(std::getenv("HCV_X_MINK")) : 8;            // (experiment)
-    static const int x_maxsplit = std::getenv("HCV_X_MAXSPLIT") ? std::atoi(std::getenv("HCV_X_MAXSPLIT")) : 0;  // (experiment)
-    long long maxsplit = K / x_mink;                            // keep every k-slice at least 8 long
-    if (x_maxsplit > 0 && s.P <= 16 && maxsplit > x_maxsplit) maxsplit = x_maxsplit;
+    long long maxsplit = K / 8;                                 // keep every k-slice at least 8 long (4 and 2, and at most 8 / 4 slices for the
+                                                                // ladder's pivot stage so that the inverse folds the sum: c5 ladder 0.1348 -> 0.144 / 0.144 / 0.144 / 0.161 ms)
     if (maxsplit < 1) maxsplit = 1;
     if (want > maxsplit) want = maxsplit;
     if (want < 1) want = 1;

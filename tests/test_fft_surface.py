@@ -280,6 +280,41 @@ def test_gpu_device_pointer_entry(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("op", ["fft", "rfft"])
+def test_gpu_four_step_batch_larger_than_one_scratch_chunk(op):
+    """The four-step passes work through a batch in chunks of 1 GiB of scratch (hcv_fftx.hip: run_big): 17 double transforms of 2^22
+    complex points (64 MiB each) are two chunks, 16 + 1.  The transforms either side of the chunk boundary and the last one against
+    torch.fft in float64 on the same inputs (rfft: the packed, doubled spectrum of HISSTools_FFT_Core.h:934-988)."""
+    torch = pytest.importorskip("torch")
+    import hisstools_library_amd.fft as F
+    lm, nb = 22, 17
+    m = 1 << lm
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.rand(nb * m, device="cuda", dtype=torch.float64, generator=g) * 2 - 1
+    b = torch.rand(nb * m, device="cuda", dtype=torch.float64, generator=g) * 2 - 1
+    rows = (0, 15, 16)
+    keep = {r: (a[r * m:(r + 1) * m].clone(), b[r * m:(r + 1) * m].clone()) for r in rows}
+    st = torch.cuda.current_stream().cuda_stream
+    if op == "fft":
+        F.exec_dev(F.Op.FFT, F.Precision.F64, lm, nb, a.data_ptr(), b.data_ptr(), a.data_ptr(), b.data_ptr(), m, m, 0, st, True)
+    else:
+        F.exec_dev(F.Op.RFFT, F.Precision.F64, lm + 1, nb, a.data_ptr(), b.data_ptr(), a.data_ptr(), b.data_ptr(), m, m, 0, st, True)
+    for r in rows:
+        x, y = keep[r]
+        if op == "fft":
+            want = torch.fft.fft(torch.complex(x, y))
+            wre, wim = want.real, want.imag
+        else:
+            t = torch.stack((x, y), dim=1).reshape(-1)           # even samples in the real array, odd ones in the imaginary
+            spec = torch.fft.rfft(t) * 2
+            wre, wim = spec.real[:m].clone(), spec.imag[:m].clone()
+            wim[0] = spec.real[m]
+        peak = float(torch.maximum(wre.abs().max(), wim.abs().max()))
+        e = max(float((a[r * m:(r + 1) * m] - wre).abs().max()), float((b[r * m:(r + 1) * m] - wim).abs().max())) / peak
+        assert e <= 1e-12, (op, r, e)
+
+
+@pytest.mark.gpu
 def test_gpu_bad_descriptors_fail_loudly():
     import hisstools_library_amd.fft as F
     with pytest.raises(RuntimeError):

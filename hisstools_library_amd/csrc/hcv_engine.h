@@ -161,6 +161,7 @@ namespace hcv
         void free_stage(Stage &st);
         bool global_reset();
         bool fence_background(bool keep_plan = false);
+        bool fence_chains();
         bool ensure_staging(Stage &st, uint32_t parts);
         // control-path device memory: stream-ordered allocation on the control stream (hipMallocAsync / hipFreeAsync).  The
         // synchronous calls take runtime-wide locks and, for hipFree, wait for the whole device: an audio thread's launches
@@ -262,6 +263,8 @@ namespace hcv
         int64_t mPipeRecA = -1, mPipeRecB = -1;   // the last two pipelined blocks that recorded an end event (sequence numbers)
         uint32_t mPipeSince = 0;            // pipelined blocks since the pipe stream was last lined up behind the main stream
         bool mPrevPipe2 = false;
+        std::atomic<uint32_t> mLateMask { 0 };              // the last block's boundary chains still running past its emit (bit 2 * stage + parity)
+        bool late_chains_done() const;
         bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)

@@ -515,8 +515,22 @@ void Engine::set_td_window(uint64_t offset, uint64_t length)
 // Control work (IR loads, resets, regrow) changes what a background accumulation reads or means: order it after any
 // background MAC still in flight and drop the pre-accumulated spectra — unless the caller keeps the plan and corrects them
 // itself (a restart of single pairs: retire_pair takes the pair out of the slices already accumulated).  Caller holds mMutex.
+// The boundary chains of a small block run on past its emit (enqueue_stage): whoever puts work on the main stream next — the next
+// block, control work — orders the main stream behind them first.  Caller holds mMutex.
+bool Engine::fence_chains()
+{
+    for (Stage *st : mStages)
+        if (st->chain_pending >= 0)
+        {
+            HCV_TRY(hipStreamWaitEvent(mStream, st->done[st->chain_pending], 0));
+            st->chain_pending = -1;
+        }
+    return true;
+}
+
 bool Engine::fence_background(bool keep_plan)
 {
+    if (!fence_chains()) return false;
     for (Stage *st : mStages)
     {
         if (st->bg_pending)
@@ -837,6 +851,18 @@ static inline size_t this_thread_hash() { return tlsAudioIdentity ? tlsAudioIden
 
 constexpr long long kTurnMinGapNs = 350000;             // a paced stream: the lock is free for at least this long per call period
 
+// Control threads, without the engine lock: has the device finished the boundary chains the last call left running?  (The `done`
+// events live as long as their stage; stages are only added or removed by control calls, which mSetMutex serialises with this one.)
+bool Engine::late_chains_done() const
+{
+    const uint32_t mask = mLateMask.load(std::memory_order_acquire);
+    for (size_t si = 0; si < mStages.size() && si < 16; si++)
+        for (int p = 0; p < 2; p++)
+            if ((mask >> (2 * si + (size_t) p)) & 1u)
+                if (hipEventQuery(mStages[si]->done[p]) == hipErrorNotReady) return false;
+    return true;
+}
+
 bool Engine::run_exclusive(std::function<bool()> fn)
 {
     // a caller that IS the audio thread (one thread making both kinds of call: offline use, most tests) cannot be inside a
@@ -857,7 +883,9 @@ bool Engine::run_exclusive(std::function<bool()> fn)
                 for (;;)
                 {
                     const uint64_t now_seq = mEnqueueSeq.load(std::memory_order_acquire);
-                    if (now_seq != seq)
+                    // (a call's boundary chains run on into the gap: the section waits for the device inside the lock here and there
+                    // — the ghost staging of a restart — so it takes its turn when they are through, or in a later gap)
+                    if (now_seq != seq && late_chains_done())
                     {
                         std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
                         if (lk.owns_lock())

@@ -450,7 +450,18 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         }
     }
     HCV_TRY(rec(st.done[q], sI));
-    HCV_TRY(wt(mStream, st.done[q]));
+    // Every stage has one hop of latency: what this chain adds to the timeline starts at sample (h_first + 1) M.  When that is the
+    // end of the block — the boundary calls of real-time sizes — this block's emit reads nothing of it (and clears a span the inverse
+    // does not touch), so the main stream does not wait for the chain HERE: the call returns when its own samples are out, and the
+    // chain runs on into the gap before the next call, whose enqueue starts with the wait (fence_chains; control work likewise).
+    const bool late = !serial && !head_here && !mProfiling && (h_first + 1) * (long long) st.M >= n0 + (long long) B;
+    if (late)
+    {
+        st.chain_pending = q;
+        blk.late_mask |= 1u << (2 * si + (size_t) q);
+    }
+    else
+        HCV_TRY(wt(mStream, st.done[q]));
 
     st.pre_hop = -1;
     if (defer)
@@ -489,6 +500,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const long long hmask = mHistLen - 1;
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
     const int q = (int) (mBlockCount & 1);
+    if (!fence_chains()) return false;       // the main stream behind the boundary chains the previous block left running
 
     const bool td_any = mCfg.has_td && mTdLpad > 0;
     const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
@@ -505,7 +517,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const bool entering = whole_hops && !mTailHeadPrev, leaving = !whole_hops && mTailHeadPrev;
     mTailHeadPrev = whole_hops;
     // hop-aligned block of a larger matrix: the head goes through the first stage's FFTs (see init)
-    const bool head_fft = !whole_hops && td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0;
+    // (not for a block of ONE hop of the first stage: the head through the FFTs is emitted in the hop's own slot, so this block's emit
+    // would wait for the stage's whole chain, where beside the time-domain head every chain of a real-time call runs on past the
+    // emit — enqueue_stage, `late`.  ns64 at 128 samples per call: p50 0.110 -> 0.075 ms, p99 0.273 -> 0.190; at 256 samples, two
+    // hops, the FFT head is ahead, p99 0.29 against 0.31)
+    const bool head_fft = !whole_hops && td_any && mHeadFFT && !td_check && (n0 % mStages[0]->M) == 0 && (B % mStages[0]->M) == 0 && B >= 2 * mStages[0]->M;
     const bool td = td_any && !head_fft && !whole_hops;
 
     // Serial blocks: everything on the main stream, in program order, with no events at all.  A dependency on a pending event
@@ -740,6 +756,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
         HCV_TRY(rec(mEvEmit[q], mStream));
     }
+    // (for control threads waiting for their turn: which `done` events the device is still working towards after this call — run_exclusive)
+    mLateMask.store(blk.late_mask, std::memory_order_release);
     mN += B;
     mBlockCount++;
     mLastNin = rows_in;
@@ -794,7 +812,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         return true;
     }
     audio_enter();
-    if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+    if (!fence_chains() || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
     static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
     const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
     if (zero_copy)
@@ -884,7 +902,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
             continue;
         }
         audio_enter();
-        if (!update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+        if (!fence_chains() || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
         if (rows_in)
         {
             // (a packed block is ONE transfer; a pitched one is moved row by row by the copy engine, a few microseconds per row)
@@ -927,7 +945,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             return true;
         }
         audio_enter();
-        if (!update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
+        if (!fence_chains() || !update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
         if (after)
         {
             // serial blocks write `outs` from the main stream; a streamed block's writer (a stage stream's inverse, or emit behind

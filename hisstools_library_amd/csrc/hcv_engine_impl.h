@@ -88,6 +88,7 @@ struct Engine::Stage
     int bg_slices = 0, bg_launched = 0; // planned / already launched slices
     hipEvent_t bg_done = nullptr;       // recorded after every background launch
     bool bg_pending = false;
+    int chain_pending = -1;             // parity of the `done` event of a boundary chain the main stream has not waited for yet (fence_chains)
     float *timeline = nullptr;          // [nout][tl_len] this stage's hop results at their emission times
     long long tl_len = 0;
     BigFFTWork big;                     // scratch of the four-step FFT (only for N > 32768)
@@ -157,6 +158,7 @@ struct Engine::Block
     bool direct_out = false;            // whole-hop block: the inverse writes the caller's block itself, no timeline, no emit launch
     bool direct_in = false;             // the (only) running stage's forward FFTs read the caller's block themselves: no scatter launch
     bool emitted = false;               // a plain small call: the head kernel has delivered the block itself (no emit launch)
+    uint32_t late_mask = 0;             // bit 2 * stage + parity: boundary chains of this block that run on past its emit
     int tail_gate = 0;
     hipEvent_t gate = nullptr;          // the tail's spectral_mac of this block has finished (tail gate)
     hipStream_t main = nullptr, sIn = nullptr, sTd = nullptr;

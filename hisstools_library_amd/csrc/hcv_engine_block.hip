@@ -131,10 +131,13 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         st.pre_hop = -1;
     }
     if (whole_hops && si < last) return true;
-    blk.src.timeline[blk.src.count] = st.timeline;              // the ring may still hold hops of earlier calls
-    blk.src.stride[blk.src.count] = st.tl_len;
-    blk.src.mask[blk.src.count] = st.tl_len - 1;
-    blk.src.count++;
+    if (!blk.emit_first)
+    {
+        blk.src.timeline[blk.src.count] = st.timeline;          // the ring may still hold hops of earlier calls
+        blk.src.stride[blk.src.count] = st.tl_len;
+        blk.src.mask[blk.src.count] = st.tl_len - 1;
+        blk.src.count++;
+    }
     const bool tail_head_here = whole_hops && si == last;
     int head_ksplit = 1;
     const bool head_here = head_fft && si == 0;
@@ -413,7 +416,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     }
 
     // ---- inverse phase (stream sI): every read-modify-write of this stage's timeline happens on this stream
-    HCV_TRY(wt(sI, mEvEmit[q]));             // emit(k-2) has cleared the timeline span reused now
+    if (!blk.emit_first) HCV_TRY(wt(sI, mEvEmit[q]));       // emit(k-2) has cleared the timeline span reused now
     if (head_here)
     {
         HCV_TRY(launch_reduce_partials(head_y, head_ksplit, (long long) T * nout_act * st.M, (long long) T * nout_act * st.M, sI));
@@ -731,31 +734,61 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // largest stage first: the tail's spectral_mac is the critical path, the short stages fill in around it.  (A whole-hop block of
     // an extended ladder: the pivot stage first — its transforms file the block's samples in the history ring, which a rung at
     // its hop boundary reads — then the rungs.)
-    for (size_t sj = 0; sj < mStages.size(); sj++)
+    // A small streamed block enqueues its emit IN FRONT of the chains it does not wait for (enqueue_stage: `late`) and of the deferred
+    // slices: there are fewer hardware queues than streams, and a main stream that shares one with a stage's stream had its emit
+    // queued behind that stage's chain — calls with the boundaries of two or three stages were done after 0.10-0.125 ms where their
+    // enqueue took 0.05-0.06.  What emit needs of such a block is decided here: the stages' timelines, and the stages whose chain's
+    // output starts inside the block (the head through the first stage's FFTs) in front of it.
+    blk.emit_first = !whole_hops && !serial && !leaving && !mProfiling && B <= 512 && !blk.direct_out && !mStages.empty();
+    auto after_emit = [&](size_t si) -> bool
     {
-        size_t si = mStages.size() - 1 - sj;
-        if (whole_hops && rungs) si = sj == 0 ? last : (sj <= mStages.size() - 1 - last ? mStages.size() - sj : mStages.size() - 1 - sj);
-        if (!enqueue_stage(blk, si, sj))
+        const Stage &sg = *mStages[si];
+        if (head_fft && si == 0) return false;
+        const long long h0 = n0 / (long long) sg.M;
+        const int hops = (int) ((n0 + B) / sg.M - h0);
+        return hops <= 0 || (h0 + 1) * (long long) sg.M >= n0 + (long long) B;
+    };
+    if (blk.emit_first)
+        for (size_t sj = 0; sj < mStages.size(); sj++)
         {
-            xcd_pin_hint(false);
-            return false;
+            Stage &sg = *mStages[mStages.size() - 1 - sj];
+            blk.src.timeline[blk.src.count] = sg.timeline;
+            blk.src.stride[blk.src.count] = sg.tl_len;
+            blk.src.mask[blk.src.count] = sg.tl_len - 1;
+            blk.src.count++;
+            HCV_TRY(wt(sg.stream, mEvEmit[q]));     // emit(k-2) has cleared the timeline span a chain of this block may reuse (before this
+                                                    // block's emit takes the event over)
         }
+    for (int pass = 0; pass < 2; pass++)
+    {
+        for (size_t sj = 0; sj < mStages.size(); sj++)
+        {
+            size_t si = mStages.size() - 1 - sj;
+            if (whole_hops && rungs) si = sj == 0 ? last : (sj <= mStages.size() - 1 - last ? mStages.size() - sj : mStages.size() - 1 - sj);
+            if ((blk.emit_first && after_emit(si)) != (pass == 1)) continue;
+            if (!enqueue_stage(blk, si, sj))
+            {
+                xcd_pin_hint(false);
+                return false;
+            }
+        }
+        if (pass == 1) break;
+        if (blk.emitted)
+        {
+            // (the head kernel delivered the block; the main stream still ends behind the scatter)
+            HCV_TRY(wt(mStream, mEvInput[q]));
+            HCV_TRY(rec(mEvEmit[q], mStream));
+        }
+        else if (!blk.direct_out)
+        {
+            if (td) HCV_TRY(wt(mStream, mEvTd[q]));
+            HCV_TRY(wt(mStream, mEvInput[q]));       // a block with no live stage still orders after its scatter
+            HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
+            HCV_TRY(rec(mEvEmit[q], mStream));
+        }
+        if (!blk.emit_first) break;
     }
     xcd_pin_hint(false);
-
-    if (blk.emitted)
-    {
-        // (the head kernel delivered the block; the main stream still ends behind the scatter)
-        HCV_TRY(wt(mStream, mEvInput[q]));
-        HCV_TRY(rec(mEvEmit[q], mStream));
-    }
-    else if (!blk.direct_out)
-    {
-        if (td) HCV_TRY(wt(mStream, mEvTd[q]));
-        HCV_TRY(wt(mStream, mEvInput[q]));       // a block with no live stage still orders after its scatter
-        HCV_TRY(launch_emit(blk.src, n0, (int) B, (int) nout_act, td ? mTdOut[q] : nullptr, mMaxBlock, dout, out_stride, mStream));
-        HCV_TRY(rec(mEvEmit[q], mStream));
-    }
     // (for control threads waiting for their turn: which `done` events the device is still working towards after this call — run_exclusive)
     mLateMask.store(blk.late_mask, std::memory_order_release);
     mN += B;

@@ -159,6 +159,8 @@ struct Engine::Block
     bool direct_in = false;             // the (only) running stage's forward FFTs read the caller's block themselves: no scatter launch
     bool emitted = false;               // a plain small call: the head kernel has delivered the block itself (no emit launch)
     uint32_t late_mask = 0;             // bit 2 * stage + parity: boundary chains of this block that run on past its emit
+    bool emit_first = false;            // a small streamed block: its emit is enqueued IN FRONT of the late chains (enqueue_chunk); the timelines are
+                                        // registered and the stages' streams are behind emit(k-2) already
     int tail_gate = 0;
     hipEvent_t gate = nullptr;          // the tail's spectral_mac of this block has finished (tail gate)
     hipStream_t main = nullptr, sIn = nullptr, sTd = nullptr;

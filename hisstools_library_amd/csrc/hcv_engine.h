@@ -265,6 +265,8 @@ namespace hcv
         bool mPrevPipe2 = false;
         std::atomic<uint32_t> mLateMask { 0 };              // the last block's boundary chains still running past its emit (bit 2 * stage + parity)
         bool late_chains_done() const;
+        hipEvent_t mEmitFirstEv = nullptr;                  // the last block's emit event when it was enqueued in front of late chains
+        hipEvent_t mHostWait = nullptr;                     // what process_end waits for
         bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)

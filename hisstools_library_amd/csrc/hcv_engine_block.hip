@@ -789,6 +789,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         if (!blk.emit_first) break;
     }
     xcd_pin_hint(false);
+    mEmitFirstEv = (blk.emit_first && !blk.direct_out) ? mEvEmit[q] : nullptr;
     // (for control threads waiting for their turn: which `done` events the device is still working towards after this call — run_exclusive)
     mLateMask.store(blk.late_mask, std::memory_order_release);
     mN += B;
@@ -866,7 +867,15 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         if (!enqueue_chunk(mDevIn, B, mDevOut, B, nin_act, nout_act, B)) return false;
         HCV_TRY(hipMemcpyAsync(mPinOut, mDevOut, sizeof(float) * nout_act * B, hipMemcpyDeviceToHost, mStream));
     }
-    HCV_TRY(hipEventRecord(mEvHostDone, mStream));
+    // (a zero-copy block that enqueued its emit in front of its late chains is waited for through that emit's own event: an event
+    // recorded NOW goes to the end of the main stream's hardware queue, behind the chains of whichever stage's stream shares it —
+    // host-pointer calls carrying two or three boundaries took 0.14 ms where device-pointer calls took 0.07)
+    if (zero_copy && mEmitFirstEv) mHostWait = mEmitFirstEv;
+    else
+    {
+        HCV_TRY(hipEventRecord(mEvHostDone, mStream));
+        mHostWait = mEvHostDone;
+    }
     audio_leave(lk);                    // (the clock, a section posted meanwhile, the lock back and a waiting control thread's turn)
     return true;
 }
@@ -883,7 +892,7 @@ bool Engine::process_end(float *const *outs, uint32_t nout_act, uint32_t B, bool
         return true;
     }
     DeviceGuard dg(mDevice);
-    HCV_TRY(hipEventSynchronize(mEvHostDone));
+    HCV_TRY(hipEventSynchronize(mHostWait ? mHostWait : mEvHostDone));
     for (uint32_t o = 0; o < nout_act; o++)
     {
         float *dst = outs[o];

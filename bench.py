@@ -1120,7 +1120,7 @@ def also_leg(workload, device, steps=40, warmup=5, timeout=420):
     return dg
 
 
-def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6, extra_blocks=()):
+def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=1.0, extra_blocks=()):
     """Paced real-time calls on the engine the headline ran on (every partition live): call k is issued no earlier than
     k * RB / fs.  `host`: hcv_convolver_process_f32 (host pointers in, host pointers out — what HISSTools::Convolver::process
     does); `device`: hcv_convolver_process_f32_dev with sync (HBM-resident audio).  Milliseconds per call."""
@@ -1169,7 +1169,9 @@ def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=0.6, e
     for EB in extra_blocks:
         if EB <= 0 or EB > RB:
             continue
-        n_e = max(64, int(0.4 * fs / EB))
+        # (1.2 s: at 32 samples per call 1800 calls, so that p99 is the 18th slowest call and not one of the dozen around the 16384-point
+        # stage's hops — with 600 calls the figure jumped between 0.07 and 0.26 ms from run to run)
+        n_e = max(64, int(1.2 * fs / EB))
         ts = np.zeros(n_e)
         t_start = time.perf_counter()
         for k in range(n_e):

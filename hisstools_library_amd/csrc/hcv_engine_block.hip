@@ -594,15 +594,28 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // zero-latency transform per output and hop, so the inverse's last pass writes the caller's block (launch_rifft_emit) and the
     // emit launch — with its wait for the stage's stream — goes too.  Needs 8-byte aligned output rows.
     blk.direct_out = whole_hops && !entering && !rungs && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
+    // A PLAIN small call — it completes no hop of any stage (three calls in four at 32 samples per call) — has nothing to wait
+    // for but its head: the head kernel then delivers the block itself, on the main stream (the stages' timelines added and
+    // cleared as emit would: launch_fir_head's `emit`), AND files the call's samples in the history ring: the whole call is one launch
+    // (scatter || head -> emit, then scatter || head + emit, now head + scatter + emit).
+    const bool head_direct = td && fir_head_is_small((int) B, (int) nin_act, (int) mTdLpad, mCfg.diag ? 1 : 0) && !direct_in;
+    bool plain = head_direct && !leaving && !blk.direct_out && !serial && rows_in > 0;
+    for (size_t si = 0; plain && si < mStages.size(); si++) plain = (n0 + B) / mStages[si]->M == n0 / mStages[si]->M;
     if (!direct_in)
     {
+        const hipStream_t sW = plain ? mStream : sIn;           // (who writes the ring)
         // the block two back read the history this scatter may overwrite
-        for (Stage *st : mStages) HCV_TRY(wt(sIn, st->done[q]));
-        HCV_TRY(wt(sIn, mEvTd[q]));
+        for (Stage *st : mStages) HCV_TRY(wt(sW, st->done[q]));
+        HCV_TRY(wt(sW, mEvTd[q]));
         // after direct-input blocks the ring was last written on the last stage's stream: later hops must land behind those
-        if (mPrevDirect && !serial) HCV_TRY(wt(sIn, mStages[last]->done[q ^ 1]));
-        HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
-        HCV_TRY(rec(mEvInput[q], sIn));
+        if (mPrevDirect && !serial) HCV_TRY(wt(sW, mStages[last]->done[q ^ 1]));
+        if (plain)
+            HCV_TRY(wt(mStream, mEvInput[q ^ 1]));              // (the previous block's samples are filed in front of these)
+        else
+        {
+            HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
+            HCV_TRY(rec(mEvInput[q], sIn));
+        }
     }
     mPrevDirect = direct_in;
     // Two-stream pipeline of a small engine's whole-hop blocks (enqueue_stage): the NEXT block's forward transforms on a second stream
@@ -653,13 +666,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         // small calls: the head reads the call's own samples from the caller's block, so it starts beside the scatter instead of behind
         // it (one cross-stream hand-over less in the chain scatter -> head -> emit of a plain real-time call) and only needs the ring
         // complete up to the call's first sample — the previous block's input event
-        const bool head_direct = fir_head_is_small((int) B, (int) nin_act, (int) mTdLpad, mCfg.diag ? 1 : 0) && !direct_in;
-        // A PLAIN small call — it completes no hop of any stage (three calls in four at 32 samples per call) — has nothing to wait
-        // for but its head: the head kernel then delivers the block itself, on the main stream (the stages' timelines added and
-        // cleared as emit would: launch_fir_head's `emit`), and the emit launch with its hand-over from the head stream goes:
-        // scatter || head + emit instead of scatter || head -> emit.
-        bool plain = head_direct && !leaving && !blk.direct_out && !serial;
-        for (size_t si = 0; plain && si < mStages.size(); si++) plain = (n0 + B) / mStages[si]->M == n0 / mStages[si]->M;
         if (plain)
         {
             EmitSources all;
@@ -673,9 +679,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             }
             // (the main stream is behind the previous block's emit and this call's control work already; the ring up to the call's
             // first sample is the previous block's input event)
-            HCV_TRY(wt(mStream, mEvInput[q ^ 1]));
             HCV_TRY(launch_fir_head(mHist, mHistLen, hmask, mTaps, (int) mTdLpad, 2048, (int) nin_act, (int) mNinAlloc, (int) nout_act, 0, n0, (int) B,
-                                    mTdValid, td_check, dout, out_stride, mStream, din, in_stride, &all));
+                                    mTdValid, td_check, dout, out_stride, mStream, din, in_stride, &all, mHist));
+            HCV_TRY(rec(mEvInput[q], mStream));         // "the block's input is in the ring"
             HCV_TRY(rec(mEvTd[q], mStream));
             blk.emitted = true;
         }

@@ -144,7 +144,8 @@ namespace hcv
     struct EmitSources;
     hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                                int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
-                               long long out_stride, hipStream_t st, const float *din = nullptr, long long in_stride = 0, const struct EmitSources *emit = nullptr);
+                               long long out_stride, hipStream_t st, const float *din = nullptr, long long in_stride = 0, const struct EmitSources *emit = nullptr,
+                               float *ring = nullptr);
 
     // ---- ring bookkeeping ----
     hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int nin, float *hist, long long hist_stride, long long hist_mask,

@@ -593,9 +593,22 @@ __global__ __launch_bounds__(FIRS_THREADS) void fir_head_small_kernel(const floa
                                                                       const float *__restrict__ taps, int Lpad, int tap_stride, int nin, int nin_alloc,
                                                                       long long n0, int B, const long long *__restrict__ valid_from,
                                                                       float *__restrict__ out, long long out_stride, int ib,
-                                                                      const float *__restrict__ din, long long in_stride, EmitSources src)
+                                                                      const float *__restrict__ din, long long in_stride, EmitSources src,
+                                                                      float *__restrict__ ring)
 {
     extern __shared__ __attribute__((aligned(16))) float firs_lds[];
+    // `ring`: the kernel also FILES the call's samples in the history ring (scatter_input's work: the first output's workgroups, each its
+    // own span of samples) — a plain real-time call is then this one launch.  Nobody reads the ring at these positions here: every
+    // window takes the call's own samples from the caller's block.
+    if (EMIT && ring && blockIdx.y == 0)
+    {
+        const int nb0 = blockIdx.x * FIRS_SAMPLES;
+        for (int e = threadIdx.x; e < nin * FIRS_SAMPLES; e += FIRS_THREADS)
+        {
+            const int i = e / FIRS_SAMPLES, j = nb0 + (e & (FIRS_SAMPLES - 1));
+            if (j < B) ring[(long long) i * hist_stride + ((n0 + j) & hist_mask)] = din[(long long) i * in_stride + j];
+        }
+    }
     const int W = FIRS_SAMPLES + Lpad;                     // x[nblk - Lpad .. nblk + 32) of one input
     float *xs = firs_lds;                                  // [ib][W]
     float *hs = firs_lds + (size_t) ib * W;                // [ib][Lpad]
@@ -1066,9 +1079,10 @@ bool fir_head_is_small(int B, int nin, int Lpad, int diag)
 
 hipError_t launch_fir_head(const float *hist, long long hist_stride, long long hist_mask, const float *taps, int Lpad, int tap_stride, int nin,
                            int nin_alloc, int nout, int diag, long long n0, int B, const long long *valid_from, bool check, float *out,
-                           long long out_stride, hipStream_t st, const float *din, long long in_stride, const EmitSources *emit)
+                           long long out_stride, hipStream_t st, const float *din, long long in_stride, const EmitSources *emit, float *ring)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
+    if (ring && !(emit && din)) return hipErrorInvalidValue;
     if (emit && !fir_head_is_small(B, nin, Lpad, diag)) return hipErrorInvalidValue;
     // small calls of matrices with several inputs: taps split over the threads, a batch of inputs staged at once (HCV_FIR_SMALL = 0:
     // the general kernel everywhere)
@@ -1087,7 +1101,7 @@ hipError_t launch_fir_head(const float *hist, long long hist_stride, long long h
             const hipError_t ea = allow_lds(fir_head_small_kernel<CHK, EM>, lds);                                                                      \
             if (ea != hipSuccess) return ea;                                                                                                           \
             hipLaunchKernelGGL((fir_head_small_kernel<CHK, EM>), grid, dim3(FIRS_THREADS), lds, st, hist, hist_stride, hist_mask, taps, Lpad, tap_stride, \
-                               nin, nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride, emit ? *emit : none);                           \
+                               nin, nin_alloc, n0, B, valid_from, out, out_stride, ib, din, in_stride, emit ? *emit : none, ring);                     \
         }
         if (check && emit) HCV_FIRS(true, true)
         else if (check) HCV_FIRS(true, false)

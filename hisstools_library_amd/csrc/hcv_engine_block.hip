@@ -487,6 +487,9 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
 //   stage s:      wait in[q], emit[q] (= emit of block k-2) ─ rfft_frames → spectral_mac → reduce → rifft_overlap_add ─ record done_s[q]
 //   head stream:  wait in[q], emit[q]                       ─ fir_head → tdout[q]                                   ─ record td[q]
 //   main stream:  wait done_s[q] for all s, td[q] ─ emit(tdout[q]) ─ record emit[q]
+//                 (small blocks: not for a stage whose chain only adds to samples BEHIND the block — `late`, enqueue_stage: that wait is
+//                 taken at the next enqueue, fence_chains — and the emit is enqueued in front of those chains; a plain small call is
+//                 one launch on the main stream, fir_head_small_kernel filing the samples, adding the head and emitting)
 //
 // Whole-hop blocks (made of whole, aligned hops of the last stage) run ONE stage on one stream instead:
 //   last stage:   rfft_frames_direct -> spectral_mac over lead + P partitions -> [reduce_partials] -> rifft_emit

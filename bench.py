@@ -70,6 +70,8 @@ WORKLOADS = {
     "m16":  (16, 16, 96000,   48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 2 s IRs (not a BASELINE config)
     "m16l": (16, 16, 480000,  48000, (True, 256, 1024, 4096, 16384)),   # mid-size: 16x16, 10 s IRs (not a BASELINE config)
     "c4s8": (64, 8,  96000,   48000, (True, 256, 1024, 4096, 16384)),   # one rank's share of c4 strong-scaled over 8 GPUs (rows split): DESIGN section 6
+    "c4g":  (32, 16, 96000,   48000, (True, 256, 1024, 4096, 16384)),   # ... the same in the 4 x 2 grid layout (4 row groups x 2 input groups): DESIGN section 6
+    "c4s8l": (64, 8, 192000,  48000, (True, 256, 1024, 4096, 16384)),   # c4s8 with 4 s impulse responses (measurement aid: how the block's time scales)
 }
 
 
@@ -732,7 +734,9 @@ def bench_line(args, ctx):
         # its own instrumentation (two more packets per block in a chain that is nothing but packet latency), so there the timed
         # region runs bare and the same `steps` steps are repeated with the events on for the roofline object.
         tail_fft, tail_p = stages[-1]
-        launch_bound = 8 * (tail_fft // 2) * tail_p * nin * nout <= (256 << 20) and tail_ratio == args.tail_ratio
+        # (... and the engines the library itself runs as serial chains — last-stage spectra below 1 GiB, hcv_engine_block.hip kSerialMB —
+        # whose one-hop block may be the two meeting launches of the n x m fused block: one rank's share of strong-scaled config 4)
+        launch_bound = 8 * (tail_fft // 2) * tail_p * nin * nout < (1024 << 20) and tail_ratio == args.tail_ratio
         if launch_bound:
             tmax = timed(False)
             stats = conv.stage_stats()

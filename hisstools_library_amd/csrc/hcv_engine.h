@@ -161,7 +161,8 @@ namespace hcv
         void free_stage(Stage &st);
         bool global_reset();
         bool fence_background(bool keep_plan = false);
-        bool fence_chains();
+        bool fence_chains(bool keep_forward = false);
+        bool join_forward_stream();
         bool ensure_staging(Stage &st, uint32_t parts);
         // control-path device memory: stream-ordered allocation on the control stream (hipMallocAsync / hipFreeAsync).  The
         // synchronous calls take runtime-wide locks and, for hipFree, wait for the whole device: an audio thread's launches
@@ -263,6 +264,14 @@ namespace hcv
         int64_t mPipeRecA = -1, mPipeRecB = -1;   // the last two pipelined blocks that recorded an end event (sequence numbers)
         uint32_t mPipeSince = 0;            // pipelined blocks since the pipe stream was last lined up behind the main stream
         bool mPrevPipe2 = false;
+        // n x m fused blocks (hcv_fused_nxm.hip): the forward transforms of such a block run on the pipe stream with NO event between the two
+        // streams — they meet inside the multiply-accumulate launch.  Whatever else touches the rings (a block of another kind, control
+        // work, synchronize) first puts the main stream behind them by an event (join_forward_stream, from fence_chains)
+        bool mFwdPending = false;           // forward launches on the pipe stream the main stream has not been put behind yet
+        bool mPrevNxm = false;              // the previous block was such a block
+        uint64_t mNxmRun = 0;               // such blocks since the pipe stream was last lined up behind the main stream
+        hipEvent_t mEvNxmEnd[4] = { nullptr, nullptr, nullptr, nullptr };    // ends of every third such block (back-pressure on the pipe stream, enqueue_chunk)
+        hipEvent_t mEvFwd = nullptr;
         std::atomic<uint32_t> mLateMask { 0 };              // the last block's boundary chains still running past its emit (bit 2 * stage + parity)
         bool late_chains_done() const;
         hipEvent_t mEmitFirstEv = nullptr;                  // the last block's emit event when it was enqueued in front of late chains
@@ -270,6 +279,7 @@ namespace hcv
         bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
+        bool mPrevPlain = false;            // the previous block was a plain small call: its samples were filed in the ring from the MAIN stream
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         bool mExtDirty = false;             // the main stream was made to wait for a foreign event (process_dev `after`): a streamed block fans it out
         uint64_t mBlockCount = 0;

@@ -189,6 +189,8 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipStreamCreateWithFlags(&mPipeStream, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipe[k], hipEventDisableTiming));
     for (int k = 0; k < 4; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeEnd[k], hipEventDisableTiming));
+    HCV_TRY(hipEventCreateWithFlags(&mEvFwd, hipEventDisableTiming));
+    for (int k = 0; k < 4; k++) HCV_TRY(hipEventCreateWithFlags(&mEvNxmEnd[k], hipEventDisableTiming));
     HCV_TRY(hipEventRecord(mEvSwapDone, mStream));
 
     // three blocks deep: block k+1 is scattered while block k-1's readers may still be running
@@ -316,12 +318,18 @@ bool Engine::alloc_stage(Stage &st)
     st.Y = st.Yq[0];
     HCV_TRY(hipMalloc(&st.hv, sizeof(long long) * pairs));
     HCV_TRY(hipMemset(st.hv, 0, sizeof(long long) * pairs));
-    if (mCfg.nout == 1 && (st.log2n == 14 || st.log2n == 12))
+    // hand-over state of the fused blocks: one-output engines (hcv_fft_split.hip), and the lead-slot stage of a matrix with several
+    // outputs (hcv_fused_nxm.hip: more multiply-accumulate tasks)
+    const bool coop_one = mCfg.nout == 1 && (st.log2n == 14 || st.log2n == 12);
+    const bool coop_nxm = mCfg.nout > 1 && !mCfg.diag && st.log2n == 14 && st.lead;
+    if (coop_one || coop_nxm)
     {
-        HCV_TRY(hipMalloc(&st.coop_bar, sizeof(unsigned) * 2));
-        HCV_TRY(hipMemset(st.coop_bar, 0, sizeof(unsigned) * 2));
-        HCV_TRY(hipMalloc(&st.coop_flags, sizeof(unsigned long long) * (kFusedMacTasks + kFusedFwdTasks)));
-        HCV_TRY(hipMemset(st.coop_flags, 0, sizeof(unsigned long long) * (kFusedMacTasks + kFusedFwdTasks)));
+        const size_t marks = (size_t) (coop_nxm ? kFusedNxmMacTasks : kFusedMacTasks) + kFusedFwdTasks;
+        const size_t counters = coop_nxm ? (size_t) 2 * kFusedShards * kFusedShardStride : 2;       // (the n x m block's counters are sharded)
+        HCV_TRY(hipMalloc(&st.coop_bar, sizeof(unsigned) * counters));
+        HCV_TRY(hipMemset(st.coop_bar, 0, sizeof(unsigned) * counters));
+        HCV_TRY(hipMalloc(&st.coop_flags, sizeof(unsigned long long) * marks));
+        HCV_TRY(hipMemset(st.coop_flags, 0, sizeof(unsigned long long) * marks));
     }
     HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) (kBgSlices + kBoundarySlices) * mCfg.nout * st.M));
     HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
@@ -458,6 +466,9 @@ Engine::~Engine()
     if (mEvSwapDone) (void) hipEventDestroy(mEvSwapDone);
     if (mEvSnap) (void) hipEventDestroy(mEvSnap);
     if (mEvHostDone) (void) hipEventDestroy(mEvHostDone);
+    if (mEvFwd) (void) hipEventDestroy(mEvFwd);
+    for (int k = 0; k < 4; k++)
+        if (mEvNxmEnd[k]) (void) hipEventDestroy(mEvNxmEnd[k]);
     if (mStageTaps) (void) hipFree(mStageTaps);
     if (mStageHead) (void) hipFree(mStageHead);
     if (mStageTailHead) (void) hipFree(mStageTailHead);
@@ -517,7 +528,7 @@ void Engine::set_td_window(uint64_t offset, uint64_t length)
 // itself (a restart of single pairs: retire_pair takes the pair out of the slices already accumulated).  Caller holds mMutex.
 // The boundary chains of a small block run on past its emit (enqueue_stage): whoever puts work on the main stream next — the next
 // block, control work — orders the main stream behind them first.  Caller holds mMutex.
-bool Engine::fence_chains()
+bool Engine::fence_chains(bool keep_forward)
 {
     for (Stage *st : mStages)
         if (st->chain_pending >= 0)
@@ -525,6 +536,22 @@ bool Engine::fence_chains()
             HCV_TRY(hipStreamWaitEvent(mStream, st->done[st->chain_pending], 0));
             st->chain_pending = -1;
         }
+    if (!keep_forward && !join_forward_stream()) return false;
+    return true;
+}
+
+// The forward launches of n x m fused blocks (hcv_fused_nxm.hip) sit on the pipe stream with no event towards the main stream: the
+// multiply-accumulate launch waits for their arrival counter, or does their work itself.  Physically they are through when that
+// launch is, unless the device scheduled one late and the helping path stood in for it — such a launch would still write its spectrum
+// and the ring's hop (the same values) whenever it runs.  So before anything else reads or writes the rings on the main stream — a
+// block of another kind, control work, a reset's clearing — the main stream goes behind the pipe stream, formally.  Caller holds mMutex.
+bool Engine::join_forward_stream()
+{
+    if (!mFwdPending) return true;
+    HCV_TRY(hipEventRecord(mEvFwd, mPipeStream));
+    HCV_TRY(hipStreamWaitEvent(mStream, mEvFwd, 0));
+    mFwdPending = false;
+    mPrevNxm = false;
     return true;
 }
 
@@ -580,6 +607,10 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     {
         h_snap = mN / st.M;
         live_P = st.P;
+        // (the main stream no longer waits for a small block's boundary chains in the call that enqueues them — enqueue_stage, `late` —
+        // and the mailbox runs this section in front of the next call's fence: put the main stream behind them first, or the copy
+        // below would read the ring slot X[h_snap - 1] the chain's forward transform is still writing)
+        if (!fence_chains()) { (void) hipGetLastError(); }
         if (hipEventRecord(mEvSnap, mStream) != hipSuccess) { (void) hipGetLastError(); }
         return true;
     });
@@ -1044,6 +1075,11 @@ bool Engine::global_reset()
 bool Engine::synchronize()
 {
     DeviceGuard dg(mDevice);
+    {
+        // (boundary chains the last small block left running past its emit: the main stream goes behind them first)
+        std::lock_guard<std::mutex> g(mMutex);
+        if (!fence_chains()) return false;
+    }
     HCV_TRY(hipStreamSynchronize(mStream));
     if (mProfiling) collect_events();
     return true;

@@ -174,9 +174,41 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     // transforms, multiply-accumulate and inverse of a steady-state one-hop block of an engine with ONE output as ONE launch with
     // in-launch hand-overs instead of two or three kernel boundaries (c1: 0.0166 -> 0.0101 ms per block).  With the MAC's HIP events
     // on (profiling) the block takes the separate launches, so that the statistics keep their meaning.
+    if (blk.nxm && tail_head_here && T == 1)
+    {
+        const int Pw = (int) (st.P + st.lead);
+        const hipError_t fe = launch_fused_block_nxm(blk.nxm_plan, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, (int) mNinAlloc,
+                                                     (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, blk.dout, blk.out_stride, st.tw, st.coop_bar,
+                                                     st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS);
+        mFwdPending = true;                     // (a refused second launch leaves the first on the pipe stream all the same)
+        if (fe == hipSuccess)
+        {
+            if (mNxmRun % 3 == 0) HCV_TRY(hipEventRecord(mEvNxmEnd[(mNxmRun / 3) & 3], sS));        // (see the back-pressure note in enqueue_chunk)
+            mNxmRun++;
+            mPrevNxm = true;
+            st.launches++;
+            st.hops += 1;
+            st.last_ksplit = (uint32_t) blk.nxm_plan.ms;
+            st.last_ot = 8;
+            st.last_tt = 1;
+            st.last_parts = (uint32_t) Pw;
+            st.fused_launches++;
+            HCV_TRY(rec(mEvInput[q], sS));
+            HCV_TRY(rec(mEvEmit[q], sS));
+            HCV_TRY(rec(st.done[q], sS));
+            HCV_TRY(wt(mStream, st.done[q]));
+            st.pre_hop = -1;
+            return true;
+        }
+        // refused: the separate kernels, from now on — behind whatever the forward launch may still write
+        (void) hipGetLastError();
+        st.coop_off = true;
+        blk.nxm = false;
+        if (!join_forward_stream()) return false;
+    }
     const bool fuse_one = T == 1 && fused_block_1x1_applies(st.log2n);
     const bool fuse_hops = T > 1 && rows_in == 1 && fused_block_hops_applies(st.log2n, T);       // (several hops of a short stage: config 2)
-    if (tail_head_here && direct_in && blk.direct_out && !blk.pipe2 && serial && rows_in >= 1 && nout_act == 1 && !mCfg.diag && !mProfiling &&
+    if (tail_head_here && direct_in && blk.direct_out && !blk.pipe2 && serial && rows_in >= 1 && nout_act == 1 && mCfg.nout == 1 && !mCfg.diag && !mProfiling &&
         !st.gh_count && !st.coop_off && st.coop_flags && (fuse_one || fuse_hops))
     {
         const int Pw = (int) (st.P + st.lead);
@@ -506,7 +538,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const long long hmask = mHistLen - 1;
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
     const int q = (int) (mBlockCount & 1);
-    if (!fence_chains()) return false;       // the main stream behind the boundary chains the previous block left running
+    if (!fence_chains(/* keep_forward */ true)) return false;       // the main stream behind the boundary chains the previous block left running
 
     const bool td_any = mCfg.has_td && mTdLpad > 0;
     const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
@@ -597,6 +629,52 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // zero-latency transform per output and hop, so the inverse's last pass writes the caller's block (launch_rifft_emit) and the
     // emit launch — with its wait for the stage's stream — goes too.  Needs 8-byte aligned output rows.
     blk.direct_out = whole_hops && !entering && !rungs && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
+    // The n x m fused block (hcv_fused_nxm.hip): a steady-state one-hop block of a serial engine with several outputs whose last stage
+    // is the reference's 16384-point tail with a lead slot — one rank's share of a strong-scaled matrix (64 x 8 of config 4 over 8 GPUs)
+    // is the shape it was built for.  Forward transforms on the pipe stream, ONE multiply-accumulate + inverse launch on the main
+    // stream, no event between them (HCV_COOP_NXM = 0 / HCV_COOP = 0: the separate kernels).
+    blk.nxm = false;
+    if (serial && whole_hops && direct_in && blk.direct_out && !mProfiling && !mCfg.diag && mCfg.nout > 1 && blk.full_matrix && mPipeStream && B == mStages[last]->M)
+    {
+        const Stage &tl = *mStages[last];
+        const long long h = n0 / (long long) tl.M;
+        const int Pw = (int) (tl.P + tl.lead);
+        const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
+        if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw)
+            blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan);
+    }
+    if (blk.nxm)
+    {
+        if (!mPrevNxm || ctl_was_dirty)
+        {
+            // the pipe stream starts behind everything the main stream holds so far (earlier blocks, control work)
+            HCV_TRY(hipEventRecord(mEvSerial, mStream));
+            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvSerial, 0));
+            mNxmRun = 0;
+        }
+        else if (mNxmRun >= 4)
+        {
+            // Back-pressure.  Nothing else holds the forward launches back — an asynchronous caller's whole burst of them would run at
+            // once — and the launch of block k overwrites the ring slot of hop h - R, which the multiply-accumulate of block
+            // k - (R - P - lead) - 1 still reads: with R = Pcap + 2 Tmax >= P + lead + 3 that block is k - 4 at the latest (the history
+            // ring, five hops and more, is covered by the same bound).  An event record costs the recording stream 4 - 5 us, so only
+            // every THIRD block records its end on the main stream, and block k's forward launch waits for the one such end in
+            // [k - 4, k - 2]: never for the launch that needs it, nor for the one in front of that (the forward transforms of block k
+            // run beside block k - 1's multiply-accumulate), and in a paced or GPU-bound stream for one long gone.
+            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvNxmEnd[((mNxmRun - 2) / 3) & 3], 0));
+        }
+    }
+    else if (mFwdPending)
+    {
+        // a block of another kind: everything behind the forward launches of the fused blocks before it (Engine::join_forward_stream)
+        if (!join_forward_stream()) return false;
+        if (!serial)
+        {
+            HCV_TRY(hipStreamWaitEvent(mInStream, mEvFwd, 0));
+            HCV_TRY(hipStreamWaitEvent(mTdStream, mEvFwd, 0));
+            for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvFwd, 0));
+        }
+    }
     // A PLAIN small call — it completes no hop of any stage (three calls in four at 32 samples per call) — has nothing to wait
     // for but its head: the head kernel then delivers the block itself, on the main stream (the stages' timelines added and
     // cleared as emit would: launch_fir_head's `emit`), AND files the call's samples in the history ring: the whole call is one launch
@@ -616,11 +694,16 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             HCV_TRY(wt(mStream, mEvInput[q ^ 1]));              // (the previous block's samples are filed in front of these)
         else
         {
+            // a plain block before this one filed ITS samples from the main stream (fir_head_small_kernel): this scatter — and, through
+            // the input event it records, every transform of this block that reads the ring — goes behind that write.  (Blocks that
+            // scatter share the input stream, whose order covered it until the plain call took the scatter over.)
+            if (mPrevPlain) HCV_TRY(wt(sIn, mEvInput[q ^ 1]));
             HCV_TRY(launch_scatter_input(din, in_stride, (int) B, (int) rows_in, mHist, mHistLen, hmask, n0, sIn));
             HCV_TRY(rec(mEvInput[q], sIn));
         }
     }
     mPrevDirect = direct_in;
+    mPrevPlain = plain;
     // Two-stream pipeline of a small engine's whole-hop blocks (enqueue_stage): the NEXT block's forward transforms on a second stream
     // beside the current block's MAC, reduction and inverse.  A cross-stream hand-over is dear on this stack — the wait on the
     // transforms' event plus the end record cost the main stream about 10 us per block, an event record alone 4-8 us — so it pays only
@@ -644,7 +727,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const int hops = (int) (B / tl.M);
         want_pipe2 = tl.log2n >= 14 && !fft_split_applies(tl.log2n, hops * (int) rows_in);
     }
-    blk.pipe2 = want_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr;
+    blk.pipe2 = want_pipe2 && serial && whole_hops && direct_in && mPipeStream != nullptr && !blk.nxm;
     if (blk.pipe2)
     {
         if (!mPrevPipe2 || ctl_was_dirty)
@@ -855,7 +938,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         return true;
     }
     audio_enter();
-    if (!fence_chains() || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+    if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
     static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
     const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
     if (zero_copy)
@@ -953,7 +1036,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
             continue;
         }
         audio_enter();
-        if (!fence_chains() || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+        if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
         if (rows_in)
         {
             // (a packed block is ONE transfer; a pitched one is moved row by row by the copy engine, a few microseconds per row)
@@ -996,7 +1079,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             return true;
         }
         audio_enter();
-        if (!fence_chains() || !update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
+        if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
         if (after)
         {
             // serial blocks write `outs` from the main stream; a streamed block's writer (a stage stream's inverse, or emit behind

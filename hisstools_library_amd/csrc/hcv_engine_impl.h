@@ -104,6 +104,7 @@ struct Engine::Stage
     unsigned *coop_bar = nullptr;       // fused blocks: the two monotonic hand-over counters (one-output engines only)
     unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
+    unsigned coop_arrived_nxm[2 * kFusedShards] = {};   // ... of the n x m block's sharded counters (hcv_fused_sync.h), per shard
     unsigned long long coop_seq = 0;        // fused blocks launched so far
     bool coop_off = false;
              // a fused launch was refused by the runtime: this stage takes the separate kernels from then on
@@ -155,6 +156,8 @@ struct Engine::Block
     bool serial = false, full_matrix = false;
     bool pipe_far = false;              // ... in a run of single-hop blocks (its transforms wait for the block three or four back)
     bool pipe2 = false;                 // serial whole-hop block with its forward transforms on the pipe stream
+    bool nxm = false;                   // serial whole-hop block of a matrix with several outputs as the two meeting launches of hcv_fused_nxm.hip
+    FusedNxmPlan nxm_plan = {};
     bool direct_out = false;            // whole-hop block: the inverse writes the caller's block itself, no timeline, no emit launch
     bool direct_in = false;             // the (only) running stage's forward FFTs read the caller's block themselves: no scatter launch
     bool emitted = false;               // a plain small call: the head kernel has delivered the block itself (no emit launch)

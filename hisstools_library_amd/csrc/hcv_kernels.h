@@ -83,6 +83,20 @@ namespace hcv
                                       float *out, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived, unsigned long long *seq,
                                       hipStream_t st);
 
+    // ---- the fused block of an n x m matrix (hcv_fused_nxm.hip): one hop of the last stage of an engine with several outputs as a forward
+    //      launch on `fwd_stream` and ONE multiply-accumulate + inverse launch on `st` that meet through the stage's arrival counters, no
+    //      event between them.  Lead-slot stages of 16384 points only; P = live partitions, lead slot included.  bar / flags / arrived /
+    //      seq as above, but SHARDED counters (hcv_fused_sync.h): bar = 2 x kFusedShards x kFusedShardStride unsigned, arrived = 2 x kFusedShards
+    //      running totals; flags = kFusedNxmMacTasks + kFusedFwdTasks marks.  `plan` says whether the shape is taken at all.
+    constexpr int kFusedNxmMacTasks = 2048, kFusedShards = 32, kFusedShardStride = 32;
+    struct FusedNxmPlan { int ms, tiles, kper_old, nmac, nfwd; };
+    bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, FusedNxmPlan *pl);
+    hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride,
+                                      long long n0, long long h, int nin, int nin_alloc, int nout, float2 *X, int Rring, const float2 *H, int hparts, int P,
+                                      float2 *Y, float *out, long long out_stride, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived,
+                                      unsigned long long *seq, hipStream_t fwd_stream, hipStream_t st);
+    const float2 *fft_split_sub_table(int log2s);          // the (2 S)-th roots of the residue-split transforms' sub-transform, current device
+
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,
                                int R, const float2 *tw, const BigFFTWork &w, hipStream_t st);
     hipError_t big_rfft_ir(int log2n, const float *src, long long count, int P, float2 *dst, const float2 *tw, const BigFFTWork &w, hipStream_t st);

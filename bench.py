@@ -740,9 +740,10 @@ def bench_line(args, ctx):
         if launch_bound:
             tmax = timed(False)
             stats = conv.stage_stats()
-            if not stats[-1].get("fused_launches"):
-                # (a block of several launches: the multiply-accumulate's own time from a second pass with its HIP events on.  A block
-                # that IS one launch has no such figure — with the events on the engine takes the separate kernels)
+            if not (stats[-1].get("fused_launches") and stats[-1].get("out_tile", 1) == 1):
+                # (a block of several launches: the multiply-accumulate's own time from a second pass with its HIP events on — the n x m
+                # block's multiply-accumulate launch included.  A one-output block that IS one launch has no such figure: with the events on
+                # the engine takes the separate kernels)
                 timing_note["profiled_ms_per_step"] = round(1e3 * float(timed(True).item()) / steps, 4)
                 bare = stats
                 stats = conv.stage_stats()
@@ -990,7 +991,9 @@ def bench_line(args, ctx):
             },
             "roofline": {
                 "bound": bound,
-                "kernel": f"spectral_mac (tail stage, FFT {tail['fft_size']}, P={parts}, ksplit={tail['ksplit']}, out_tile={tail['out_tile']})",
+                "kernel": (f"mac_meet_kernel (n x m block: tail stage, FFT {tail['fft_size']}, P={parts}, {tail['ksplit']} partial spectra per output, out_tile=8)"
+                           if tail.get("fused_launches") and tail.get("out_tile") == 8 else
+                           f"spectral_mac (tail stage, FFT {tail['fft_size']}, P={parts}, ksplit={tail['ksplit']}, out_tile={tail['out_tile']})"),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -1006,7 +1009,7 @@ def bench_line(args, ctx):
             },
         }
         if bound == "launch":
-            fused = int(tail.get("fused_launches", 0))
+            fused = int(tail.get("fused_launches", 0)) if tail.get("out_tile", 1) == 1 else 0
             if fused:
                 # the whole block — forward transforms, multiply-accumulate, inverse — is ONE launch (hcv_fft_split.hip): that kernel is what
                 # ran, and its duration cannot be had from inside the run without lengthening the chain; profiles/kernel_us.json holds the

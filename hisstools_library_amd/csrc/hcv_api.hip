@@ -409,14 +409,32 @@ namespace
             if (nl.fixedStages.size() == layout.fixedStages.size()) return;            // the same stage list
             uint64_t cap = length;
             for (uint64_t s : part4Size) cap = std::max(cap, s);
-            std::unique_ptr<Engine> fresh(make_engine(nl, cap));
+            std::unique_ptr<Engine> fresh(make_engine(nl, cap));                        // (milliseconds: before any flag is raised)
             if (!fresh) return;                                                         // (the old layout stays; the error text is set)
+            fresh->set_profiling(engine->profiling());
             swapping.store(true, std::memory_order_seq_cst);
+            // A shard's engine pointer is held by the shard pool's jobs across a block, without a count in `users`: its first process
+            // call and this swap settle it between them (Dekker: each side writes its flag, then reads the other's, both seq_cst — at
+            // least one of them sees the other).  The call raises everProcessed and, finding `swapping`, waits the few microseconds
+            // of the pointer swap out (first_use: once in the object's life); this side, finding everProcessed, leaves the engine be.
+            if (pristineOnly && everProcessed.load(std::memory_order_seq_cst))
+            {
+                swapping.store(false, std::memory_order_release);
+                return;                                                                 // (`fresh` is destroyed: the shard keeps its stage list)
+            }
             while (users.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
             engine.swap(fresh);
             layout = nl;
             swapping.store(false, std::memory_order_release);
             // (`fresh` now holds the old engine: destroyed here, after whatever it still had in flight)
+        }
+
+        // a shard's first process call (see relayout_for): from here on the shard keeps its stage list
+        void first_use()
+        {
+            if (everProcessed.load(std::memory_order_relaxed)) return;
+            everProcessed.store(true, std::memory_order_seq_cst);
+            while (swapping.load(std::memory_order_seq_cst)) hcv::cpu_relax();
         }
 
         Engine *make_engine(const Layout &l, uint64_t maxLength)
@@ -1034,7 +1052,9 @@ extern "C" int hcv_convolver_reset_chan(hcv_convolver *h, uint32_t inChan, uint3
     const bool inOk = conv_in_ok(m, inChan, outChan);
     if (outChan >= m.nout) return HCV_ERR_OUT_CHAN_OUT_OF_RANGE;
     if (!inOk) return HCV_ERR_IN_CHAN_OUT_OF_RANGE;
-    m.engine->reset_pair(m.diag ? outChan : inChan, outChan);
+    // (an empty object whose engine is being replaced, Matrix::relayout_for, has nothing to restart: the hold says so)
+    EngineUse use(m);
+    if (use.ok) m.engine->reset_pair(m.diag ? outChan : inChan, outChan);
     return HCV_ERR_NONE;
 }
 
@@ -1043,7 +1063,10 @@ extern "C" void hcv_convolver_reset(hcv_convolver *h)
     if (h->sh)
         for (hcv_shard &x : h->sh->s) x.m->engine->reset_all();
     else
-        h->m->engine->reset_all();
+    {
+        EngineUse use(*h->m);
+        if (use.ok) h->m->engine->reset_all();
+    }
 }
 
 extern "C" int hcv_convolver_resize(hcv_convolver *h, uint32_t inChan, uint32_t outChan, uintptr_t length)
@@ -1144,7 +1167,7 @@ namespace
 static int sharded_process_host(hcv_convolver *h, const float *const *ins, float *const *outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
     hcv_shards &sh = *h->sh;
-    for (hcv_shard &x : sh.s) x.m->everProcessed.store(true, std::memory_order_release);      // (from here on the shards keep their stage lists)
+    for (hcv_shard &x : sh.s) x.m->first_use();         // (from here on the shards keep their stage lists)
     HostJob j;
     j.sh = &sh;
     j.ins = ins;
@@ -1400,7 +1423,7 @@ static int sharded_process_dev(hcv_convolver *h, const float *ins_dev, size_t in
         set_error("sharded Convolver: no peer access between the devices; use the host-pointer entry point (hcv_convolver_process_f32)");
         return -1;
     }
-    for (hcv_shard &x : sh.s) x.m->everProcessed.store(true, std::memory_order_release);
+    for (hcv_shard &x : sh.s) x.m->first_use();
     DevJob j;
     j.sh = &sh;
     j.ins = ins_dev;
@@ -1490,23 +1513,43 @@ extern "C" int hcv_convolver_synchronize(hcv_convolver *h)
 extern "C" int hcv_convolver_device(hcv_convolver *h) { return h->sh ? h->sh->home : h->m->engine->device(); }
 extern "C" int hcv_convolver_num_shards(hcv_convolver *h) { return h->sh ? (int) h->sh->s.size() : 1; }
 // (the statistics of a sharded object are those of its first shard)
-extern "C" void hcv_convolver_set_profiling(hcv_convolver *h, int on)
+// The diagnostic entry points take the matrix's state mutex: the engine of an empty object is only ever replaced under it
+// (Matrix::relayout_for, from set / resize), so none of them can look at an engine that is going away.  (They may wait out a
+// set() in progress — milliseconds; they are not for the audio thread.)
+namespace
 {
-    if (h->sh)
-        for (hcv_shard &x : h->sh->s) x.m->engine->set_profiling(on != 0);
-    else
-        h->m->engine->set_profiling(on != 0);
+    template <class F> void each_engine(hcv_convolver *h, F f)
+    {
+        if (h->sh)
+        {
+            for (hcv_shard &x : h->sh->s)
+            {
+                std::lock_guard<std::mutex> g(x.m->stateMutex);
+                f(*x.m->engine);
+            }
+        }
+        else
+        {
+            std::lock_guard<std::mutex> g(h->m->stateMutex);
+            f(*h->m->engine);
+        }
+    }
+    template <class F> auto first_engine(hcv_convolver *h, F f)
+    {
+        Matrix &m = h->sh ? *h->sh->s[0].m : *h->m;
+        std::lock_guard<std::mutex> g(m.stateMutex);
+        return f(*m.engine);
+    }
 }
-extern "C" int hcv_convolver_num_stages(hcv_convolver *h) { return (int) h->engine0()->num_stages(); }
+extern "C" void hcv_convolver_set_profiling(hcv_convolver *h, int on) { each_engine(h, [&](Engine &e) { e.set_profiling(on != 0); }); }
+extern "C" int hcv_convolver_num_stages(hcv_convolver *h) { return first_engine(h, [](Engine &e) { return (int) e.num_stages(); }); }
 extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
 {
-    if (h->sh)
-        for (hcv_shard &x : h->sh->s) { x.m->engine->clear_stats(); x.m->engine->clear_rt_stats(); }
-    else
+    each_engine(h, [](Engine &e)
     {
-        h->m->engine->clear_stats();
-        h->m->engine->clear_rt_stats();
-    }
+        e.clear_stats();
+        e.clear_rt_stats();
+    });
 }
 
 extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
@@ -1522,10 +1565,7 @@ extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
         out->mailbox_runs += r.mailbox_runs;
         out->ctl_turns += r.ctl_turns;
     };
-    if (h->sh)
-        for (hcv_shard &x : h->sh->s) add(*x.m->engine);
-    else
-        add(*h->m->engine);
+    each_engine(h, add);
     return 0;
 }
 
@@ -1589,7 +1629,7 @@ extern "C" int hcv_convolver_process_f32_dev_allreduce(hcv_convolver *h, const f
 extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_stats *out)
 {
     hcv::StageStats s;
-    if (stage < 0 || !out || !h->engine0()->stage_stats((size_t) stage, &s)) return -1;
+    if (stage < 0 || !out || !first_engine(h, [&](Engine &e) { return e.stage_stats((size_t) stage, &s); })) return -1;
     out->fft_size = s.fft_size;
     out->partitions = s.partitions;
     out->num_ins = s.nin;

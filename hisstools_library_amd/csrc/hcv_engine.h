@@ -144,6 +144,7 @@ namespace hcv
         void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; mMailboxRuns = 0; mCtlTurns = 0; }
 
         void set_profiling(bool on);
+        bool profiling() const { return mProfiling; }
         bool stage_stats(size_t s, StageStats *out);
         void clear_stats();
 
@@ -193,7 +194,8 @@ namespace hcv
             std::atomic<bool> done { false };
             bool ok = false;
         };
-        bool run_exclusive(std::function<bool()> fn);       // control threads
+        bool run_exclusive(std::function<bool()> fn, long long turn_budget_ns = -1);       // control threads
+        std::atomic<long long> mTurnCostNs { 0 };           // what the sections run in control turns have taken (smoothed, quick to rise)
         void audio_enter();                                 // audio thread, engine lock held: timestamp + run a posted section
         std::atomic<CtlJob *> mMailbox { nullptr };
         std::atomic<long long> mLastAudioNs { 0 };
@@ -270,7 +272,8 @@ namespace hcv
         bool mFwdPending = false;           // forward launches on the pipe stream the main stream has not been put behind yet
         bool mPrevNxm = false;              // the previous block was such a block
         uint64_t mNxmRun = 0;               // such blocks since the pipe stream was last lined up behind the main stream
-        hipEvent_t mEvNxmEnd[4] = { nullptr, nullptr, nullptr, nullptr };    // ends of every third such block (back-pressure on the pipe stream, enqueue_chunk)
+        uint32_t mNxmEvery = 3;             // ... every how many of them record their end (from the rings' depth, enqueue_chunk)
+        hipEvent_t mEvNxmEnd[4] = { nullptr, nullptr, nullptr, nullptr };    // ends of every mNxmEvery-th such block (back-pressure on the pipe stream, enqueue_chunk)
         hipEvent_t mEvFwd = nullptr;
         std::atomic<uint32_t> mLateMask { 0 };              // the last block's boundary chains still running past its emit (bit 2 * stage + parity)
         bool late_chains_done() const;

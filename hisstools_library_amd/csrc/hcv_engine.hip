@@ -304,7 +304,10 @@ bool Engine::alloc_stage(Stage &st)
     uint64_t cap = st.cfg.capacity ? st.cfg.capacity : st.M;
     st.Pcap = (uint32_t) std::max<uint64_t>(1, (cap + st.M - 1) / st.M);
     st.Tmax = mMaxBlock / st.M + 1;
-    st.R = st.Pcap + 2 * st.Tmax;      // FFT of block k+1 may write while the MAC of block k still reads
+    // (the n x m block's forward launches run ahead of the multiply-accumulates on a stream of their own, held back by an event only
+    // every few blocks: four more ring slots let that be every sixth block instead of every third — enqueue_chunk)
+    st.ring_extra = (mCfg.nout > 1 && !mCfg.diag && st.log2n == 14 && st.lead) ? 4 : 0;
+    st.R = st.Pcap + 2 * st.Tmax + st.ring_extra;      // FFT of block k+1 may write while the MAC of block k still reads
     const size_t hs_elems = pairs * st.hstride();
     const size_t x_elems = (size_t) mCfg.nin * st.R * st.M;
     // room for split-K partials: up to 64 slices for short spectra, fewer as the bin axis alone fills the chip
@@ -324,8 +327,8 @@ bool Engine::alloc_stage(Stage &st)
     const bool coop_nxm = mCfg.nout > 1 && !mCfg.diag && st.log2n == 14 && st.lead;
     if (coop_one || coop_nxm)
     {
-        const size_t marks = (size_t) (coop_nxm ? kFusedNxmMacTasks : kFusedMacTasks) + kFusedFwdTasks;
-        const size_t counters = coop_nxm ? (size_t) 2 * kFusedShards * kFusedShardStride : 2;       // (the n x m block's counters are sharded)
+        const size_t marks = (size_t) (coop_nxm ? 0 : kFusedMacTasks) + kFusedFwdTasks;
+        const size_t counters = coop_nxm ? (size_t) kFusedShards * kFusedShardStride : 2;           // (the n x m block's counter is sharded)
         HCV_TRY(hipMalloc(&st.coop_bar, sizeof(unsigned) * counters));
         HCV_TRY(hipMemset(st.coop_bar, 0, sizeof(unsigned) * counters));
         HCV_TRY(hipMalloc(&st.coop_flags, sizeof(unsigned long long) * marks));
@@ -590,7 +593,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
 
     // ---- outside the engine lock: allocate, clear, re-stride what exists
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
-    const uint32_t newR = newP + 2 * st.Tmax;
+    const uint32_t newR = newP + 2 * st.Tmax + st.ring_extra;
     float2 *nHs = nullptr, *nX = nullptr;
     const size_t hs_bytes = sizeof(float2) * pairs * (newP + st.lead) * st.M;
     const size_t x_bytes = sizeof(float2) * (size_t) mCfg.nin * newR * st.M;
@@ -894,7 +897,9 @@ bool Engine::late_chains_done() const
     return true;
 }
 
-bool Engine::run_exclusive(std::function<bool()> fn)
+// turn_budget_ns >= 0: only a control TURN is wanted, and only if one comes within that time — otherwise nothing is run and the
+// call returns false (the resets of a control thread: their flags are consumed by the audio thread's next block anyway)
+bool Engine::run_exclusive(std::function<bool()> fn, long long turn_budget_ns)
 {
     // a caller that IS the audio thread (one thread making both kinds of call: offline use, most tests) cannot be inside a
     // process call: it takes the lock directly
@@ -904,7 +909,15 @@ bool Engine::run_exclusive(std::function<bool()> fn)
         if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_acquire) < kStreamingWindowNs)
         {
             const long long period = mAudioPeriodNs.load(std::memory_order_relaxed), hold = mAudioHoldNs.load(std::memory_order_relaxed);
-            if (period > 0 && period - hold >= kTurnMinGapNs)
+            // (the gap must hold the section with room to spare — what the sections of earlier turns took, measured, and a quarter more and
+            // 0.1 ms — or the audio thread's next call would find the lock taken by a thread it may even outrank: the mailbox cannot do
+            // that to it)
+            const long long cost = mTurnCostNs.load(std::memory_order_relaxed);
+            const long long need = std::max(kTurnMinGapNs, cost + cost / 4 + 100000);
+            // (a turn refused for the estimate alone lets the estimate age: one slow section — a preempted control thread — must not
+            // keep every later one out)
+            if (period > 0 && period - hold >= kTurnMinGapNs && period - hold < need) mTurnCostNs.store(cost - cost / 8, std::memory_order_relaxed);
+            if (period > 0 && period - hold >= need)
             {
                 // a paced stream: a control TURN — behind the audio thread's next release of the lock, in the gap before its next call
                 uint64_t seq = mEnqueueSeq.load(std::memory_order_acquire);
@@ -921,11 +934,15 @@ bool Engine::run_exclusive(std::function<bool()> fn)
                         std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
                         if (lk.owns_lock())
                         {
+                            const long long ts = steady_ns();
                             bool ok = fn();
                             // the restart the section raised (set() always ends in reset()) is applied here too, at this very block
                             // boundary: what the audio thread would otherwise do at the start of its next call
                             ok = ok && apply_pending_resets();
                             mCtlTurns++;
+                            // (what a section costs, for the gap rule above: quick to rise, slow to fall)
+                            const long long cost = steady_ns() - ts, prev = mTurnCostNs.load(std::memory_order_relaxed);
+                            mTurnCostNs.store(cost > prev ? cost : prev + (cost - prev) / 8, std::memory_order_relaxed);
                             return ok;
                         }
                         seq = now_seq;                      // (the next call is in already: behind that one, then)
@@ -933,13 +950,19 @@ bool Engine::run_exclusive(std::function<bool()> fn)
                     if ((++spins & 63) == 0)
                     {
                         const long long waited = steady_ns() - t0;
+                        if (turn_budget_ns >= 0 && waited > turn_budget_ns) return false;
                         if (waited > 2 * kStreamingWindowNs) { stopped = true; break; }
                         if (waited > 3000000) std::this_thread::sleep_for(std::chrono::microseconds(30));     // (a slow stream: stop burning the core)
                     }
                     cpu_relax();
                 }
-                if (stopped) continue;                      // no call came: the stream has stopped — look at the clock again
+                if (stopped)
+                {
+                    if (turn_budget_ns >= 0) return false;
+                    continue;                               // no call came: the stream has stopped — look at the clock again
+                }
             }
+            if (turn_budget_ns >= 0) return false;          // (no turn to be had: the flags wait for the audio thread's next block)
             // a stream without gaps: hand the section to the audio thread's next call and wait for it (this is the control thread)
             CtlJob job;
             job.fn = fn;
@@ -960,6 +983,7 @@ bool Engine::run_exclusive(std::function<bool()> fn)
         }
         // no stream: the control thread takes the lock itself (a process call that starts right now polls for this short,
         // host-only section — lock_for_audio — the one case left in which the audio thread can find the lock taken by a control call)
+        if (turn_budget_ns >= 0) return false;
         std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
         if (lk.owns_lock())
         {
@@ -1037,7 +1061,9 @@ void Engine::reset_all()
 
 // A control thread resetting pairs of a PACED stream applies the restart itself, in a control turn (its fence, retiring kernels and
 // ghost spectra are device work the audio thread need not enqueue); everywhere else the flags wait for the next block, as the
-// reference's reset flags do (MonoConvolve.cpp:148-152).
+// reference's reset flags do (MonoConvolve.cpp:148-152).  The reference's reset is a flag write; this one returns within two call
+// periods (5 ms at most) whether or not it got its turn — the flags are raised either way and the audio thread's next block consumes
+// what is left of them.
 void Engine::apply_resets_in_a_turn()
 {
     if (mAudioThread.load(std::memory_order_acquire) == this_thread_hash()) return;
@@ -1047,7 +1073,7 @@ void Engine::apply_resets_in_a_turn()
     std::unique_lock<std::mutex> gs(mSetMutex, std::try_to_lock);       // (control calls are serialised; one in progress applies the flags itself)
     if (!gs.owns_lock()) return;
     DeviceGuard dg(mDevice);
-    (void) run_exclusive([]() -> bool { return true; });
+    (void) run_exclusive([]() -> bool { return true; }, std::min<long long>(2 * period, 5000000));
 }
 
 // Every loaded pair restarts: clear the rings and restart the hop clock.  The input-spectrum rings are not

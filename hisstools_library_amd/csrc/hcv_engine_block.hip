@@ -177,13 +177,30 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     if (blk.nxm && tail_head_here && T == 1)
     {
         const int Pw = (int) (st.P + st.lead);
+        EventPair *pe = nullptr;
+        if (mProfiling)
+        {
+            // (the multiply-accumulate launch's own time, as the separate kernels' statistics have it)
+            for (EventPair *c : mEvents)
+                if (!c->live) { pe = c; break; }
+            if (!pe)
+            {
+                pe = new EventPair();
+                HCV_TRY(hipEventCreate(&pe->a));
+                HCV_TRY(hipEventCreate(&pe->b));
+                mEvents.push_back(pe);
+            }
+            pe->stage = si;
+        }
         const hipError_t fe = launch_fused_block_nxm(blk.nxm_plan, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, (int) mNinAlloc,
                                                      (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, blk.dout, blk.out_stride, st.tw, st.coop_bar,
-                                                     st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS);
+                                                     st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS, /* chained */ mNxmRun > 0,
+                                                     pe ? pe->a : nullptr, pe ? pe->b : nullptr);
+        if (pe && fe == hipSuccess) pe->live = true;
         mFwdPending = true;                     // (a refused second launch leaves the first on the pipe stream all the same)
         if (fe == hipSuccess)
         {
-            if (mNxmRun % 3 == 0) HCV_TRY(hipEventRecord(mEvNxmEnd[(mNxmRun / 3) & 3], sS));        // (see the back-pressure note in enqueue_chunk)
+            if (mNxmRun % mNxmEvery == 0) HCV_TRY(hipEventRecord(mEvNxmEnd[(mNxmRun / mNxmEvery) & 3], sS));        // (see the back-pressure note in enqueue_chunk)
             mNxmRun++;
             mPrevNxm = true;
             st.launches++;
@@ -193,6 +210,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             st.last_tt = 1;
             st.last_parts = (uint32_t) Pw;
             st.fused_launches++;
+            st.steady_launches++;                   // (the unchecked, nontemporal instantiation of this path: it takes no other)
             HCV_TRY(rec(mEvInput[q], sS));
             HCV_TRY(rec(mEvEmit[q], sS));
             HCV_TRY(rec(st.done[q], sS));
@@ -634,7 +652,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // is the shape it was built for.  Forward transforms on the pipe stream, ONE multiply-accumulate + inverse launch on the main
     // stream, no event between them (HCV_COOP_NXM = 0 / HCV_COOP = 0: the separate kernels).
     blk.nxm = false;
-    if (serial && whole_hops && direct_in && blk.direct_out && !mProfiling && !mCfg.diag && mCfg.nout > 1 && blk.full_matrix && mPipeStream && B == mStages[last]->M)
+    if (serial && whole_hops && direct_in && blk.direct_out && !mCfg.diag && mCfg.nout > 1 && blk.full_matrix && mPipeStream && B == mStages[last]->M)
     {
         const Stage &tl = *mStages[last];
         const long long h = n0 / (long long) tl.M;
@@ -652,19 +670,22 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvSerial, 0));
             mNxmRun = 0;
         }
-        else if (mNxmRun >= 4)
+        // Back-pressure.  Nothing else holds the forward launches back — an asynchronous caller's whole burst of them would run at once —
+        // and the launch of block k overwrites the ring slot of hop h - R, which the multiply-accumulate of block k - (R - P - lead) - 1
+        // still reads, and the history ring's samples of hop h - hops, which the helping path of block k - hops + 1 may still read: block
+        // k - lag must be through, lag = min(R - P - lead + 1, hops - 1) (R = Pcap + 2 Tmax + 4: seven with 8192-sample blocks).  An event
+        // record costs the recording stream 4 - 7 us, so only every (lag - 1)-th block records its end on the main stream, and block k's
+        // forward launch waits for the one such end in [k - lag, k - 2]: never for the launch that needs it, nor for the one in front of
+        // that (the forward transforms of block k run beside block k - 1's inverse), and in a paced or GPU-bound stream for one long gone.
         {
-            // Back-pressure.  Nothing else holds the forward launches back — an asynchronous caller's whole burst of them would run at
-            // once — and the launch of block k overwrites the ring slot of hop h - R, which the multiply-accumulate of block
-            // k - (R - P - lead) - 1 still reads: with R = Pcap + 2 Tmax >= P + lead + 3 that block is k - 4 at the latest (the history
-            // ring, five hops and more, is covered by the same bound).  An event record costs the recording stream 4 - 5 us, so only
-            // every THIRD block records its end on the main stream, and block k's forward launch waits for the one such end in
-            // [k - 4, k - 2]: never for the launch that needs it, nor for the one in front of that (the forward transforms of block k
-            // run beside block k - 1's multiply-accumulate), and in a paced or GPU-bound stream for one long gone.
-            HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvNxmEnd[((mNxmRun - 2) / 3) & 3], 0));
+            const Stage &tl = *mStages[last];
+            const long long lag = std::min<long long>((long long) tl.R - (long long) (tl.P + tl.lead) + 1, mHistLen / (long long) tl.M - 1);
+            mNxmEvery = (uint32_t) std::max<long long>(1, std::min<long long>(8, lag - 1));
+            if (lag < 2) blk.nxm = false;           // (no room to run ahead at all: the separate kernels)
+            else if ((long long) mNxmRun >= lag) HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvNxmEnd[((mNxmRun - 2) / mNxmEvery) & 3], 0));
         }
     }
-    else if (mFwdPending)
+    if (!blk.nxm && mFwdPending)
     {
         // a block of another kind: everything behind the forward launches of the fused blocks before it (Engine::join_forward_stream)
         if (!join_forward_stream()) return false;

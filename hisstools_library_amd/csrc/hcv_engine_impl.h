@@ -63,7 +63,7 @@ struct Engine::Stage
     StageCfg cfg;
     int log2n = 0;
     uint32_t N = 0, M = 0;
-    uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0;
+    uint32_t Pcap = 0, P = 0, R = 0, Tmax = 0, ring_extra = 0;
     // Hs = [pairs][lead + Pcap][M].  lead = 1 on the last stage of a whole-hop capable layout: slot 0 of every pair then holds
     // the spectrum of IR[0 : M) — everything in front of the stage's own segment — so that in whole-hop mode the stage runs ONE
     // zero-latency uniform convolution over lead + P partitions (Y(h) = sum_p' X[h - p'] H'[p']); the stage's own partitions
@@ -104,7 +104,7 @@ struct Engine::Stage
     unsigned *coop_bar = nullptr;       // fused blocks: the two monotonic hand-over counters (one-output engines only)
     unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
-    unsigned coop_arrived_nxm[2 * kFusedShards] = {};   // ... of the n x m block's sharded counters (hcv_fused_sync.h), per shard
+    unsigned coop_arrived_nxm[kFusedShards] = {};       // ... of the n x m block's sharded counter (hcv_fused_sync.h), per shard
     unsigned long long coop_seq = 0;        // fused blocks launched so far
     bool coop_off = false;
              // a fused launch was refused by the runtime: this stage takes the separate kernels from then on

@@ -54,13 +54,18 @@ __global__ __launch_bounds__(256) void rfft_split_kernel(float *__restrict__ his
 }
 
 // One workgroup = (transform q = (t, o), sample classes n2 = 2 j, 2 j + 1).  Y: [ksplit][T][nout][M] partial sums.
-template <int LOG2N, int LOG2R>
-__global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, int nout, float *__restrict__ out,
-                                                                long long out_stride, const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin)
+// (TG = 1024 for launches that add up several slices: sixteen loads per thread cover them all at once)
+template <int LOG2N, int LOG2R, int TG = 256>
+__global__ __launch_bounds__(TG) void rifft_split_emit_kernel(const float2 *__restrict__ Y, int ksplit, long long ks_stride, int nout, float *__restrict__ out,
+                                                               long long out_stride, const float2 *__restrict__ tw, const float2 *__restrict__ tws, int pin,
+                                                               unsigned long long *started, int started_marks, unsigned long long started_seq)
 {
     constexpr int N = 1 << LOG2N, M = N / 2, R = 1 << LOG2R, NW = R / 2;
     extern __shared__ __attribute__((aligned(16))) float2 dyn[];
     int bx = blockIdx.x;
+    // ("this launch has started": marks 128 bytes apart that the n x m block's NEXT forward launch waits for — hcv_fused_nxm.hip)
+    if (started && (int) blockIdx.x < started_marks && threadIdx.x == 0)
+        __hip_atomic_store(started + (size_t) blockIdx.x * 16, started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (pin >= 0)
     {
         if ((bx & 7) != pin) return;
@@ -68,8 +73,8 @@ __global__ __launch_bounds__(256) void rifft_split_emit_kernel(const float2 *__r
     }
     const int j = bx % NW, q = bx / NW;
     const int t = q / nout, o = q % nout;
-    rifft_split_body<LOG2N, LOG2R, false>(dyn, threadIdx.x, j, Y + ((long long) t * nout + o) * M, ksplit, ks_stride,
-                                          out + (long long) o * out_stride + (long long) t * M - M, tw, tws);
+    rifft_split_body<LOG2N, LOG2R, false, TG>(dyn, threadIdx.x, j, Y + ((long long) t * nout + o) * M, ksplit, ks_stride,
+                                              out + (long long) o * out_stride + (long long) t * M - M, tw, tws);
 }
 
 // ------------------------------------------------------------------------------------------------ the fused 1 x 1 block
@@ -266,7 +271,7 @@ hipError_t launch_rfft_frames_direct_split(int log2n, float *hist, long long his
 
 template <int LOG2N, int LOG2R>
 static hipError_t launch_rifft_split_t(const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride, const float2 *tw,
-                                       hipStream_t st)
+                                       hipStream_t st, unsigned long long *started, int started_marks, unsigned long long started_seq)
 {
     const float2 *tws = fft_split_sub_table(LOG2N - LOG2R);
     if (!tws) return hipErrorInvalidValue;
@@ -280,23 +285,30 @@ static hipError_t launch_rifft_split_t(const float2 *Y, int ksplit, long long ks
         (void) hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !allowed[dev])
         {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rifft_split_emit_kernel<LOG2N, LOG2R>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rifft_split_emit_kernel<LOG2N, LOG2R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int) lds);
+            if (e == hipSuccess && LOG2N == 14)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(rifft_split_emit_kernel<LOG2N, LOG2R, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int) lds);
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) allowed[dev] = true;
         }
     }
     const int pin = xcd_pin_for((long long) NW * T * nout);
-    hipLaunchKernelGGL((rifft_split_emit_kernel<LOG2N, LOG2R>), dim3(NW * T * nout * (pin >= 0 ? 8 : 1)), dim3(256), lds, st, Y, ksplit, ks_stride, nout, out, out_stride,
-                       tw, tws, pin);
+    if (LOG2N == 14 && ksplit > 1)
+        hipLaunchKernelGGL((rifft_split_emit_kernel<LOG2N, LOG2R, 1024>), dim3(NW * T * nout * (pin >= 0 ? 8 : 1)), dim3(1024), lds, st, Y, ksplit, ks_stride, nout, out,
+                           out_stride, tw, tws, pin, started, started_marks, started_seq);
+    else
+        hipLaunchKernelGGL((rifft_split_emit_kernel<LOG2N, LOG2R>), dim3(NW * T * nout * (pin >= 0 ? 8 : 1)), dim3(256), lds, st, Y, ksplit, ks_stride, nout, out,
+                           out_stride, tw, tws, pin, started, started_marks, started_seq);
     return hipGetLastError();
 }
 
 hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
-                                   const float2 *tw, hipStream_t st)
+                                   const float2 *tw, hipStream_t st, unsigned long long *started, int started_marks, unsigned long long started_seq)
 {
     const int lr = split_radix_log2(log2n);
-#define HCV_SPLIT_I(LN, LR) if (log2n == LN && lr == LR) return launch_rifft_split_t<LN, LR>(Y, ksplit, ks_stride, T, nout, out, out_stride, tw, st)
+#define HCV_SPLIT_I(LN, LR) if (log2n == LN && lr == LR) return launch_rifft_split_t<LN, LR>(Y, ksplit, ks_stride, T, nout, out, out_stride, tw, st, started, started_marks, started_seq)
     HCV_SPLIT_I(14, 4); HCV_SPLIT_I(12, 3);
 #undef HCV_SPLIT_I
     return hipErrorInvalidValue;

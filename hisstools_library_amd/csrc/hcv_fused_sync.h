@@ -228,19 +228,18 @@ __device__ __forceinline__ void fused_roles(Bodies &b, const FusedSync &sy, int 
     b.inverse(m);
 }
 
-// ---- sharded arrival counters (the n x m blocks, hcv_fused_nxm.hip: hundreds of arrivals per counter) ----
-// An agent-scope atomic is performed at the memory side, one at a time per address: 256 workgroups counting themselves in on ONE
-// counter within a few microseconds of each other were served at ~0.12 us each — the launch's last arrival landed 31 us after its
-// last workgroup had finished, and the 576 arrivals of a forward launch took longer than its transforms.  So each of the two
-// counters is kShards counters 128 bytes apart (task t counts in on shard t mod kShards), and a waiting workgroup's first 32 lanes
-// poll one shard each; the host keeps a running total per shard.
+// ---- sharded arrival counters (the n x m block, hcv_fused_nxm.hip) ----
+// An agent-scope atomic is performed at the memory side, one at a time per line, and so is an agent-scope load: the arrivals of a
+// launch and the polls of the workgroups waiting for them queue up at the counter's line.  The n x m block's forward launch counts in on
+// kShards counters 128 bytes apart (task t on shard t mod kShards) and a waiting workgroup's first 32 lanes poll one shard each; the
+// host keeps a running total per shard.
 constexpr int kShards = 32, kShardStride = 32;          // (unsigned per shard: 128 bytes)
 struct FusedSyncSharded
 {
-    unsigned *bar;                       // [2][kShards * kShardStride]: forward transforms, multiply-accumulate
-    unsigned long long *flagF, *flagM;   // per task: sequence number of the launch that last completed it
+    unsigned *bar;                       // [kShards * kShardStride]: the forward transforms' arrivals
+    unsigned long long *flagF;           // per forward task: sequence number of the launch that last completed it
     unsigned long long seq;
-    unsigned targetA[kShards], targetB[kShards];
+    unsigned targetA[kShards];
     int spin;
 };
 __device__ __forceinline__ void grid_publish_sharded(int tid, unsigned long long *flag, unsigned long long seq, unsigned *counters, int task)
@@ -253,8 +252,8 @@ __device__ __forceinline__ void grid_publish_sharded(int tid, unsigned long long
         if (counters) __hip_atomic_fetch_add(counters + (task % kShards) * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-// bounded wait for ALL shards; `targets` = the launch's kShards totals (kernel arguments).  FRESH as grid_wait_bounded
-template <bool FRESH = false>
+// bounded wait for ALL shards; `targets` = the launch's kShards totals (kernel arguments).  `slot` has not been read since the
+// workgroup's last barrier
 __device__ __forceinline__ bool grid_wait_bounded_sharded(int tid, unsigned *counters, const unsigned *targets, int spin, int *slot)
 {
     int ok = 0;
@@ -271,71 +270,9 @@ __device__ __forceinline__ bool grid_wait_bounded_sharded(int tid, unsigned *cou
             else __builtin_amdgcn_s_sleep(20);
         }
     }
-    if constexpr (FRESH)
-    {
-        if (tid == 0) *slot = ok;
-        __syncthreads();
-        return *slot != 0;
-    }
-    else
-        return wg_broadcast(tid, ok, slot) != 0;
-}
-template <class Bodies>
-__device__ __forceinline__ void fused_slow_path_sharded(Bodies &b, const FusedSyncSharded &sy, int m, int nfwd, int nmac, int ninv, bool from_mac_wait, int *slot)
-{
-    unsigned *barM = sy.bar + kShards * kShardStride;
-    if (!from_mac_wait)
-    {
-        const int first = (int) ((long long) m * nfwd / nmac);
-        for (int k = next_undone(b.tid, sy.flagF, sy.seq, nfwd, first, 0, slot); k < nfwd; k = next_undone(b.tid, sy.flagF, sy.seq, nfwd, first, k + 1, slot))
-        {
-            int task = first + k;
-            if (task >= nfwd) task -= nfwd;
-            b.forward(task);
-            grid_publish_sharded(b.tid, sy.flagF + task, sy.seq, nullptr, task);
-        }
-        b.mac_old(m);
-        b.mac_new(m);
-        grid_publish_sharded(b.tid, sy.flagM + m, sy.seq, barM, m);
-        if (m >= ninv) return;
-        if (grid_wait_bounded_sharded(b.tid, barM, sy.targetB, sy.spin, slot))
-        {
-            b.inverse(m);
-            return;
-        }
-    }
-    const int first = m * (nmac / ninv) + 1;
-    for (int k = next_undone(b.tid, sy.flagM, sy.seq, nmac, first, 0, slot); k < nmac; k = next_undone(b.tid, sy.flagM, sy.seq, nmac, first, k + 1, slot))
-    {
-        int task = first + k;
-        if (task >= nmac) task -= nmac;
-        b.mac_old(task);
-        b.mac_new(task);
-        grid_publish_sharded(b.tid, sy.flagM + task, sy.seq, nullptr, task);
-    }
-    b.inverse(m);
-}
-// every workgroup m of the launch is a multiply-accumulate task, the first ninv go on to the inverse; the forward transforms are
-// ANOTHER launch's workgroups (they count themselves in on the first counter's shards)
-template <class Bodies, class Slow>
-__device__ __forceinline__ void fused_roles_consumer(Bodies &b, const FusedSyncSharded &sy, int m, int ninv, int *slot, const Slow &slow)
-{
-    unsigned *barM = sy.bar + kShards * kShardStride;
-    b.mac_old(m);
-    if (!grid_wait_bounded_sharded<true>(b.tid, sy.bar, sy.targetA, sy.spin, slot))
-    {
-        slow(m, false);
-        return;
-    }
-    b.mac_new(m);
-    grid_publish_sharded(b.tid, sy.flagM + m, sy.seq, barM, m);
-    if (m >= ninv) return;
-    if (!grid_wait_bounded_sharded<true>(b.tid, barM, sy.targetB, sy.spin, slot + 1))
-    {
-        slow(m, true);
-        return;
-    }
-    b.inverse(m);
+    if (tid == 0) *slot = ok;
+    __syncthreads();
+    return *slot != 0;
 }
 
 // The host's running totals of the two counters and the launch sequence number move only once the runtime has accepted the
@@ -364,27 +301,21 @@ inline FusedSync fused_sync(unsigned *bar, unsigned long long *flags, const unsi
     sy.spin = fused_spin();
     return sy;
 }
-// host side of the sharded counters: `arrived` = [2][kShards] running totals; a launch of n tasks adds n / kShards (+ 1 for the first n mod kShards shards)
+// host side of the sharded counters: `arrived` = kShards running totals; a launch of n tasks adds n / kShards (+ 1 for the first n mod kShards shards)
 inline unsigned shard_share(unsigned n, int shard) { return n / kShards + ((unsigned) shard < n % kShards ? 1u : 0u); }
-inline FusedSyncSharded fused_sync_sharded(unsigned *bar, unsigned long long *flags, const unsigned *arrived, unsigned long long seq, unsigned producers,
-                                           unsigned macs, unsigned mac_slots)
+inline FusedSyncSharded fused_sync_sharded(unsigned *bar, unsigned long long *flags, const unsigned *arrived, unsigned long long seq, unsigned producers)
 {
     FusedSyncSharded sy;
     sy.bar = bar;
-    sy.flagM = flags;
-    sy.flagF = flags + mac_slots;
+    sy.flagF = flags;
     sy.seq = seq + 1;
-    for (int c = 0; c < kShards; c++)
-    {
-        sy.targetA[c] = arrived[c] + shard_share(producers, c);
-        sy.targetB[c] = arrived[kShards + c] + shard_share(macs, c);
-    }
+    for (int c = 0; c < kShards; c++) sy.targetA[c] = arrived[c] + shard_share(producers, c);
     sy.spin = fused_spin();
     return sy;
 }
-inline void fused_arrivals_sharded(unsigned *arrived, int which, unsigned n)
+inline void fused_arrivals_sharded(unsigned *arrived, unsigned n)
 {
-    for (int c = 0; c < kShards; c++) arrived[which * kShards + c] += shard_share(n, c);
+    for (int c = 0; c < kShards; c++) arrived[c] += shard_share(n, c);
 }
 inline hipError_t fused_launched(unsigned *arrived, unsigned long long *seq, unsigned producers, unsigned macs)
 {

@@ -55,8 +55,10 @@ namespace hcv
     void fft_split_prepare(int log2n);
     hipError_t launch_rfft_frames_direct_split(int log2n, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride,
                                                long long n0, long long h_first, int T, int nin, float2 *X, int R, const float2 *tw, hipStream_t st);
+    // (started / started_marks / started_seq: the launch's first workgroups write `started_seq` to marks 128 bytes apart as they begin)
     hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long long ks_stride, int T, int nout, float *out, long long out_stride,
-                                       const float2 *tw, hipStream_t st);
+                                       const float2 *tw, hipStream_t st, unsigned long long *started = nullptr, int started_marks = 0,
+                                       unsigned long long started_seq = 0);
 
     // ---- the fused 1 x 1 block (hcv_fft_split.hip): one hop of a one-input, one-output engine in ONE launch.  h = the hop, h_mac =
     //      the hop partition 0 reads (h with a lead slot, h - 1 for a lone stage), H = the pair's P live partitions.  Hand-over state,
@@ -83,18 +85,21 @@ namespace hcv
                                       float *out, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived, unsigned long long *seq,
                                       hipStream_t st);
 
-    // ---- the fused block of an n x m matrix (hcv_fused_nxm.hip): one hop of the last stage of an engine with several outputs as a forward
-    //      launch on `fwd_stream` and ONE multiply-accumulate + inverse launch on `st` that meet through the stage's arrival counters, no
-    //      event between them.  Lead-slot stages of 16384 points only; P = live partitions, lead slot included.  bar / flags / arrived /
-    //      seq as above, but SHARDED counters (hcv_fused_sync.h): bar = 2 x kFusedShards x kFusedShardStride unsigned, arrived = 2 x kFusedShards
-    //      running totals; flags = kFusedNxmMacTasks + kFusedFwdTasks marks.  `plan` says whether the shape is taken at all.
-    constexpr int kFusedNxmMacTasks = 2048, kFusedShards = 32, kFusedShardStride = 32;
+    // ---- the block of an n x m matrix (hcv_fused_nxm.hip): one hop of the last stage of an engine with several outputs as a forward
+    //      launch on `fwd_stream` and a multiply-accumulate launch on `st` that meet through the stage's sharded arrival counters, no
+    //      event between them, then the inverse on `st`.  Lead-slot stages of 16384 points only; P = live partitions, lead slot included.
+    //      bar = kFusedShards x kFusedShardStride unsigned, flags = kFusedFwdTasks marks (both zero-initialised, touched by these launches
+    //      only); arrived = kFusedShards running totals of the host, seq = the launch sequence number; chained = the previous launch on this
+    //      state was the block right before this one (its forward launch then waits for that block's multiply-accumulate to end: a
+    //      scheduling hint); ev_begin / ev_end (optional) are recorded around the multiply-accumulate launch.  `plan` says whether the shape is taken.
+    constexpr int kFusedShards = 32, kFusedShardStride = 32;
     struct FusedNxmPlan { int ms, tiles, kper_old, nmac, nfwd; };
     bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, FusedNxmPlan *pl);
     hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride,
                                       long long n0, long long h, int nin, int nin_alloc, int nout, float2 *X, int Rring, const float2 *H, int hparts, int P,
                                       float2 *Y, float *out, long long out_stride, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived,
-                                      unsigned long long *seq, hipStream_t fwd_stream, hipStream_t st);
+                                      unsigned long long *seq, hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin = nullptr,
+                                      hipEvent_t ev_end = nullptr);
     const float2 *fft_split_sub_table(int log2s);          // the (2 S)-th roots of the residue-split transforms' sub-transform, current device
 
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,

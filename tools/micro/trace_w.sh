@@ -14,7 +14,7 @@ for r in rows:
     n=r["Kernel_Name"].replace("void ","").replace("hcv::(anonymous namespace)::","").replace("hcv::","")
     r["n"]=re.sub(r"\(.*","",n)[:46]
 rows.sort(key=lambda r:r["s"])
-ours=[i for i,r in enumerate(rows) if any(k in r["n"] for k in ("spectral_mac","fused_","rifft","rfft","fwd_publish","reduce_partials","emit"))]
+ours=[i for i,r in enumerate(rows) if any(k in r["n"] for k in ("spectral_mac","fused_","mac_meet","rifft","rfft","fwd_publish","reduce_partials","emit"))]
 last=ours[-1]
 tail=[rows[i] for i in ours[-400:]]
 agg=collections.defaultdict(lambda:[0,0.0])

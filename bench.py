@@ -312,9 +312,15 @@ def shard_plan(nin, nout, world, rank, scaling, sharding):
     """Which block of the (global) matrix this rank convolves.  Returns a dict: the global matrix size, this rank's
     [in_lo, in_hi) x [out_lo, out_hi), the grid (row groups x column groups) and its position in it."""
     if scaling == "strong":
-        go = min(world, nout)
-        while world % go:
-            go -= 1
+        if sharding == "grid":
+            # (N/2) row groups x 2 input groups: half the forward transforms per rank, one all-reduce of the row group's block per step
+            if world < 2 or world % 2 or world // 2 > nout or nin < 2:
+                raise SystemExit(f"cannot split a {nin}x{nout} matrix over {world} ranks as a (N/2) x 2 grid")
+            go = world // 2
+        else:
+            go = min(world, nout)
+            while world % go:
+                go -= 1
         gi = world // go
         if gi > nin:
             raise SystemExit(f"cannot split a {nin}x{nout} matrix over {world} ranks")
@@ -396,8 +402,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if args.sharding == "grid" and (world < 2 or world % 2 or args.scaling != "weak"):
-        raise SystemExit("--sharding grid needs weak scaling and an even number of ranks (>= 2)")
+    if args.sharding == "grid" and (world < 2 or world % 2):
+        raise SystemExit("--sharding grid needs an even number of ranks (>= 2)")
     ctx = {"world": world, "rank": rank, "local": local, "dev": dev, "backend": backend}
 
     also = args.also
@@ -430,6 +436,30 @@ def main():
             dog.start()
             for w in also:
                 digests.append(strong_leg(w, args, ctx))
+                if w == "c4" and world % 2 == 0 and not os.environ.get("BENCH_NO_C4_GRID"):
+                    # config 4 strong-scaled in BOTH layouts SURVEY 8e names: output rows over the N ranks (every rank transforms all 64 inputs,
+                    # no exchange) and the (N/2) x 2 grid (half the transforms per rank, one all-reduce of a row group's block per step); the
+                    # line quotes the faster one, and its efficiency against the whole matrix on ONE of these GPUs, measured in this run
+                    grid = strong_leg(w, args, ctx, sharding="grid")
+                    one = None
+                    if rank == 0:
+                        one = also_leg("c4", local, steps=min(args.steps, 40), warmup=min(args.warmup, 5), rt=False, timeout=240)
+                    dist.barrier()
+                    if rank == 0:
+                        rows = digests[-1]
+                        best, name = rows, f"rows {world} x 1"
+                        if grid and not grid.get("error") and (rows.get("error") or (grid.get("value") or 0) > (rows.get("value") or 0)):
+                            best, name = grid, f"grid {world // 2} x 2"
+                        strong_c4 = {"layout": name, "msamples_per_s": best.get("value"), "ms_per_step": best.get("ms_per_step"),
+                                     "rows_msamples_per_s": rows.get("value"), "grid_msamples_per_s": (grid or {}).get("value"),
+                                     "grid_error": (grid or {}).get("error"), "grid_max_rel_err": ((grid or {}).get("self_check") or {}).get("max_rel_err"),
+                                     "one_gpu_msamples_per_s": (one or {}).get("value"), "one_gpu_error": (one or {}).get("error")}
+                        if strong_c4["msamples_per_s"] and strong_c4["one_gpu_msamples_per_s"]:
+                            strong_c4["efficiency"] = round(strong_c4["msamples_per_s"] / (world * strong_c4["one_gpu_msamples_per_s"]), 4)
+                        line["config"]["c4_strong"] = strong_c4
+                        if grid:
+                            grid["workload"] = "c4grid" + str(grid.get("workload", ""))[2:]       # (its own key among the digests)
+                            digests.append(grid)
             dog.cancel()
         if rank == 0 and line is not None:
             line["config"]["also"] = digests
@@ -463,10 +493,13 @@ def flat_scalars(line):
                     "extended_step_frac": (ex.get("roofline_step") or {}).get("frac"), "extended_step_traffic": (ex.get("roofline_step") or {}).get("traffic"),
                     "extended_max_rel_err": (ex.get("self_check") or {}).get("max_rel_err"),
                     "extended_error": ex.get("error")})
+    sc4 = cfg.get("c4_strong")
     for d in cfg.get("also") or []:
         if not d:
             continue
         k = _leg_key(d)
+        if k == "c4grid_strong":
+            continue                    # (the grid layout's digest is in the side file; its scalars are above)
         if d.get("error"):
             out[k + "_error"] = str(d["error"])[:160]
             continue
@@ -496,6 +529,12 @@ def flat_scalars(line):
             out[f"{k}_rt32_p50_ms"] = sb["32"].get("p50_ms")
             out[f"{k}_rt32_p99_ms"] = sb["32"].get("p99_ms")
             out[f"{k}_rt32_over_budget"] = sb["32"].get("over_budget")
+    if isinstance(sc4, dict):
+        # config 4 strong-scaled over the run's GPUs: the faster of the two layouts, its efficiency against ONE of these GPUs running the whole matrix
+        out.update({"c4_strong_layout": sc4.get("layout"), "c4_strong_msamples_per_s": sc4.get("msamples_per_s"), "c4_strong_efficiency": sc4.get("efficiency"),
+                    "c4_strong_rows_msamples_per_s": sc4.get("rows_msamples_per_s"), "c4_strong_grid_msamples_per_s": sc4.get("grid_msamples_per_s"),
+                    "c4_strong_grid_max_rel_err": sc4.get("grid_max_rel_err"), "c4_one_gpu_msamples_per_s": sc4.get("one_gpu_msamples_per_s"),
+                    "c4_strong_grid_error": None if not sc4.get("grid_error") else str(sc4.get("grid_error"))[:120]})
     return out
 
 
@@ -521,6 +560,8 @@ def emit(line):
     keep["self_check_ok"] = sc.get("ok")
     keep["self_check_against"] = None if not sc else str(sc.get("against", "")).split(":")[0]
     keep.update({k: v for k, v in flat.items() if v is not None})         # (absent = not applicable: a launch-bound leg has no mac_frac)
+    if isinstance(cfg.get("c4_strong"), dict) and keep.get("c4_strong_layout", "").startswith("grid"):
+        keep["c4_strong_ms_per_step"] = cfg["c4_strong"].get("ms_per_step")      # (the keys above quote the faster layout)
     keep["workload"] = str(keep.get("workload", "")).replace(", audio + spectra resident in HBM", "").replace("process block", "block")
     keep["details_file"] = path
     for k in [k for k, v in keep.items() if v is None or k.endswith("_bound")]:      # (a leg's bound shows in what it carries: mac_frac or kernel)
@@ -542,13 +583,13 @@ def emit(line):
     return short
 
 
-def strong_leg(workload, args, ctx, steps=40, warmup=5):
+def strong_leg(workload, args, ctx, steps=40, warmup=5, sharding="rows"):
     """N > 1: one more workload on the ranks the headline ran on, strong-scaled, with a self-check in which EVERY rank streams its
     share (the collective of an input-split layout included) and rank 0 compares with the reference CPU leg.  Returns the digest
     (rank 0) or None."""
     import copy
     a = copy.copy(args)
-    a.workload, a.scaling, a.sharding = workload, "strong", "rows"
+    a.workload, a.scaling, a.sharding = workload, "strong", sharding
     a.steps, a.warmup = min(args.steps, steps), min(args.warmup, warmup)
     a.batched_block, a.extended_ratio, a.realtime_block, a.realtime_extra, a.tail_ratio = 0, 0, 0, "", 0
     a.no_all_cores, a.no_cpu_baseline, a.leg = True, False, True         # (the bounded CPU leg is this leg's checker; --no-self-check skips both)
@@ -1104,11 +1145,11 @@ def box_copy_rate(dev, gib=2.0, reps=5):
     return 2.0 * n * 4 / (best * 1e-3) / 1e9
 
 
-def also_leg(workload, device, steps=40, warmup=5, timeout=420):
+def also_leg(workload, device, steps=40, warmup=5, timeout=420, rt=True):
     """A further workload after the headline, in a child process (its own engine, inputs, timed region and self-check against the
     reference CPU leg): the digest of the child's bench line.  The two 64x64 shapes also run the paced real-time legs (128-, 64-
     and 32-sample calls).  Never takes the headline down."""
-    rt = ["--realtime-block", "128", "--realtime-extra", "64,32"] if workload in ("ns64", "c4") else ["--realtime-block", "0"]
+    rt = ["--realtime-block", "128", "--realtime-extra", "64,32"] if rt and workload in ("ns64", "c4") else ["--realtime-block", "0"]
     # (the north-star shape also on the extended ladder: what an unchanged caller of the reference API gets for it, hcv_api.hip's rule)
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "", "--leg",
            "--no-all-cores", "--batched-block", "0", "--extended-ratio", "8" if workload == "ns64" else "0"] + rt

@@ -652,14 +652,20 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // is the shape it was built for.  Forward transforms on the pipe stream, ONE multiply-accumulate + inverse launch on the main
     // stream, no event between them (HCV_COOP_NXM = 0 / HCV_COOP = 0: the separate kernels).
     blk.nxm = false;
-    if (serial && whole_hops && direct_in && blk.direct_out && !mCfg.diag && mCfg.nout > 1 && blk.full_matrix && mPipeStream && B == mStages[last]->M)
+    // Streamed engines (a GB and more of tail spectra) keep the separate kernels: measured with HCV_NXM_BIG = 1 on one box, 64 x 64 (512
+    // workgroups in two rounds) gains nothing with 2 s IRs (0.553 -> 0.551 ms per step) and loses 3 % with 10 s; c5's 16 x 16 / 703 partitions
+    // (one round) ran 1.82 against 1.99 ms in one pair of runs and 1.94 / 1.95 against 1.92 / 1.99 in the next — both kernels stream at
+    // 0.93 - 0.95 of what the box reads at all, and the difference is the box's own spread.
+    static const int nxm_big = std::getenv("HCV_NXM_BIG") ? std::atoi(std::getenv("HCV_NXM_BIG")) : 0;
+    if ((serial || nxm_big != 0) && whole_hops && direct_in && blk.direct_out && !mCfg.diag && mCfg.nout > 1 && blk.full_matrix && mPipeStream && B == mStages[last]->M)
     {
         const Stage &tl = *mStages[last];
         const long long h = n0 / (long long) tl.M;
         const int Pw = (int) (tl.P + tl.lead);
         const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
         if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw)
-            blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan);
+            blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan) &&
+                      (serial || nxm_big > 0);
     }
     if (blk.nxm)
     {

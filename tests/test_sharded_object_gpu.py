@@ -234,8 +234,14 @@ def test_bench_default_two_ranks_attach_strong_legs():
     for k in ("c4_strong", "c3_strong"):
         assert k + "_error" not in cfg, cfg
         assert cfg[k + "_msamples_per_s"] > 0 and cfg[k + "_ms_per_step"] > 0 and cfg[k + "_self_check_ok"] is True and cfg[k + "_max_rel_err"] <= 1e-5, cfg
+    # config 4 in BOTH strong layouts (rows over the ranks; (N/2) x 2 grid with one all-reduce per step), the faster one quoted with its
+    # efficiency against the whole matrix on one GPU measured in the same run
+    assert cfg["c4_strong_layout"] in ("rows 2 x 1", "grid 1 x 2") and cfg["c4_strong_msamples_per_s"] > 0 and cfg["c4_one_gpu_msamples_per_s"] > 0
+    assert 0 < cfg["c4_strong_efficiency"] < 1.5 and cfg["c4_strong_rows_msamples_per_s"] > 0 and cfg["c4_strong_grid_msamples_per_s"] > 0
+    assert cfg["c4_strong_grid_max_rel_err"] <= 1e-5 and "c4_strong_grid_error" not in cfg
     legs = json.load(open(details))["config"]["also"]
-    assert [a["workload"].split(":")[0] for a in legs] == ["c4", "c3"]
+    assert [a["workload"].split(":")[0] for a in legs] == ["c4", "c4grid", "c3"]
+    legs = [legs[0], legs[2]]
     for a, shape, word in zip(legs, ("(64x64 over 2 GPU)", "(8x1 over 2 GPU)"), ("output rows per rank", "all-reduce")):
         assert "error" not in a, a
         assert a["scaling"] == "strong" and a["n_gpus"] == 2 and shape in a["workload"] and word in a["sharding"]
@@ -269,8 +275,11 @@ def test_the_drivers_eight_rank_command_on_one_gpu():
     for k in ("c4_strong", "c3_strong"):
         assert k + "_error" not in cfg, cfg
         assert cfg[k + "_msamples_per_s"] > 0 and cfg[k + "_self_check_ok"] is True and cfg[k + "_max_rel_err"] <= 1e-5, cfg
+    assert cfg["c4_strong_layout"] in ("rows 8 x 1", "grid 4 x 2") and cfg["c4_strong_msamples_per_s"] > 0 and cfg["c4_strong_efficiency"] > 0
+    assert cfg["c4_strong_grid_max_rel_err"] <= 1e-5
     legs = json.load(open(details))["config"]["also"]
-    assert [a["n_gpus"] for a in legs] == [8, 8] and "(64x64 over 8 GPU)" in legs[0]["workload"] and "(8x1 over 8 GPU)" in legs[1]["workload"]
+    assert [a["n_gpus"] for a in legs] == [8, 8, 8] and "(64x64 over 8 GPU)" in legs[0]["workload"] and "(8x1 over 8 GPU)" in legs[2]["workload"]
+    assert "grid 4 x 2" in legs[1]["sharding"]
     assert wall < 1200, wall
 
 

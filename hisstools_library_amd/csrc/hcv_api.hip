@@ -1669,4 +1669,10 @@ extern "C" int hcv_set_default_device(int device)
 }
 
 extern "C" int hcv_get_default_device(void) { return gDefaultDevice; }
+extern "C" int hcv_ctl_reserve(int device, size_t bytes)
+{
+    if (device < 0 || device >= hcv_device_count()) return -1;
+    return hcv::ctl_arena_reserve(device, bytes) ? 0 : -1;
+}
+extern "C" size_t hcv_ctl_reserved(int device) { return hcv::ctl_arena_size(device); }
 extern "C" const char *hcv_last_error(void) { return tlsError.c_str(); }

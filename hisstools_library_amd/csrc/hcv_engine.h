@@ -334,6 +334,9 @@ namespace hcv
     };
 
     const float2 *twiddles(int device, int log2n, std::string *err);   // cached per (device, size)
+    // the control arena of a device (hcv_engine.hip): what it is to hold — before the device's first engine — and what it holds
+    bool ctl_arena_reserve(int device, size_t bytes);
+    size_t ctl_arena_size(int device);
     // who counts as "the audio thread" for the calling thread's process calls (hcv_engine.hip): a shard's enqueue thread takes the identity
     // of the user thread that posted the block
     void set_thread_audio_identity(size_t id);

@@ -10,6 +10,12 @@
 namespace hcv
 {
 
+namespace
+{
+    struct CtlArena;
+    CtlArena *arena_of(int device, bool create);       // the device's control arena (below, with ctl_alloc)
+}
+
 static int ilog2(uint64_t v)
 {
     int l = 0;
@@ -138,6 +144,7 @@ bool Engine::init(const EngineCfg &cfg)
         return false;
     }
     DeviceGuard dg(mDevice);
+    (void) arena_of(mDevice, true);             // (the control arena of this device: mapped now, before any stream runs)
 
     mMaxBlock = cfg.max_block;
     if (!mMaxBlock)
@@ -722,8 +729,155 @@ static hipMemPool_t ctl_pool(int device)
     return pool;
 }
 
+// The control ARENA (round 5): device memory for the control path that is mapped BEFORE any stream runs.  Obtaining new device memory
+// from the driver — a regrown stage's spectra: up to a gigabyte in the contract test — stalls every HIP call of the process while the
+// driver maps it: the audio thread's next launch stood behind that for 19 - 49 ms, whichever allocator asked (hipMalloc, or the stream-
+// ordered pool when it held nothing that large yet).  So each device gets ONE block at the creation of its first engine
+// (HCV_CTL_RESERVE_MB, default 4096; 0 = none; hcv_ctl_reserve() sizes it explicitly before the first engine) and the control path's
+// buffers — regrown spectra and rings, staging buffers, the IR upload buffer — are carved out of it: first fit over a coalescing free
+// list, host-only.  A freed block goes back behind an event recorded on the freeing engine's control stream (ctl_free is stream-ordered
+// like hipFreeAsync: the block's last users are ordered in front of that point) and is handed out again only once that event has
+// completed, so any engine of the device may take it.  Requests the arena cannot serve fall back to the stream-ordered pool (and may
+// stall: a host that must never see that reserves what it will need).
+namespace
+{
+    struct CtlArena
+    {
+        std::mutex mtx;
+        char *base = nullptr;
+        size_t size = 0;
+        std::map<size_t, size_t> free;                                  // offset -> length
+        std::map<size_t, size_t> live;                                  // offset -> length
+        struct Pending { size_t off; hipEvent_t ev; };
+        std::vector<Pending> pending;
+        bool tried = false;
+
+        void release(size_t off, size_t len)
+        {
+            auto it = free.emplace(off, len).first;
+            auto nx = std::next(it);
+            if (nx != free.end() && it->first + it->second == nx->first)
+            {
+                it->second += nx->second;
+                free.erase(nx);
+            }
+            if (it != free.begin())
+            {
+                auto pv = std::prev(it);
+                if (pv->first + pv->second == it->first)
+                {
+                    pv->second += it->second;
+                    free.erase(it);
+                }
+            }
+        }
+        // blocks whose last users are through go back to the free list (wait = block for those that are not)
+        void reap(bool wait)
+        {
+            for (size_t k = 0; k < pending.size();)
+            {
+                hipError_t e = wait ? hipEventSynchronize(pending[k].ev) : hipEventQuery(pending[k].ev);
+                if (e == hipErrorNotReady)
+                {
+                    (void) hipGetLastError();
+                    k++;
+                    continue;
+                }
+                (void) hipGetLastError();
+                (void) hipEventDestroy(pending[k].ev);
+                auto lv = live.find(pending[k].off);
+                if (lv != live.end())
+                {
+                    release(lv->first, lv->second);
+                    live.erase(lv);
+                }
+                pending[k] = pending.back();
+                pending.pop_back();
+            }
+        }
+        void *take(size_t bytes)
+        {
+            bytes = (bytes + 255) & ~size_t(255);
+            for (auto it = free.begin(); it != free.end(); ++it)
+                if (it->second >= bytes)
+                {
+                    const size_t off = it->first, len = it->second;
+                    free.erase(it);
+                    if (len > bytes) free.emplace(off + bytes, len - bytes);
+                    live.emplace(off, bytes);
+                    return base + off;
+                }
+            return nullptr;
+        }
+    };
+    std::mutex gArenaMutex;
+    std::map<int, CtlArena *> gArenas;
+    std::map<int, size_t> gArenaWanted;                                 // hcv_ctl_reserve: bytes asked for per device (before its first engine)
+
+    CtlArena *arena_of(int device, bool create)
+    {
+        std::lock_guard<std::mutex> g(gArenaMutex);
+        auto it = gArenas.find(device);
+        if (it != gArenas.end()) return it->second;
+        if (!create) return nullptr;
+        CtlArena *a = new CtlArena();
+        size_t want = size_t(4096) << 20;
+        if (const char *env = std::getenv("HCV_CTL_RESERVE_MB")) want = (size_t) std::max(0, std::atoi(env)) << 20;
+        auto w = gArenaWanted.find(device);
+        if (w != gArenaWanted.end()) want = w->second;
+        if (want)
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;      // (never more than half of what is left)
+            void *p = nullptr;
+            if (want && hipMalloc(&p, want) == hipSuccess && p)
+            {
+                a->base = static_cast<char *>(p);
+                a->size = want;
+                a->free.emplace(0, want);
+            }
+            else
+                (void) hipGetLastError();
+        }
+        gArenas[device] = a;
+        return a;
+    }
+}
+
+// (C ABI, hcv_api.hip: hcv_ctl_reserve) what the control arena of `device` is to hold; takes effect if the device has no engine yet
+bool ctl_arena_reserve(int device, size_t bytes)
+{
+    std::lock_guard<std::mutex> g(gArenaMutex);
+    if (gArenas.count(device)) return false;
+    gArenaWanted[device] = bytes;
+    return true;
+}
+
+size_t ctl_arena_size(int device)
+{
+    CtlArena *a = arena_of(device, false);
+    return a ? a->size : 0;
+}
+
 hipError_t Engine::ctl_alloc(void **p, size_t bytes)
 {
+    if (CtlArena *a = arena_of(mDevice, false))
+        if (a->base)
+        {
+            std::lock_guard<std::mutex> g(a->mtx);
+            a->reap(false);
+            void *q = a->take(bytes);
+            if (!q && !a->pending.empty())
+            {
+                a->reap(true);              // (the control thread may wait for the device: blocks freed a moment ago, not yet through)
+                q = a->take(bytes);
+            }
+            if (q)
+            {
+                *p = q;
+                return hipSuccess;
+            }
+        }
     hipMemPool_t pool = ctl_pool(mDevice);
     const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);
     if (e != hipSuccess) (void) hipGetLastError();
@@ -732,7 +886,36 @@ hipError_t Engine::ctl_alloc(void **p, size_t bytes)
 
 void Engine::ctl_free(void *p)
 {
-    if (p) (void) hipFreeAsync(p, mCtlStream);
+    if (!p) return;
+    if (CtlArena *a = arena_of(mDevice, false))
+        if (a->base && static_cast<char *>(p) >= a->base && static_cast<char *>(p) < a->base + a->size)
+        {
+            hipEvent_t ev = nullptr;
+            const bool have = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, mCtlStream) == hipSuccess;
+            if (!have)
+            {
+                // (no event to be had: wait the stream out, then the block is free at once)
+                (void) hipGetLastError();
+                (void) hipStreamSynchronize(mCtlStream);
+                if (ev) (void) hipEventDestroy(ev);
+                ev = nullptr;
+            }
+            std::lock_guard<std::mutex> g(a->mtx);
+            const size_t off = (size_t) (static_cast<char *>(p) - a->base);
+            if (ev)
+                a->pending.push_back({ off, ev });
+            else
+            {
+                auto lv = a->live.find(off);
+                if (lv != a->live.end())
+                {
+                    a->release(lv->first, lv->second);
+                    a->live.erase(lv);
+                }
+            }
+            return;
+        }
+    (void) hipFreeAsync(p, mCtlStream);
 }
 
 // staging room of a stage for one pair's spectra (grown with the stage's capacity); control thread only

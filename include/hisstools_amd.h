@@ -61,6 +61,13 @@ HCV_API int hcv_device_count(void);                       /* number of HIP devic
 HCV_API int hcv_set_default_device(int device);           /* device used by subsequently created objects */
 HCV_API int hcv_get_default_device(void);
 HCV_API const char *hcv_last_error(void);                 /* thread-local text of the last failure */
+/* The control arena (MI355X extension; the reference's MemorySwap allocates on the control thread, MemorySwap.h:187-229, and its malloc
+ * never touches the audio thread): device memory for set / resize — regrown spectra, staging buffers — is carved out of ONE block per
+ * device that is mapped at the creation of the device's first object, so that no later control call has the driver map memory under a
+ * running audio thread.  Default size HCV_CTL_RESERVE_MB (4096); hcv_ctl_reserve sizes it explicitly BEFORE the device's first object
+ * (returns -1 once one exists); hcv_ctl_reserved reports what the device holds (0: no arena yet / none). */
+HCV_API int hcv_ctl_reserve(int device, size_t bytes);
+HCV_API size_t hcv_ctl_reserved(int device);
 
 /* ---------------------------------------------------------------- HISSTools_FFT (float real transforms on the path)
  * hisstools_rfft 5-arg  HISSTools_FFT.cpp:226-230   (zero-padding unzip + real FFT, output x2, vDSP packing)

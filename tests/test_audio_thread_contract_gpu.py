@@ -49,7 +49,7 @@ def _paced(call, ncalls, period):
 
 @pytest.mark.parametrize("entry", ["host_pointers", "device_pointers", "sharded_host_pointers"])
 def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
-    _twice(lambda: _scenario(H, oracle, entry))
+    _scenario(H, oracle, entry)
 
 
 def test_process_never_waits_for_set_or_regrow_at_32_samples_per_call(H, oracle):
@@ -58,21 +58,10 @@ def test_process_never_waits_for_set_or_regrow_at_32_samples_per_call(H, oracle)
     below 3/4 of the budget.  Measured with the sections in control turns: p50 0.056, p99 0.163, max 0.316 ms, none of 4200 over
     budget (round 3, sections on the audio thread: 1 - 5 calls at 0.7 - 1.1 ms); two are tolerated — the caller is a Python thread on a
     shared host, and a regrow that has the driver map new device memory stalls every HIP call of the process."""
-    _twice(lambda: _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200, over_max=2))
+    _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200)
 
 
-def _twice(run):
-    """The scenario is a wall-clock experiment on a shared box (a Python audio thread, the driver mapping a regrown stage's memory under
-    every HIP call of the process): round 4 saw it fail once in some twenty full-suite runs and never twice on one box.  One retry; the
-    output of the first attempt stays in the log."""
-    try:
-        run()
-    except AssertionError as e:
-        print(f"first attempt: {e}")
-        run()
-
-
-def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=4):
+def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=0):
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
     nin = nout = 16
@@ -155,7 +144,7 @@ def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=4):
     # (the one call that meets the driver mapping the regrown stage's new memory — up to 1 GB here — stalls with every other HIP call of
     # the process for as long as that takes: 19 to 49 ms observed, by box; round 4 saw 41-49 ms on one box and 4 passes on the next)
     over = int((ts > budget).sum())
-    assert over <= over_max and ts.max() < 100.0, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
+    assert over <= over_max and ts.max() < budget, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
     assert np.percentile(ts, 99) < 0.75 * budget, f"p99 {np.percentile(ts, 99):.3f} ms"
     assert np.isfinite(ys).all()
     y_ref = ref.run(xs, len(steady), 2048)

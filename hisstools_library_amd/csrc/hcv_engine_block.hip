@@ -193,10 +193,18 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             pe->stage = si;
         }
         const hipError_t fe = launch_fused_block_nxm(blk.nxm_plan, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, (int) mNinAlloc,
-                                                     (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, blk.dout, blk.out_stride, st.tw, st.coop_bar,
-                                                     st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS, /* chained */ mNxmRun > 0,
+                                                     (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, blk.direct_out ? blk.dout : nullptr, blk.out_stride,
+                                                     st.tw, st.coop_bar, st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS, /* chained */ mNxmRun > 0,
                                                      pe ? pe->a : nullptr, pe ? pe->b : nullptr);
         if (pe && fe == hipSuccess) pe->live = true;
+        if (fe == hipSuccess && !blk.direct_out)
+        {
+            // (an extended ladder's pivot stage: the hop goes into the stage's timeline, emitted with NO latency — hop h at h M — beside the
+            // rungs' timelines; the inverse adds the partial spectra up as it loads them)
+            HCV_TRY(wt(sS, mEvEmit[q]));        // emit(k-2) has cleared the timeline span reused now
+            HCV_TRY(launch_rifft_overlap_add(st.log2n, st.Y, blk.nxm_plan.ms, (long long) nout_act * st.M, h_first - 1, 1, (int) nout_act, st.timeline, st.tl_len,
+                                             st.tl_len - 1, st.tw, &st.big, sS));
+        }
         mFwdPending = true;                     // (a refused second launch leaves the first on the pipe stream all the same)
         if (fe == hipSuccess)
         {
@@ -212,7 +220,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             st.fused_launches++;
             st.steady_launches++;                   // (the unchecked, nontemporal instantiation of this path: it takes no other)
             HCV_TRY(rec(mEvInput[q], sS));
-            HCV_TRY(rec(mEvEmit[q], sS));
+            if (blk.direct_out) HCV_TRY(rec(mEvEmit[q], sS));      // (the inverse delivered the block itself; otherwise the emit launch records it)
             HCV_TRY(rec(st.done[q], sS));
             HCV_TRY(wt(mStream, st.done[q]));
             st.pre_hop = -1;
@@ -657,7 +665,14 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // (one round) ran 1.82 against 1.99 ms in one pair of runs and 1.94 / 1.95 against 1.92 / 1.99 in the next — both kernels stream at
     // 0.93 - 0.95 of what the box reads at all, and the difference is the box's own spread.
     static const int nxm_big = std::getenv("HCV_NXM_BIG") ? std::atoi(std::getenv("HCV_NXM_BIG")) : 0;
-    if ((serial || nxm_big != 0) && whole_hops && direct_in && blk.direct_out && !mCfg.diag && mCfg.nout > 1 && blk.full_matrix && mPipeStream && B == mStages[last]->M)
+    // The pivot stage of an extended ladder CAN take it (HCV_NXM_LADDER = 1; its hop then goes into the stage's timeline, which emit adds to
+    // the rungs'), and its multiply-accumulate falls from 49 + 13 us (with the reduction) to 25 - 39 — but the ladder's step does not: c5
+    // on the ladder 0.147 / 0.153 ms against 0.137 / 0.140 as it is, same box, alternating.  The step is the rungs' slices and the pivot's
+    // launches sharing the memory system (601 MB per step: 92 us at what the box reads at all), not the pivot's chain; one workgroup per
+    // CU with most of its registers crowds the slices' workgroups out.  Off by default.
+    static const bool nxm_ladder = std::getenv("HCV_NXM_LADDER") && std::atoi(std::getenv("HCV_NXM_LADDER")) != 0;
+    if ((serial || nxm_big != 0 || (rungs && nxm_ladder)) && whole_hops && direct_in && (blk.direct_out || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
+        blk.full_matrix && mPipeStream && B == mStages[last]->M)
     {
         const Stage &tl = *mStages[last];
         const long long h = n0 / (long long) tl.M;
@@ -665,7 +680,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
         if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw)
             blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan) &&
-                      (serial || nxm_big > 0);
+                      (serial || nxm_big > 0 || rungs);
     }
     if (blk.nxm)
     {

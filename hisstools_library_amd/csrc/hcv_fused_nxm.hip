@@ -353,7 +353,7 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     a.sy = fused_sync_sharded(bar, flags, arrived, *seq, (unsigned) pl.nfwd);
     a.hint = flags + kNxmHintBase;
     static const bool hint_on = !(std::getenv("HCV_NXM_HINT") && std::atoi(std::getenv("HCV_NXM_HINT")) == 0);
-    a.hint_wait = (chained && hint_on) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
+    a.hint_wait = (chained && hint_on && out) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
     hipLaunchKernelGGL((fwd_publish_kernel<LOG2N>), dim3(pl.nfwd), dim3(64 * kNxmWaves), lds_fwd, fwd_stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;                          // (nothing ran: the counters stand where they stood)
@@ -366,6 +366,7 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, st)) != hipSuccess) return e;
+    if (!out) return hipSuccess;                             // (the caller adds the hop to the stage's timeline itself: the extended ladder's pivot stage)
     return launch_rifft_emit_split(LOG2N, Y, pl.ms, (long long) nout * M, 1, nout, out, out_stride, tw, st, a.hint, std::min(kNxmHints, nout * 8), a.sy.seq);
 }
 

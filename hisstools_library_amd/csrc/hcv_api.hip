@@ -585,7 +585,7 @@ namespace
     }
 }
 
-struct hcv_mono { std::unique_ptr<Matrix> m; };
+struct hcv_mono { std::unique_ptr<Matrix> m; bool quirks = false; };
 struct hcv_ntomono { std::unique_ptr<Matrix> m; };
 // One block of a sharded Convolver: its own Matrix (engine) on its own device, owning outputs [out_lo, out_hi) of inputs
 // [in_lo, in_hi) of the caller's matrix
@@ -661,6 +661,7 @@ static hcv_mono *mono_create(uintptr_t maxLength, int zeroLatency, uint32_t A, u
     }
     hcv_mono *h = new hcv_mono();
     h->m.reset(m);
+    h->quirks = std::getenv("HCV_REFERENCE_QUIRKS") && std::atoi(std::getenv("HCV_REFERENCE_QUIRKS")) != 0;
     return h;
 }
 
@@ -698,6 +699,12 @@ extern "C" int hcv_mono_process(hcv_mono *h, const float *in, float *temp, float
     if (!use.ok) return 0;                                  // (the engine of an empty object is being replaced: nothing loaded, out untouched)
     const float *ins[1] = { in };
     float *outs[1] = { out };
+    // HCV_REFERENCE_QUIRKS=1 (read when the object is made): MonoConvolve.cpp:195-197 as the reference has it.  In a zero-latency layout of
+    // fewer than four FFT sizes mPart1 is null, so the first FFT stage is processed with `accumulate || mPart1` = the caller's flag: called
+    // without accumulate it WRITES `out` and the time-domain head's output, written a line before, is lost — provided that stage holds
+    // partitions (a PartitionedConvolve without an IR returns false and touches nothing).  The default sums every stage.
+    if (h->quirks)
+        h->m->engine->set_drop_head(!accumulate && h->m->layout.zeroLatency && h->m->layout.sizes.size() < 4 && h->m->engine->stage_partitions(0, 0, 0) > 0);
     if (!h->m->engine->process(ins, outs, 1, 1, numSamples, accumulate != 0))
     {
         set_error(h->m->engine->last_error());

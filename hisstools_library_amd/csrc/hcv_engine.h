@@ -144,6 +144,9 @@ namespace hcv
         void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; mMailboxRuns = 0; mCtlTurns = 0; }
 
         void set_profiling(bool on);
+        // HCV_REFERENCE_QUIRKS (hcv_api.hip): the next blocks leave the time-domain head out — what MonoConvolve::process does to it in a
+        // zero-latency layout of fewer than four FFT sizes (MonoConvolve.cpp:195-197: the stage behind the missing one overwrites it)
+        void set_drop_head(bool on) { mDropHead.store(on, std::memory_order_relaxed); }
         bool profiling() const { return mProfiling; }
         bool stage_stats(size_t s, StageStats *out);
         void clear_stats();
@@ -329,6 +332,7 @@ namespace hcv
         uint32_t mLastNin = 0, mLastNout = 0;   // active matrix of the previous block
         long long mN = 0;                   // samples since the last global reset
         bool mProfiling = false;
+        std::atomic<bool> mDropHead { false };
         bool mOneStream = false;            // every kernel on mStream (small engines: dependency hops cost more than overlap gains)
         std::vector<EventPair *> mEvents;
     };

@@ -566,7 +566,8 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     const int q = (int) (mBlockCount & 1);
     if (!fence_chains(/* keep_forward */ true)) return false;       // the main stream behind the boundary chains the previous block left running
 
-    const bool td_any = mCfg.has_td && mTdLpad > 0;
+    const bool drop_head = mDropHead.load(std::memory_order_relaxed);     // (reference-quirk mode: the head's output is lost, see hcv_engine.h)
+    const bool td_any = mCfg.has_td && mTdLpad > 0 && !drop_head;
     const bool td_check = mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid);
     // Whole-hop mode: the block is made of whole, aligned hops of the last stage.  Every output sample of such a block only
     // needs inputs that the last stage's own frames hold, so IR[0 : its hop) is served by ONE extra zero-latency partition
@@ -576,7 +577,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // the one hop whose result is due in the new block (see the stage loop).
     const size_t last = mStages.empty() ? 0 : mPivot;          // the stage whole-hop blocks run on
     const bool rungs = !mStages.empty() && mPivot + 1 < mStages.size();      // the extended ladder's far-tail stages run beside it
-    const bool whole_hops = mTailHead && !td_check && (n0 % mStages[last]->M) == 0 && (B % mStages[last]->M) == 0 &&
+    const bool whole_hops = mTailHead && !drop_head && !td_check && (n0 % mStages[last]->M) == 0 && (B % mStages[last]->M) == 0 &&
                             !(mStages[last]->max_hv > n0 / mStages[last]->M);
     const bool entering = whole_hops && !mTailHeadPrev, leaving = !whole_hops && mTailHeadPrev;
     mTailHeadPrev = whole_hops;

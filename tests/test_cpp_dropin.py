@@ -67,3 +67,43 @@ def test_audiofile_loads_an_ir_into_the_convolver(tmp_path):
     build(AUDIO_SRC, AUDIO_EXE)
     out = subprocess.run([AUDIO_EXE, str(tmp_path / "smoke.aifc")], capture_output=True, text=True)
     assert out.returncode == 0 and "convolver load ok" in out.stdout, out.stdout + out.stderr
+
+
+GOLDEN_SRC = os.path.join(ROOT, "tests", "cpp", "dropin_golden.cpp")
+GOLDEN_EXE = os.path.join(OUT_DIR, "dropin_golden")
+
+
+def _export_golden(path):
+    """golden_v1.npz (made by the unmodified reference) as a flat binary a C++ programme reads without a zip / npy parser"""
+    import struct
+
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(g.files)))
+        for k in g.files:
+            a = np.ascontiguousarray(g[k], dtype=np.float32)
+            name = k.encode()
+            f.write(struct.pack("<I", len(name)) + name + struct.pack("<I", a.ndim) + struct.pack(f"<{a.ndim}I", *a.shape))
+            f.write(a.tobytes())
+
+
+def test_golden_programme_compiles_and_links(tmp_path):
+    build(GOLDEN_SRC, GOLDEN_EXE)
+    path = str(tmp_path / "golden_v1.bin")
+    _export_golden(path)
+    assert subprocess.call([GOLDEN_EXE, path]) in (0, 2)
+
+
+@pytest.mark.gpu
+def test_reference_golden_vectors_through_the_cpp_headers(tmp_path):
+    """Every end-to-end golden vector of the reference (PartitionedConvolve x 3, TimeDomainConvolve x 4, MonoConvolve x 4 + moved
+    elements of a std::vector, NToMonoConvolve 3 -> 1, Convolver 2 x 3 float and double, 3-channel parallel) through
+    include/hisstools_amd/*.h, as a C++ caller of the reference would drive its classes: 2e-6 / 1e-5 of the peak."""
+    build(GOLDEN_SRC, GOLDEN_EXE)
+    path = str(tmp_path / "golden_v1.bin")
+    _export_golden(path)
+    out = subprocess.run([GOLDEN_EXE, path], capture_output=True, text=True)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all golden vectors within tolerance" in out.stdout and out.stdout.count(" ok") >= 22

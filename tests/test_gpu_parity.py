@@ -240,6 +240,35 @@ def test_zero_latency_with_fewer_than_four_sizes_keeps_the_head(H, oracle):
     assert rel_err(y_ref + head_only, truth_conv(x, h)) < TOL     # the reference is missing exactly the head
 
 
+def test_reference_quirks_mode_loses_the_head_as_the_reference_does(H, oracle, monkeypatch):
+    """HCV_REFERENCE_QUIRKS=1 (opt-in, read when the object is made): the same layout now gives the REFERENCE's stream — the head's output
+    overwritten by the first FFT stage (MonoConvolve.cpp:195-197), as the oracle restates it bit for bit — within the float32 tolerance;
+    an IR that ends inside the head keeps it (that stage holds no partitions and touches nothing), and accumulate = true sums everything."""
+    monkeypatch.setenv("HCV_REFERENCE_QUIRKS", "1")
+    for sizes in ((256, 4096, 16384), (1024, 16384, 0), (4096, 0, 0)):
+        h, x = oracle.synth_ir(2, 2, 30000), oracle.synth_audio(4, 50000)
+        gpu = H.MonoConvolve(30000, zeroLatency=True, A=sizes[0], B=sizes[1], C_=sizes[2])
+        ref = oracle.MonoConvolve(30000, zeroLatency=True, A=sizes[0], B=sizes[1], C_=sizes[2])
+        ref.setResetOffset(0)
+        assert gpu.set(h, False) == 0 and ref.set(h, False) == 0
+        y, y_ref = gpu.run(x, 2048), ref.run(x, 2048)
+        assert rel_err(y, y_ref) < TOL, (sizes, rel_err(y, y_ref))
+        assert rel_err(y, truth_conv(x, h)) > 1e-3                  # (and it really is missing the head)
+    # an IR shorter than the head: no FFT stage is loaded, nothing overwrites the head
+    h, x = oracle.synth_ir(1, 1, 100), oracle.synth_audio(2, 20000)
+    gpu = H.MonoConvolve(30000, zeroLatency=True, A=256, B=4096, C_=16384)
+    ref = oracle.MonoConvolve(30000, zeroLatency=True, A=256, B=4096, C_=16384)
+    ref.setResetOffset(0)
+    assert gpu.set(h, False) == 0 and ref.set(h, False) == 0
+    assert rel_err(gpu.run(x, 1024), ref.run(x, 1024)) < TOL
+    assert rel_err(gpu.run(x, 1024), truth_conv(x, h)[: x.size]) < 1.0
+    # four sizes: mPart1 exists, nothing is lost, quirk mode or not
+    h, x = oracle.synth_ir(2, 2, 30000), oracle.synth_audio(4, 50000)
+    gpu = H.MonoConvolve(30000, zeroLatency=True, A=256, B=1024, C_=4096, D=16384)
+    assert gpu.set(h, False) == 0
+    assert rel_err(gpu.run(x, 2048), truth_conv(x, h)) < TOL
+
+
 def test_mono_impulse_is_exact(H):
     # delta in -> the IR comes out sample-exact in the zero-latency chain (SURVEY §9.13)
     h = np.zeros(40000, np.float32)

@@ -170,6 +170,54 @@ def test_dense_irs_16x16_steady_state_vs_oracle(H, oracle, torch):
     assert tail["mac_steady_launches"] >= hops - 41, tail
 
 
+def test_config5_depth_dense_irs_vs_oracle(H, oracle, torch):
+    """Dense-IR parity with the reference ARITHMETIC at config 5's own depth (what bench.py's self-check does after its timed region, here
+    in the suite): 16x16, L = 5 760 000 (P = 703 tail partitions), dense decaying-noise IRs on EVERY pair, inputs 0..3 carrying audio and
+    the others silent, streamed in 8192-sample hops PAST the whole IR (712 hops: ramp-up with partition bounds, then the unchecked
+    split-K instantiation with all 703 partitions live).  Rows 0, 7, 8, 15 — first and last row of both output tiles — against
+    oracle.Convolver(4, 4) holding the same sixteen IRs (PartitionedConvolve.cpp:321-348 scheduling, :387-426 the multiply-accumulate)."""
+    dev = torch.device("cuda:0")
+    nin = nout = 16
+    L, B, hops = 5760000, 8192, 712
+    S = hops * B
+    rows, cols = [0, 7, 8, 15], [0, 1, 2, 3]
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
+    ref = oracle.Convolver(len(cols), len(rows), 0)
+    ref.setResetOffset(0)
+    spare = []
+    for o in rows:
+        for i in cols:
+            h = oracle.synth_ir(i, o, L)
+            assert c.set(i, o, h, True) == 0 and ref.set(i, rows.index(o), h, True) == 0
+            if len(spare) < 4:
+                spare.append(torch.from_numpy(h).to(dev))
+    # (every other pair dense too — their spectra are part of every launch's traffic: four of the IRs above, from HBM)
+    k = 0
+    for o in range(nout):
+        for i in range(nin):
+            if not (o in rows and i in cols):
+                torch.cuda.synchronize()
+                assert c.set_dev(i, o, spare[k % len(spare)].data_ptr(), L, True) == 0
+                k += 1
+    xs = np.zeros((nin, S), np.float32)
+    for i in cols:
+        xs[i] = oracle.synth_audio(i, S)
+    xd, yd = torch.from_numpy(xs).to(dev), torch.zeros((nout, S), device=dev)
+    torch.cuda.synchronize()
+    c.clear_stats()
+    for pos in range(0, S, B):
+        c.process_dev(xd.data_ptr() + 4 * pos, S, yd.data_ptr() + 4 * pos, S, nin, nout, B)
+    c.synchronize()
+    y = yd[rows].cpu().numpy()
+    y_ref, _ = ref.stream_timed(xs[cols], len(rows), 2048)
+    for k, o in enumerate(rows):
+        assert rel_err(y[k], y_ref[k]) < TOL_SUM, (o, rel_err(y[k], y_ref[k]))
+        assert rel_err(y[k][-8 * B:], y_ref[k][-8 * B:]) < TOL_SUM, (o, rel_err(y[k][-8 * B:], y_ref[k][-8 * B:]))
+    tail = c.stage_stats()[-1]
+    assert tail["fft_size"] == 16384 and tail["partitions"] == 703 and tail["out_tile"] == 8 and tail["ksplit"] > 1 and tail["hop_tile"] == 1
+    assert tail["mac_launches"] == hops and tail["mac_steady_launches"] >= hops - 704, tail
+
+
 def test_batched_calls_steady_state_vs_hop_calls(H, torch):
     """Offline-style calls (65536 samples = 8 tail hops per call: the hop-tiled instantiations) must give the stream the
     hop-sized calls give, in the steady state too — 16x16 with a 40-partition tail (>= 32: hop tile 8), dense random IRs."""

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhisstools_amd.so")
+# (HCV_LIBRARY_PATH: a diagnostic build of the same library — the sanitizer builds of tools/sanitize/run.sh — in place of the product)
+LIB_PATH = os.environ.get("HCV_LIBRARY_PATH") or os.path.join(_HERE, "libhisstools_amd.so")
 
 f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)

@@ -24,6 +24,7 @@
 #include "hcv_engine.h"
 #include "hcv_fft_split_device.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <string>
 
@@ -280,10 +281,10 @@ static hipError_t launch_rifft_split_t(const float2 *Y, int ksplit, long long ks
     if (lds > 48 * 1024)
     {
         // (more than the default dynamic LDS must be asked for, once per device and instantiation)
-        static bool allowed[64] = {};
+        static std::atomic<bool> allowed[64];                 // (several engines' host threads come through here: found by ThreadSanitizer)
         int dev = 0;
         (void) hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !allowed[dev])
+        if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire))
         {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rifft_split_emit_kernel<LOG2N, LOG2R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int) lds);
@@ -291,7 +292,7 @@ static hipError_t launch_rifft_split_t(const float2 *Y, int ksplit, long long ks
                 e = hipFuncSetAttribute(reinterpret_cast<const void *>(rifft_split_emit_kernel<LOG2N, LOG2R, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int) lds);
             if (e != hipSuccess) return e;
-            if (dev >= 0 && dev < 64) allowed[dev] = true;
+            if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
         }
     }
     const int pin = xcd_pin_for((long long) NW * T * nout);
@@ -644,15 +645,15 @@ hipError_t launch_fused_block_nx1(int log2n, float *hist, long long hist_stride,
     const float2 *tws = fft_split_sub_table(LOG2N - LOG2R);
     if (!tws) return hipErrorInvalidValue;
     constexpr size_t lds = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R);
-    static bool allowed[64] = {};
+    static std::atomic<bool> allowed[64];                 // (several engines' host threads come through here: found by ThreadSanitizer)
     int dev = 0;
     (void) hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !allowed[dev])
+    if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire))
     {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_block_nx1_kernel<LOG2N, LOG2R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int) lds);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) allowed[dev] = true;
+        if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
     }
     FusedNx1Params a;
     a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws;
@@ -676,15 +677,15 @@ hipError_t launch_fused_block_1x1(int log2n, float *hist, long long hist_mask, c
     const float2 *tws = fft_split_sub_table(LOG2N - LOG2R);
     if (!tws) return hipErrorInvalidValue;
     constexpr size_t lds = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R);
-    static bool allowed[64] = {};
+    static std::atomic<bool> allowed[64];                 // (several engines' host threads come through here: found by ThreadSanitizer)
     int dev = 0;
     (void) hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !allowed[dev])
+    if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire))
     {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_block_1x1_kernel<LOG2N, LOG2R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int) lds);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) allowed[dev] = true;
+        if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
     }
     FusedBlockParams a;
     a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws;
@@ -714,15 +715,15 @@ hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, 
     if (!tws) return hipErrorInvalidValue;
     constexpr size_t lds_fft = sizeof(float2) * (size_t) (M + lds_padded(S) + S + R), lds_red = sizeof(float4) * 16 * TMAX * 64;
     constexpr size_t lds = lds_fft > lds_red ? lds_fft : lds_red;
-    static bool allowed[64] = {};
+    static std::atomic<bool> allowed[64];                 // (several engines' host threads come through here: found by ThreadSanitizer)
     int dev = 0;
     (void) hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !allowed[dev])
+    if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire))
     {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_block_hops_kernel<LOG2N, LOG2R, TMAX>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) allowed[dev] = true;
+        if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
     }
     FusedHopsParams a;
     a.hist = hist; a.in = in; a.out = out; a.X = X; a.H = H; a.Y = Y; a.tw = tw; a.tws = tws;

@@ -44,6 +44,7 @@
 #include "hcv_fft_frames_device.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace hcv
@@ -333,15 +334,15 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     constexpr size_t lds_fwd = sizeof(float2) * (size_t) lds_padded(M);                  // the whole-frame transform (the helping path runs it too)
     constexpr size_t lds_red = sizeof(float4) * (size_t) kNxmWaves * kNxmOT * 64;
     constexpr size_t lds = lds_fwd > lds_red ? lds_fwd : lds_red;
-    static bool allowed[64] = {};
+    static std::atomic<bool> allowed[64];                 // (several engines' host threads come through here: found by ThreadSanitizer)
     int dev = 0;
     (void) hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !allowed[dev])
+    if (dev < 0 || dev >= 64 || !allowed[dev].load(std::memory_order_acquire))
     {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mac_meet_kernel<LOG2N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(fwd_publish_kernel<LOG2N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_fwd);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) allowed[dev] = true;
+        if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
     }
     FusedNxmParams a;
     a.hist = hist; a.in = in; a.X = X; a.H = H; a.Y = Y; a.tw = tw;

@@ -12,11 +12,11 @@ given up.
 
 A control thread loops set(resize=True) with GROWING 10 s-class IRs on a 16x16 zero-latency engine — every growth re-strides the
 tail stage's whole spectrum store — while the audio thread issues paced 128-sample calls.  Asserted: the calls stay inside the
-2.67 ms real-time budget of 128 samples at 48 kHz (p99 below half of it; at most two of 1400 may exceed it — the caller is a
-Python thread on a shared host); no block was given up; the outputs whose pairs are NOT being replaced equal
+2.67 ms real-time budget of 128 samples at 48 kHz — every one of the 1400, p99 below three quarters of it; no block was given up; the outputs whose pairs are NOT being replaced equal
 the CPU oracle's sample for sample (tolerance 1e-5) right through the swaps and regrows; the replaced pairs stay finite; and
 after the control thread has finished, a known IR set + reset gives the oracle's stream again.
 """
+import os
 import threading
 import time
 
@@ -56,9 +56,23 @@ def test_process_never_waits_for_set_or_regrow_at_32_samples_per_call(H, oracle)
     """The same contract at the smallest block size hosts use: 32-sample calls (0.67 ms budget), 4200 of them (2.8 s of audio), beside
     ~700 set(resize) calls.  The same criteria (no block given up, the sections in control turns); of the wall-clock ones p99 stays
     below 3/4 of the budget.  Measured with the sections in control turns: p50 0.056, p99 0.163, max 0.316 ms, none of 4200 over
-    budget (round 3, sections on the audio thread: 1 - 5 calls at 0.7 - 1.1 ms); two are tolerated — the caller is a Python thread on a
-    shared host, and a regrow that has the driver map new device memory stalls every HIP call of the process."""
+    budget (round 3, sections on the audio thread: 1 - 5 calls at 0.7 - 1.1 ms); round 5, regrown buffers out of the control arena: max
+    0.32 - 0.39 ms, none over budget, none tolerated."""
     _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200)
+
+
+def _timing_criteria(rt, sets, ts, budget, over_max):
+    assert rt["blocks_muted"] == 0 and rt["lock_contended"] <= 2 and rt["lock_wait_ns_max"] < 1_000_000, rt
+    assert rt["ctl_turns"] + rt["mailbox_runs"] >= sets["n"] - 1 and rt["mailbox_runs"] <= max(2, sets["n"] // 20), (rt, sets["n"])
+    # The wall-clock side is measured from a Python thread on a shared host, where a preempted caller shows up as one slow call:
+    # all but a handful of the 1400 calls inside the budget, none that looks like a stall behind an upload or a regrow (tens to
+    # hundreds of milliseconds in round 1), p99 well inside it
+    # (round 4 tolerated up to 100 ms here and retried the scenario: the one call that met the driver mapping a regrown stage's new memory
+    # stalled with every other HIP call of the process, 19 to 49 ms by box.  Round 5: the regrown buffers come out of the control arena,
+    # mapped before any stream runs — hcv_engine.hip — and EVERY call stays inside its budget: no retry, no tolerated outlier)
+    over = int((ts > budget).sum())
+    assert over <= over_max and ts.max() < budget, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
+    assert np.percentile(ts, 99) < 0.75 * budget, f"p99 {np.percentile(ts, 99):.3f} ms"
 
 
 def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=0):
@@ -136,16 +150,12 @@ def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=0):
     # the stream never stopped and is paced: every swap section ran in a control turn between two calls (at least one per set();
     # a regrow's pointer swap is one more), next to none on the audio thread; no block was given up, and the lock was found taken
     # at most twice, briefly (a section that overran the gap)
-    assert rt["blocks_muted"] == 0 and rt["lock_contended"] <= 2 and rt["lock_wait_ns_max"] < 1_000_000, rt
-    assert rt["ctl_turns"] + rt["mailbox_runs"] >= sets["n"] - 1 and rt["mailbox_runs"] <= max(2, sets["n"] // 20), (rt, sets["n"])
-    # The wall-clock side is measured from a Python thread on a shared host, where a preempted caller shows up as one slow call:
-    # all but a handful of the 1400 calls inside the budget, none that looks like a stall behind an upload or a regrow (tens to
-    # hundreds of milliseconds in round 1), p99 well inside it
-    # (the one call that meets the driver mapping the regrown stage's new memory — up to 1 GB here — stalls with every other HIP call of
-    # the process for as long as that takes: 19 to 49 ms observed, by box; round 4 saw 41-49 ms on one box and 4 passes on the next)
-    over = int((ts > budget).sum())
-    assert over <= over_max and ts.max() < budget, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
-    assert np.percentile(ts, 99) < 0.75 * budget, f"p99 {np.percentile(ts, 99):.3f} ms"
+    if os.environ.get("SAN_RUN"):
+        # (tools/sanitize/run.sh: an instrumented library is several times slower — sections overrun their gaps, calls their budgets; the
+        # wall-clock criteria are not that run's subject, the engine-exact ones below the timing block are)
+        assert rt["blocks_muted"] == 0 and not sets["errors"]
+    else:
+        _timing_criteria(rt, sets, ts, budget, over_max)
     assert np.isfinite(ys).all()
     y_ref = ref.run(xs, len(steady), 2048)
     for k, o in enumerate(steady):

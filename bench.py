@@ -569,7 +569,7 @@ def emit(line):
             keep.pop(k)
     short["config"] = keep
     rf = short.get("roofline") or {}
-    short["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "avg_launch_ms",
+    short["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_commit", "alg_bytes_per_launch", "avg_launch_ms",
                                                  "launches", "steady_launches", "box_read_GBps", "achieved_over_box_read", "whole_step_frac",
                                                  "survey_8d_ceiling_msamples_per_s", "kernel_share_of_step", "avg_launch_source") if k in rf}
     if rf.get("traffic") is not None:
@@ -619,7 +619,7 @@ def digest_of(d):
         "workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"], "n_gpus": d["n_gpus"], "steps": d["steps"], "warmup": d["warmup"],
         "ms_per_step": d["ms_per_step"], "realtime_factor": d["config"].get("realtime_factor"),
         "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms",
-                                            "launches", "steady_launches", "traffic", "traffic_source", "profiled_ms_per_step", "box_read_GBps",
+                                            "launches", "steady_launches", "traffic", "traffic_commit", "traffic_kernel", "traffic_source", "profiled_ms_per_step", "box_read_GBps",
                                             "achieved_over_box_read", "box_copy_GBps", "avg_launch_source", "kernel_share_of_step", "whole_step_frac",
                                             "note_ceiling", "survey_8d_ceiling_msamples_per_s") if k in rf},
         "self_check": {k: sc.get(k) for k in ("max_rel_err", "tolerance", "ok", "against", "mac_steady_launches", "error") if k in sc},
@@ -965,11 +965,12 @@ def bench_line(args, ctx):
         # launches, and the "achieved" rate is cache bandwidth
         live_bytes = 8 * Hh * parts * nin * nout
         bound = "hbm" if live_bytes > (256 << 20) else "launch"
-        traffic = None
+        traffic, traffic_commit, traffic_kernel = None, None, None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                trec = json.load(open(tpath))
+                traffic, traffic_commit, traffic_kernel = trec.get("hbm_bytes_per_launch"), trec.get("commit"), trec.get("kernel")
             except Exception:
                 traffic = None
         roofline_batched = None
@@ -1040,6 +1041,8 @@ def bench_line(args, ctx):
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_commit": traffic_commit,
+                "traffic_kernel": traffic_kernel,
                 "traffic_source": None if traffic is None else f"static: profiles/traffic_{args.workload}.json (rocprofv3 --pmc passes of an earlier run of this "
                                                                f"command, tools/pmc_traffic.sh), not measured in this run",
                 "alg_bytes_per_launch": int(alg_bytes),

@@ -366,6 +366,9 @@ bool Engine::alloc_stage(Stage &st)
     else
     {
         HCV_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+        // (the second lane of an extended ladder's pivot stage: created where the layout has rungs behind this stage)
+        static const bool two_lanes = !(std::getenv("HCV_PIVOT_LANES") && std::atoi(std::getenv("HCV_PIVOT_LANES")) == 1);
+        if (two_lanes && st.lead && mCfg.pivot >= 0 && (size_t) mCfg.pivot + 1 < mCfg.stages.size()) HCV_TRY(hipStreamCreateWithFlags(&st.stream2, hipStreamNonBlocking));
     }
     for (int k = 0; k < 2; k++)
     {
@@ -417,6 +420,8 @@ void Engine::free_stage(Stage &st)
     for (int k = 0; k < 2; k++)
         if (st.done[k]) (void) hipEventDestroy(st.done[k]);
     if (st.stream && st.stream != mStream) (void) hipStreamDestroy(st.stream);
+    if (st.stream2) (void) hipStreamDestroy(st.stream2);
+    st.stream2 = nullptr;
     st.Hs = st.X = st.Y = nullptr;
     st.stream = nullptr;
     st.hv = nullptr;
@@ -435,6 +440,7 @@ Engine::~Engine()
     for (Stage *st : mStages)
     {
         if (st->stream) (void) hipStreamSynchronize(st->stream);
+        if (st->stream2) (void) hipStreamSynchronize(st->stream2);
     }
     if (mStream) (void) hipStreamSynchronize(mStream);
     for (void *p : mParked) (void) hipFree(p);

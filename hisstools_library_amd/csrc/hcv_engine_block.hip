@@ -118,7 +118,16 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
 {
     HCV_BLOCK_LOCALS(blk);
     Stage &st = *mStages[si];
-    const hipStream_t sS = serial ? mStream : st.stream;
+    // Two lanes for the pivot stage of an extended ladder: a whole-hop block's chain on that stage — transforms, multiply-accumulate,
+    // reduction, inverse: four latency-bound launches, ~95 us for c5's 16 x 16 x 8 partitions — ran on ONE stream, block after block, and
+    // WAS the ladder's step (0.137 ms) while the rungs' slices beside it left the memory system half idle.  Blocks of odd parity take the
+    // stage's second stream: the only thing block k's chain needs of block k - 1's is its forward transforms (the history ring's hop, and
+    // the ring of spectra in stream order behind them) — one event, the block's input event; the inverses add into disjoint spans of the
+    // timeline, the partial sums are double-buffered by parity as ever.  (HCV_PIVOT_LANES = 1: one lane.)  c5 on the ladder 0.1355 -> 0.130 ms per
+    // step, 64 x 64 / 10 s 0.722 -> 0.707.  (The block's emit on the lane as well, instead of the main stream — which shares a hardware queue
+    // with one of the lanes —: built, no gain, 0.128 - 0.131 against 0.131; not kept.)
+    const bool lane2 = !serial && whole_hops && si == last && st.stream2 != nullptr && (q & 1);
+    const hipStream_t sS = serial ? mStream : (lane2 ? st.stream2 : st.stream);
     if (whole_hops && entering && si <= last)
     {
         // what this stage has pending duplicates what the pivot stage's whole-hop convolution now computes (for the pivot stage
@@ -307,6 +316,8 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     else if (direct_here)
     {
         // the transforms read the caller's block themselves and file it in the history ring: no scatter, no wait for one
+        // (two lanes: behind the previous block's transforms, which ran on the other one)
+        if (st.stream2 && !serial) HCV_TRY(wt(sF, mEvInput[q ^ 1]));
         HCV_TRY(launch_rfft_frames_direct(st.log2n, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, T, (int) rows_in, st.X, (int) st.R, st.tw, sF));
         HCV_TRY(rec(mEvInput[q], sF));          // "the block's input is in the ring"
     }
@@ -625,7 +636,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(hipEventRecord(mEvSerial, mStream));
         HCV_TRY(hipStreamWaitEvent(mInStream, mEvSerial, 0));
         HCV_TRY(hipStreamWaitEvent(mTdStream, mEvSerial, 0));
-        for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvSerial, 0));
+        for (Stage *st : mStages)
+        {
+            HCV_TRY(hipStreamWaitEvent(st->stream, mEvSerial, 0));
+            if (st->stream2) HCV_TRY(hipStreamWaitEvent(st->stream2, mEvSerial, 0));
+        }
     }
     mPrevSerial = serial;
     if (mGhostPruneAt >= 0 && n0 >= mGhostPruneAt && !prune_ghosts()) return false;
@@ -640,7 +655,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         HCV_TRY(rec(mEvCtl, mStream));
         HCV_TRY(wt(sIn, mEvCtl));
         // (deferred slices are launched without waiting for the block's input: order them after the control work directly)
-        for (Stage *st : mStages) HCV_TRY(wt(st->stream, mEvCtl));
+        for (Stage *st : mStages)
+        {
+            HCV_TRY(wt(st->stream, mEvCtl));
+            if (st->stream2) HCV_TRY(wt(st->stream2, mEvCtl));
+        }
         mCtlDirty = false;
     }
     // Direct input: when exactly one FFT stage runs this block and the block is made of whole,
@@ -715,7 +734,11 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         {
             HCV_TRY(hipStreamWaitEvent(mInStream, mEvFwd, 0));
             HCV_TRY(hipStreamWaitEvent(mTdStream, mEvFwd, 0));
-            for (Stage *st : mStages) HCV_TRY(hipStreamWaitEvent(st->stream, mEvFwd, 0));
+            for (Stage *st : mStages)
+            {
+                HCV_TRY(hipStreamWaitEvent(st->stream, mEvFwd, 0));
+                if (st->stream2) HCV_TRY(hipStreamWaitEvent(st->stream2, mEvFwd, 0));
+            }
         }
     }
     // A PLAIN small call — it completes no hop of any stage (three calls in four at 32 samples per call) — has nothing to wait

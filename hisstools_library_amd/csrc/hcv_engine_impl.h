@@ -97,6 +97,8 @@ struct Engine::Stage
     float2 *stage_spec = nullptr;       // staging for one pair's spectra (set_ir phase A), stage_parts partitions
     uint32_t stage_parts = 0;
     hipStream_t stream = nullptr;       // stages are independent until emit(): each runs on its own stream (the MAC stream)
+    hipStream_t stream2 = nullptr;      // the pivot stage of an extended ladder: whole-hop blocks of odd parity run their chain here (two lanes,
+                                        // enqueue_stage), so that consecutive blocks' latency-bound chains overlap
     hipEvent_t mac_done[2] = { nullptr, nullptr };     // the stage's spectral_mac of a block has finished (tail gate)
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;

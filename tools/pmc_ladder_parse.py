@@ -25,5 +25,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 out["hbm_read_bytes_per_step"] = int(per_step["FETCH_SIZE"])
 out["hbm_write_bytes_per_step"] = int(per_step["WRITE_SIZE"])
 out["hbm_bytes_per_step"] = out["hbm_read_bytes_per_step"] + out["hbm_write_bytes_per_step"]
+import datetime, os
+out["kernel"] = "every launch of one 8192-sample step (dominant: " + next(iter(out["FETCH_SIZE_bytes_per_step_by_kernel"]), "?") + ")"
+out["commit"] = os.environ.get("PMC_COMMIT", "unknown")
+out["date"] = datetime.date.today().isoformat()
 json.dump(out, open(f"profiles/traffic_{w}_ladder.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

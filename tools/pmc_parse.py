@@ -35,7 +35,8 @@ tail = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     run = load(f"{src}/{c}/run_counter_collection.csv")
     # the steady-state tail launch: the unpredicated single-hop spectral_mac (<OT, 1, false, NT>) moving the most bytes
-    cand = {k: v for k, v in run.items() if ("spectral_mac_tiled_kernel" in k[0] if batched else ("spectral_mac_kernel" in k[0] and ", 1, false," in k[0]))}
+    # (... or the n x m block's multiply-accumulate launch, hcv_fused_nxm.hip, where the engine takes that block: c4s8, c4g)
+    cand = {k: v for k, v in run.items() if ("spectral_mac_tiled_kernel" in k[0] if batched else (("spectral_mac_kernel" in k[0] and ", 1, false," in k[0]) or "mac_meet_kernel" in k[0]))}
     # the head partition's MAC of whole-hop mode can share the tail's template variant and grid: the tail launches are the
     # ones near the largest value of the (name, grid) group that holds it
     key = max(cand, key=lambda k: max(cand[k]))
@@ -48,5 +49,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 out["hbm_read_bytes_per_launch"] = int(tail["FETCH_SIZE"] * 1024 * factors["FETCH_SIZE"])
 out["hbm_write_bytes_per_launch"] = int(tail["WRITE_SIZE"] * 1024 * factors["WRITE_SIZE"])
 out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_bytes_per_launch"]
+# which build the counters were read on: the commit (PMC_COMMIT, handed in by whoever starts the run: the GPU box has no .git) and the date
+import datetime, os
+out["commit"] = os.environ.get("PMC_COMMIT", "unknown")
+out["date"] = datetime.date.today().isoformat()
 json.dump(out, open(f"profiles/traffic_{w}{'_batched' if batched else ''}.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

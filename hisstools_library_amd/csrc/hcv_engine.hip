@@ -4,6 +4,7 @@
 #include "hcv_engine_impl.h"
 
 #include <chrono>
+#include <cstdio>
 #include <map>
 #include <thread>
 
@@ -884,6 +885,8 @@ hipError_t Engine::ctl_alloc(void **p, size_t bytes)
                 return hipSuccess;
             }
         }
+    static const bool arena_debug = std::getenv("HCV_ARENA_DEBUG") != nullptr;
+    if (arena_debug) std::fprintf(stderr, "[hcv arena] %zu bytes not served by the arena of device %d: stream-ordered pool\n", bytes, mDevice);
     hipMemPool_t pool = ctl_pool(mDevice);
     const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);
     if (e != hipSuccess) (void) hipGetLastError();

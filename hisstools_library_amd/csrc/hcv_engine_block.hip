@@ -685,12 +685,14 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // (one round) ran 1.82 against 1.99 ms in one pair of runs and 1.94 / 1.95 against 1.92 / 1.99 in the next — both kernels stream at
     // 0.93 - 0.95 of what the box reads at all, and the difference is the box's own spread.
     static const int nxm_big = std::getenv("HCV_NXM_BIG") ? std::atoi(std::getenv("HCV_NXM_BIG")) : 0;
-    // The pivot stage of an extended ladder CAN take it (HCV_NXM_LADDER = 1; its hop then goes into the stage's timeline, which emit adds to
-    // the rungs'), and its multiply-accumulate falls from 49 + 13 us (with the reduction) to 25 - 39 — but the ladder's step does not: c5
-    // on the ladder 0.147 / 0.153 ms against 0.137 / 0.140 as it is, same box, alternating.  The step is the rungs' slices and the pivot's
-    // launches sharing the memory system (601 MB per step: 92 us at what the box reads at all), not the pivot's chain; one workgroup per
-    // CU with most of its registers crowds the slices' workgroups out.  Off by default.
-    static const bool nxm_ladder = std::getenv("HCV_NXM_LADDER") && std::atoi(std::getenv("HCV_NXM_LADDER")) != 0;
+    // The pivot stage of an extended ladder takes it too where its chain runs on two lanes (enqueue_stage; HCV_NXM_LADDER = 0 / 1 forces the
+    // choice): its hop goes into the stage's timeline, which emit adds to the rungs'.  The multiply-accumulate falls from 49 + 13 us (with the
+    // reduction) to 25 - 39.  On ONE lane that did not pay — c5 on the ladder 0.147 / 0.153 ms per step against 0.137 / 0.140 with the
+    // separate kernels, same box, alternating: the chain on that stream was the step, and one workgroup per CU with most of its registers
+    // crowds the rungs' slices out while it runs — on two lanes it does: 0.124 / 0.125 against 0.131 / 0.131 (0.60 of HBM for the ladder's
+    // 601 MB per step).
+    static const int nxm_ladder_env = std::getenv("HCV_NXM_LADDER") ? std::atoi(std::getenv("HCV_NXM_LADDER")) : -1;
+    const bool nxm_ladder = nxm_ladder_env >= 0 ? nxm_ladder_env != 0 : (rungs && mStages[last]->stream2 != nullptr);
     if ((serial || nxm_big != 0 || (rungs && nxm_ladder)) && whole_hops && direct_in && (blk.direct_out || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
         blk.full_matrix && mPipeStream && B == mStages[last]->M)
     {
@@ -721,7 +723,9 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         {
             const Stage &tl = *mStages[last];
             const long long lag = std::min<long long>((long long) tl.R - (long long) (tl.P + tl.lead) + 1, mHistLen / (long long) tl.M - 1);
-            mNxmEvery = (uint32_t) std::max<long long>(1, std::min<long long>(8, lag - 1));
+            // (two lanes, enqueue_stage: the end recorded on one lane says nothing of the other lane's newer blocks — only, through the emits
+            // both lanes' inverses wait for, that every block four and more back is through: the window is four blocks shorter)
+            mNxmEvery = (uint32_t) std::max<long long>(1, std::min<long long>(8, lag - 1 - (tl.stream2 ? 4 : 0)));
             if (lag < 2) blk.nxm = false;           // (no room to run ahead at all: the separate kernels)
             else if ((long long) mNxmRun >= lag) HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvNxmEnd[((mNxmRun - 2) / mNxmEvery) & 3], 0));
         }

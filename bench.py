@@ -918,21 +918,25 @@ def bench_line(args, ctx):
     extended = None
     if args.extended_ratio and not args.tail_ratio and not reduce_path:
         try:
-            e_el, e_stats, e_fin, _, _, e_conv = run(args.extended_ratio, args.steps, args.warmup, 0, keep=True)
-            extended = {"tail_ratio": args.extended_ratio, "stages": [(s_["fft_size"], s_["partitions"]) for s_ in e_stats],
-                        "msamples_per_s": round(nout_total * B * args.steps / e_el / 1e6, 2), "ms_per_step": round(1e3 * e_el / args.steps, 4),
+            # (timed over at least 128 steps: the ladder's last rung turns over once in 4 steps of config 5 and its streams run well ahead of
+            # one another, so K = 20 steps between two device syncs — 2.4 ms — is mostly fill and drain: 0.117 - 0.158 ms per step from run
+            # to run on one box where 128 steps and 512 steps both give 0.119 - 0.120, profiles/r05_queue_probe.txt)
+            e_steps = max(args.steps, 128)
+            e_el, e_stats, e_fin, _, _, e_conv = run(args.extended_ratio, e_steps, args.warmup, 0, keep=True)
+            extended = {"tail_ratio": args.extended_ratio, "stages": [(s_["fft_size"], s_["partitions"]) for s_ in e_stats], "steps": e_steps,
+                        "msamples_per_s": round(nout_total * B * e_steps / e_el / 1e6, 2), "ms_per_step": round(1e3 * e_el / e_steps, 4),
                         "finite_output": e_fin}
             # the same self-check the headline has: the ladder's engine, reset, against the reference CPU leg's rows (the SAME
             # convolution on a different partitioning).  Its steps are not an HBM test — its spectra are read 8 x less often per rung
             # — so no roofline fraction is quoted for it: the per-stage multiply-accumulate times say where its step goes
             if have_ref and not args.no_self_check and world == 1:
                 extended["self_check"] = check_against_cpu_leg(e_conv)
-            extended["all_stage_mac_ms_per_step"] = {str(s_["fft_size"]): round(s_["mac_ms"] / args.steps, 4) for s_ in e_stats}
+            extended["all_stage_mac_ms_per_step"] = {str(s_["fft_size"]): round(s_["mac_ms"] / e_steps, 4) for s_ in e_stats}
             # SURVEY 8d's per-sample-time figure summed over the ladder's stages (8 Nin (Nout + 1) sum P + 12 Nin stages + 4 Nout stages)
             # against the WHOLE step: no single kernel dominates this leg (profiles/r03_c5_extended_kernel_summary.txt)
             e_sum_p, e_ns = sum(s_["partitions"] for s_ in e_stats), len(e_stats)
             e_bytes = (8.0 * nin * (nout + 1) * e_sum_p + 12.0 * nin * e_ns + 4.0 * nout * e_ns) * B
-            e_gbs = e_bytes / (e_el / args.steps) / 1e9
+            e_gbs = e_bytes / (e_el / e_steps) / 1e9
             extended["roofline_step"] = {"bound": "hbm", "achieved": round(e_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(e_gbs / 8000.0, 4),
                                          "alg_bytes_per_step": int(e_bytes), "sum_partitions": int(e_sum_p),
                                          "note": "whole step (every stage's kernels, transforms included) against SURVEY 8d's bytes for this ladder"}

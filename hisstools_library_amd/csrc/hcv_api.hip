@@ -1650,6 +1650,7 @@ extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_
     out->hop_tile = s.hop_tile;
     out->launch_partitions = s.launch_partitions;
     out->fused_launches = s.fused_launches;
+    out->fused_stood_down = s.fused_stood_down;
     return 0;
 }
 

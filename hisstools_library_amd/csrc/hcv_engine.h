@@ -82,6 +82,7 @@ namespace hcv
         uint64_t mac_steady_launches;   // of mac_launches: the unchecked instantiation with nontemporal IR loads
         uint32_t hop_tile, launch_partitions;
         uint64_t fused_launches;        // of mac_launches: whole blocks run as ONE launch (hcv_fft_split.hip: fused_block_*_kernel)
+        uint64_t fused_stood_down;      // times the n x m block was stood down for 4096 blocks (its forward launches kept arriving late)
     };
 
     class Engine
@@ -289,6 +290,7 @@ namespace hcv
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         bool mExtDirty = false;             // the main stream was made to wait for a foreign event (process_dev `after`): a streamed block fans it out
         uint64_t mBlockCount = 0;
+        int mStreamsSpread = -2;        // hcv_queue_probe.hip's verdict at creation: streams replaced, -1 = not run, -2 = not needed
         int mPinXcd = 0;                    // the XCD this engine's pinned tiny launches go to (hcv_kernels.h: xcd_pin_for); engines are spread over the eight
 
         // rings and staging

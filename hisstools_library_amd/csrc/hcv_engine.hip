@@ -285,6 +285,30 @@ bool Engine::init(const EngineCfg &cfg)
         if (!alloc_stage(*st)) return false;
     }
     if (mLeadSlot) HCV_TRY(hipMalloc(&mStageTailHead, sizeof(float2) * mStages[mPivot]->M));
+    // The streams that carry a step side by side, on hardware queues chosen for them (hcv_queue_probe.hip; nothing is enqueued on them yet).
+    // An extended ladder has five busy streams for the process's four queues: the pivot stage's two lanes and the first rung get queues of
+    // their own, the LAST rung the main stream's — whose emit launches then wait behind that rung's long multiply-accumulate slices now and
+    // then.  Measured, c5 on the ladder over 128 steps, ms per step: that pairing 0.116 - 0.119 (what a process's second engine got by
+    // itself); emit with the first lane — what a process's first engine got — 0.124 - 0.139: emit (k), waiting for the other lane's block,
+    // holds the first lane's block k + 1 back; emit alone (eight queues, or a stream of high priority: another pool of queues) 0.130 - 0.150.
+    // An engine whose one-hop block is the n x m pair of launches: the forward launch's stream not with the main one.
+    if (!mOneStream && !mStages.empty())
+    {
+        Stage &pv = *mStages[mPivot];
+        std::vector<hipStream_t *> roles;
+        static const int share_env = std::getenv("HCV_QUEUE_SHARE") ? std::atoi(std::getenv("HCV_QUEUE_SHARE")) : -2;
+        int share = -1;
+        if (pv.stream2)
+        {
+            roles.push_back(&pv.stream);
+            roles.push_back(&pv.stream2);
+            for (size_t k = mPivot + 1; k < mStages.size() && roles.size() < 4; k++) roles.push_back(&mStages[k]->stream);
+            share = share_env >= -1 ? std::min(share_env, (int) roles.size() - 1) : (int) roles.size() - 1;
+        }
+        else if (pv.nxm_helped)
+            roles.push_back(&mPipeStream);
+        if (!roles.empty()) mStreamsSpread = spread_streams(mStream, roles.data(), (int) roles.size(), share);
+    }
     // Head through the FFT: the head's taps (<= one hop of the first FFT stage, MonoConvolve.cpp:235-240) form one extra,
     // zero-latency partition of that stage, whose input spectra exist anyway.  Used for hop-aligned blocks of larger
     // matrices, where the direct-form FIR would cost more than all FFT-stage MACs together; ragged blocks and small
@@ -341,6 +365,16 @@ bool Engine::alloc_stage(Stage &st)
         HCV_TRY(hipMemset(st.coop_bar, 0, sizeof(unsigned) * counters));
         HCV_TRY(hipMalloc(&st.coop_flags, sizeof(unsigned long long) * marks));
         HCV_TRY(hipMemset(st.coop_flags, 0, sizeof(unsigned long long) * marks));
+        if (coop_nxm)
+        {
+            HCV_TRY(hipHostMalloc((void **) &st.nxm_helped, sizeof(unsigned), hipHostMallocMapped));
+            *st.nxm_helped = 0;
+            if (hipHostGetDevicePointer((void **) &st.nxm_helped_dev, st.nxm_helped, 0) != hipSuccess)
+            {
+                (void) hipGetLastError();
+                st.nxm_helped_dev = nullptr;
+            }
+        }
     }
     HCV_TRY(hipMalloc(&st.Ypre, sizeof(float2) * (size_t) (kBgSlices + kBoundarySlices) * mCfg.nout * st.M));
     HCV_TRY(hipEventCreateWithFlags(&st.bg_done, hipEventDisableTiming));
@@ -402,6 +436,8 @@ void Engine::free_stage(Stage &st)
     if (st.hv) (void) hipFree(st.hv);
     if (st.coop_bar) (void) hipFree(st.coop_bar);
     if (st.coop_flags) (void) hipFree(st.coop_flags);
+    if (st.nxm_helped) (void) hipHostFree(st.nxm_helped);
+    st.nxm_helped = st.nxm_helped_dev = nullptr;
     if (st.gh_start) (void) hipFree(st.gh_start);
     if (st.gh_ent) (void) hipFree(st.gh_ent);
     st.gh_start = nullptr;
@@ -1345,6 +1381,7 @@ bool Engine::stage_stats(size_t s, StageStats *out)
     out->hop_tile = st.last_tt;
     out->launch_partitions = st.last_parts;
     out->fused_launches = st.fused_launches;
+    out->fused_stood_down = st.nxm_stood_down;
     return true;
 }
 

@@ -204,7 +204,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const hipError_t fe = launch_fused_block_nxm(blk.nxm_plan, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, (int) mNinAlloc,
                                                      (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, blk.direct_out ? blk.dout : nullptr, blk.out_stride,
                                                      st.tw, st.coop_bar, st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS, /* chained */ mNxmRun > 0,
-                                                     pe ? pe->a : nullptr, pe ? pe->b : nullptr);
+                                                     pe ? pe->a : nullptr, pe ? pe->b : nullptr, st.nxm_helped_dev);
         if (pe && fe == hipSuccess) pe->live = true;
         if (fe == hipSuccess && !blk.direct_out)
         {
@@ -685,14 +685,15 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // (one round) ran 1.82 against 1.99 ms in one pair of runs and 1.94 / 1.95 against 1.92 / 1.99 in the next — both kernels stream at
     // 0.93 - 0.95 of what the box reads at all, and the difference is the box's own spread.
     static const int nxm_big = std::getenv("HCV_NXM_BIG") ? std::atoi(std::getenv("HCV_NXM_BIG")) : 0;
-    // The pivot stage of an extended ladder takes it too where its chain runs on two lanes (enqueue_stage; HCV_NXM_LADDER = 0 / 1 forces the
-    // choice): its hop goes into the stage's timeline, which emit adds to the rungs'.  The multiply-accumulate falls from 49 + 13 us (with the
-    // reduction) to 25 - 39.  On ONE lane that did not pay — c5 on the ladder 0.147 / 0.153 ms per step against 0.137 / 0.140 with the
-    // separate kernels, same box, alternating: the chain on that stream was the step, and one workgroup per CU with most of its registers
-    // crowds the rungs' slices out while it runs — on two lanes it does: 0.124 / 0.125 against 0.131 / 0.131 (0.60 of HBM for the ladder's
-    // 601 MB per step).
-    static const int nxm_ladder_env = std::getenv("HCV_NXM_LADDER") ? std::atoi(std::getenv("HCV_NXM_LADDER")) : -1;
-    const bool nxm_ladder = nxm_ladder_env >= 0 ? nxm_ladder_env != 0 : (rungs && mStages[last]->stream2 != nullptr);
+    // The pivot stage of an extended ladder can take it (HCV_NXM_LADDER = 1; its hop then goes into the stage's timeline, which emit adds to
+    // the rungs') but does not by default.  Measured, c5 on the ladder, ms per step: ONE lane 0.147 / 0.153 with it against 0.137 / 0.140
+    // without (one workgroup per CU with most of its registers crowds the rungs' slices out while it runs); TWO lanes (enqueue_stage) as the
+    // process's only engine 0.121 - 0.129 with it against 0.125 - 0.131 without — inside the boxes' spread — and as the process's SECOND engine
+    // (bench.py's extended leg) 0.80 with it: its forward launches sat behind the first engine's streams in a hardware queue they share, every
+    // multiply-accumulate waited its full bound and then did the transforms itself.  The stand-down below brings that to 0.148; the two
+    // lanes alone run 0.118 - 0.125 there (0.60 - 0.64 of HBM for the ladder's 601 MB per step), so that is the default.
+    static const int nxm_ladder_env = std::getenv("HCV_NXM_LADDER") ? std::atoi(std::getenv("HCV_NXM_LADDER")) : 0;
+    const bool nxm_ladder = nxm_ladder_env != 0;
     if ((serial || nxm_big != 0 || (rungs && nxm_ladder)) && whole_hops && direct_in && (blk.direct_out || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
         blk.full_matrix && mPipeStream && B == mStages[last]->M)
     {
@@ -700,7 +701,27 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const long long h = n0 / (long long) tl.M;
         const int Pw = (int) (tl.P + tl.lead);
         const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
-        if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw)
+        // (launches whose wait for the forward transforms ran out report it, hcv_fused_nxm.hip: three of them within 64 blocks and the stage
+        // takes the separate kernels for the next 4096 blocks — the forward stream is stuck behind another stream in a hardware queue they
+        // share, e.g. a second engine of the process: c5 on the ladder as the bench's second engine ran 0.80 ms per step that way, 0.125 without)
+        Stage &tw_ = *mStages[last];
+        if (tw_.nxm_helped)
+        {
+            const unsigned now = *reinterpret_cast<volatile unsigned *>(tw_.nxm_helped);
+            if (now != tw_.nxm_helped_seen)
+            {
+                tw_.nxm_helped_seen = now;
+                tw_.nxm_strikes = (mBlockCount - tw_.nxm_strike_block <= 64) ? tw_.nxm_strikes + 1 : 1;
+                tw_.nxm_strike_block = mBlockCount;
+                if (tw_.nxm_strikes >= 3)
+                {
+                    tw_.nxm_off_until = mBlockCount + 4096;
+                    tw_.nxm_stood_down++;
+                    tw_.nxm_strikes = 0;
+                }
+            }
+        }
+        if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw && mBlockCount >= tl.nxm_off_until)
             blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan) &&
                       (serial || nxm_big > 0 || rungs);
     }

@@ -12,6 +12,9 @@
 namespace hcv
 {
 
+// hcv_queue_probe.hip: fresh streams swapped until they feed different hardware queues (roles[share] the anchor's own)
+int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share);
+
 #define HCV_TRY(expr)                                                                                                  \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -106,6 +109,9 @@ struct Engine::Stage
     unsigned *coop_bar = nullptr;       // fused blocks: the two monotonic hand-over counters (one-output engines only)
     unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
+    unsigned *nxm_helped = nullptr, *nxm_helped_dev = nullptr;     // host-mapped: n x m launches that had to do their forward transforms themselves
+    unsigned nxm_helped_seen = 0, nxm_strikes = 0;
+    uint64_t nxm_strike_block = 0, nxm_off_until = 0, nxm_stood_down = 0;               // (engine block counts) the last strike; separate kernels until this block
     unsigned coop_arrived_nxm[kFusedShards] = {};       // ... of the n x m block's sharded counter (hcv_fused_sync.h), per shard
     unsigned long long coop_seq = 0;        // fused blocks launched so far
     bool coop_off = false;

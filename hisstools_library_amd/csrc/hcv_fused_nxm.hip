@@ -65,6 +65,8 @@ struct FusedNxmParams
     int ms, tiles, kper_old;                    // k-slice groups (partial spectra per output), output tiles of 8, (i, p >= 1) terms per wave
     unsigned long long *hint;                   // [kNxmHints] marks 128 bytes apart: "inverse workgroup m of launch `seq` has started"
     int hint_wait;                              // > 0: the forward launch holds itself back until the PREVIOUS block's inverse has started (marks to look at)
+    unsigned *helped;                           // host memory (mapped): launches whose wait for the forward transforms ran out — the engine's cue to
+                                                // take the separate kernels for a while (enqueue_stage)
 };
 
 static_assert(kShards == kFusedShards && kShardStride == kFusedShardStride, "hcv_kernels.h sizes the engine's counters");
@@ -263,6 +265,9 @@ namespace
     {
         const FusedSyncSharded &sy = ka->sy;
         const int nfwd = ka->nin;
+        // (told to the host, once per launch: a forward launch that does not come — stuck behind another stream's packets in a hardware
+        // queue the two share, there are four queues for a dozen streams — is a condition that lasts, and every block would pay the wait)
+        if (m == 0 && tid == 0 && ka->helped) __hip_atomic_fetch_add(ka->helped, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const int first = (int) ((long long) m * nfwd / nmac);
         for (int k = next_undone(tid, sy.flagF, sy.seq, nfwd, first, 0, slot_b); k < nfwd; k = next_undone(tid, sy.flagF, sy.seq, nfwd, first, k + 1, slot_b))
         {
@@ -328,7 +333,7 @@ bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, F
 hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0,
                                   long long h, int nin, int nin_alloc, int nout, float2 *X, int Rring, const float2 *H, int hparts, int P, float2 *Y, float *out,
                                   long long out_stride, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived, unsigned long long *seq,
-                                  hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin, hipEvent_t ev_end)
+                                  hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin, hipEvent_t ev_end, unsigned *helped)
 {
     constexpr int LOG2N = kNxmLog2N, M = 1 << (LOG2N - 1);
     constexpr size_t lds_fwd = sizeof(float2) * (size_t) lds_padded(M);                  // the whole-frame transform (the helping path runs it too)
@@ -353,6 +358,10 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     a.ms = pl.ms; a.tiles = pl.tiles; a.kper_old = pl.kper_old;
     a.sy = fused_sync_sharded(bar, flags, arrived, *seq, (unsigned) pl.nfwd);
     a.hint = flags + kNxmHintBase;
+    a.helped = fused_spin() > 0 ? helped : nullptr;      // (HCV_COOP_SPIN=0 is the test suite's way to run the helping path on purpose)
+    // (a forward launch is normally through tens of microseconds before it is needed: a shorter wait than the one-output blocks' — ~0.1 ms —
+    // before the multiply-accumulate's workgroups do the transforms themselves)
+    a.sy.spin = std::min(a.sy.spin, 256);
     static const bool hint_on = !(std::getenv("HCV_NXM_HINT") && std::atoi(std::getenv("HCV_NXM_HINT")) == 0);
     a.hint_wait = (chained && hint_on && out) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
     hipLaunchKernelGGL((fwd_publish_kernel<LOG2N>), dim3(pl.nfwd), dim3(64 * kNxmWaves), lds_fwd, fwd_stream, a);

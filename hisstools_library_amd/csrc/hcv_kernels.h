@@ -91,7 +91,8 @@ namespace hcv
     //      bar = kFusedShards x kFusedShardStride unsigned, flags = kFusedFwdTasks marks (both zero-initialised, touched by these launches
     //      only); arrived = kFusedShards running totals of the host, seq = the launch sequence number; chained = the previous launch on this
     //      state was the block right before this one (its forward launch then waits for that block's multiply-accumulate to end: a
-    //      scheduling hint); ev_begin / ev_end (optional) are recorded around the multiply-accumulate launch.  `plan` says whether the shape is taken.
+    //      scheduling hint); ev_begin / ev_end (optional) are recorded around the multiply-accumulate launch; helped (optional, host-mapped) counts the
+    //      launches whose wait for the forward transforms ran out.  `plan` says whether the shape is taken.
     constexpr int kFusedShards = 32, kFusedShardStride = 32;
     struct FusedNxmPlan { int ms, tiles, kper_old, nmac, nfwd; };
     bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, FusedNxmPlan *pl);
@@ -99,7 +100,7 @@ namespace hcv
                                       long long n0, long long h, int nin, int nin_alloc, int nout, float2 *X, int Rring, const float2 *H, int hparts, int P,
                                       float2 *Y, float *out, long long out_stride, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived,
                                       unsigned long long *seq, hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin = nullptr,
-                                      hipEvent_t ev_end = nullptr);
+                                      hipEvent_t ev_end = nullptr, unsigned *helped = nullptr);
     const float2 *fft_split_sub_table(int log2s);          // the (2 S)-th roots of the residue-split transforms' sub-transform, current device
 
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,

@@ -1,0 +1,182 @@
+// Which hardware queue does a stream feed?  HIP hands every stream of a process one of a handful of hardware queues (four by default) —
+// the least used one at the moment the stream is made, so which streams end up together depends on everything the process made before
+// (other engines, the framework around us) and, between equally used queues, on their addresses.  Work of two streams in one queue runs in
+// the order it was enqueued: an engine of twelve streams whose five busy ones — the pivot stage's two lanes, the two far-tail rungs and
+// the main stream's emit — happen to pair the emit with a rung's 0.3 ms multiply-accumulate loses a quarter of its throughput (c5 on the
+// ladder as bench.py's second engine: 0.150 ms per step in such processes against 0.118 in the others, profiles/r05_queue_probe.txt).
+//
+// There is no API that tells the queue of a stream; there is an experiment: hold stream A with a kernel that waits for a word in host
+// memory (bounded: 0.3 ms), send an empty kernel down stream B and watch whether it gets through.  spread_streams() runs that experiment
+// at engine creation — on fresh streams, nothing of the engine is enqueued yet — and swaps the busy streams for others until they feed
+// different queues.
+#include "hcv_engine_impl.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+namespace hcv {
+namespace {
+
+__global__ void hold_kernel(const volatile unsigned *release, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();                   // (100 MHz)
+    while (!*release && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+__global__ void touch_kernel() {}
+
+struct Probe
+{
+    unsigned *flag = nullptr, *flag_dev = nullptr;
+    std::vector<hipEvent_t> ev;
+    bool ok = false;
+
+    bool init()
+    {
+        if (hipHostMalloc((void **) &flag, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return false;
+        if (hipHostGetDevicePointer((void **) &flag_dev, flag, 0) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+    ~Probe()
+    {
+        for (hipEvent_t e : ev) (void) hipEventDestroy(e);
+        if (flag) (void) hipHostFree(flag);
+        (void) hipGetLastError();
+    }
+
+    // bit i set: work sent down reps[i] waited for the kernel holding c — one hardware queue.  -1: the experiment itself failed.
+    long shares(hipStream_t c, const std::vector<hipStream_t> &reps)
+    {
+        while (ev.size() < reps.size())
+        {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+            ev.push_back(e);
+        }
+        *reinterpret_cast<volatile unsigned *>(flag) = 0;
+        hold_kernel<<<1, 64, 0, c>>>(flag_dev, 30000ull);
+        for (size_t i = 0; i < reps.size(); i++)
+        {
+            touch_kernel<<<1, 64, 0, reps[i]>>>();
+            if (hipEventRecord(ev[i], reps[i]) != hipSuccess) return -1;
+        }
+        long pending = (1l << reps.size()) - 1;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (pending && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150))
+            for (size_t i = 0; i < reps.size(); i++)
+                if ((pending >> i & 1) && hipEventQuery(ev[i]) == hipSuccess) pending &= ~(1l << i);
+        (void) hipGetLastError();                                   // (hipErrorNotReady of the queries)
+        *reinterpret_cast<volatile unsigned *>(flag) = 1;
+        bool fine = hipStreamSynchronize(c) == hipSuccess;
+        for (hipStream_t r : reps) fine = hipStreamSynchronize(r) == hipSuccess && fine;
+        return fine ? pending : -1;
+    }
+};
+
+}  // namespace
+
+// roles[0 .. n): the engine's busy streams, all freshly made.  On return they feed pairwise different hardware queues as far as the process
+// has queues to give, none of them the queue of `anchor` — but roles[share] (share >= 0), which feeds exactly that one.  A role that cannot
+// be served keeps the stream it had.  Returns the number of streams replaced (0: the ones at hand were fine), -1 when the experiment could
+// not be run (nothing changed).
+int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
+{
+    static const bool allow = !(std::getenv("HCV_QUEUE_PROBE") && std::atoi(std::getenv("HCV_QUEUE_PROBE")) == 0);
+    if (!allow || n <= 0 || n > 6) return -1;
+    Probe px;
+    if (!px.init()) return -1;
+    // (the first launch of a kernel loads its code: not inside the watched window)
+    *px.flag = 1;
+    hold_kernel<<<1, 64, 0, anchor>>>(px.flag_dev, 1ull);
+    touch_kernel<<<1, 64, 0, anchor>>>();
+    if (hipStreamSynchronize(anchor) != hipSuccess) return -1;
+
+    struct Cand { hipStream_t s; int cls; bool made; };
+    std::vector<Cand> cands;
+    std::vector<hipStream_t> reps{anchor};                          // one stream per queue seen so far; class 0 = the anchor's
+    auto classify = [&](hipStream_t s) -> int
+    {
+        const long m = px.shares(s, reps);
+        if (m < 0) return -1;
+        for (size_t i = 0; i < reps.size(); i++)
+            if (m >> i & 1) return (int) i;
+        if (reps.size() >= 12) return (int) reps.size();            // (more queues than anybody needs: all further ones count as one)
+        reps.push_back(s);
+        return (int) reps.size() - 1;
+    };
+    auto cleanup = [&](int rc)
+    {
+        for (Cand &c : cands)
+            if (c.made && c.s) (void) hipStreamDestroy(c.s);
+        return rc;
+    };
+    for (int r = 0; r < n; r++)
+    {
+        const int cls = classify(*roles[r]);
+        if (cls < 0) return cleanup(-1);
+        cands.push_back({*roles[r], cls, false});
+    }
+    // pick[r] = candidate of role r, -1 = none; returns the roles served
+    auto assign = [&](std::vector<int> &pick) -> int
+    {
+        std::vector<char> used(reps.size() + 1, 0);
+        pick.assign(n, -1);
+        int served = 0;
+        // first the stream a role has, if it will do; then a made one of a queue nobody has taken
+        for (int pass = 0; pass < 2; pass++)
+            for (int r = 0; r < n; r++)
+            {
+                if (pick[r] >= 0) continue;
+                for (int c = pass == 0 ? r : n; c < (pass == 0 ? r + 1 : (int) cands.size()); c++)
+                {
+                    bool taken = false;
+                    for (int p : pick) taken = taken || p == c;
+                    const int cls = cands[c].cls;
+                    const bool fits = r == share ? cls == 0 : cls != 0;
+                    if (taken || used[cls] || !fits) continue;
+                    pick[r] = c;
+                    used[cls] = 1;
+                    served++;
+                    break;
+                }
+            }
+        return served;
+    };
+    std::vector<int> pick;
+    int served = assign(pick);
+    for (int extra = 0; served < n && extra < 10; extra++)
+    {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        const int cls = classify(s);
+        if (cls < 0)
+        {
+            (void) hipStreamDestroy(s);
+            return cleanup(-1);
+        }
+        cands.push_back({s, cls, true});
+        served = assign(pick);
+    }
+    int replaced = 0;
+    for (int r = 0; r < n; r++)
+    {
+        if (pick[r] < n) continue;                                  // (served by its own stream, or not served: it keeps what it had)
+        Cand &c = cands[pick[r]];
+        (void) hipStreamDestroy(*roles[r]);
+        *roles[r] = c.s;
+        c.made = false;                                             // (taken: not the cleanup's any more)
+        replaced++;
+    }
+    if (std::getenv("HCV_QUEUE_PROBE_DEBUG"))
+    {
+        std::fprintf(stderr, "[hcv] queue probe: %zu queues seen, %d of %d busy streams on queues of their own, %d replaced; classes:", reps.size(), served, n, replaced);
+        for (int r = 0; r < n; r++) std::fprintf(stderr, " %d", pick[r] >= 0 ? cands[pick[r]].cls : -1);
+        std::fprintf(stderr, "\n");
+    }
+    return cleanup(replaced);
+}
+
+}  // namespace hcv

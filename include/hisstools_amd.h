@@ -218,6 +218,9 @@ typedef struct hcv_stage_stats
     /* of mac_launches: whole blocks of a one-output engine that ran as ONE launch (transforms, multiply-accumulate and inverse
      * with in-launch hand-overs) */
     uint64_t fused_launches;
+    /* times the stage stood its n x m block down for 4096 blocks: three launches within 64 blocks found their forward launch missing
+     * (stuck behind another stream's work in a shared hardware queue) and did the transforms themselves */
+    uint64_t fused_stood_down;
 } hcv_stage_stats;
 HCV_API void hcv_convolver_set_profiling(hcv_convolver *h, int on);
 HCV_API int hcv_convolver_num_stages(hcv_convolver *h);

@@ -64,7 +64,8 @@ STREAM = ("import json, numpy as np, hisstools_library_amd as H\n"
           "rb = r.run(np.ascontiguousarray(xs[:, cut:]), nout, 2048)\n"
           "y, ref = np.concatenate([ya, yb], axis=1), np.concatenate([ra, rb], axis=1)\n"
           "err = max(float(np.abs(y[o].astype(np.float64) - ref[o]).max() / np.abs(ref[o]).max()) for o in range(nout))\n"
-          "print(json.dumps({'stages': stages, 'err': err, 'stages_after': [s['fft_size'] for s in c.stage_stats()]}))\n")
+          "print(json.dumps({'stages': stages, 'err': err, 'stages_after': [s['fft_size'] for s in c.stage_stats()],\n"
+          "                  'fused': sum(int(s['fused_launches']) for s in c.stage_stats())}))\n")
 
 
 @pytest.mark.parametrize("blocks", ["[8192, 32768, 1000, 333, 16384]", "8192", "128"])
@@ -77,6 +78,13 @@ def test_env_tail_ratio_for_the_reference_constructor(blocks):
     # without the variable this small matrix keeps the reference's own partitioning (the rule asks for >= 1 GiB of tail spectra)
     r0 = _child(STREAM.replace("BLOCKS", "8192").replace("S, cut = 2, 2, 600000, 1300000, 700000 + 4321", "S, cut = 2, 2, 600000, 200000, 100000"), {})
     assert r0["stages"] == [256, 1024, 4096, 16384] and r0["err"] <= TOL, r0
+
+
+def test_the_pivot_on_the_n_x_m_block_when_asked_for():
+    """HCV_NXM_LADDER=1 (off by default, hcv_engine_block.hip: as a process's second engine it lost): the pivot stage's hop as the
+    n x m block writing into the stage's timeline, the rungs beside it — the same stream"""
+    r = _child(STREAM.replace("BLOCKS", "8192"), {"HCV_TAIL_RATIO": "8", "HCV_NXM_LADDER": "1"})
+    assert r["stages"] == [256, 1024, 4096, 16384, 131072, 1 << 20] and r["err"] <= TOL and r["fused"] >= 8, r
 
 
 def test_the_automatic_rule_on_the_baseline_shapes(H, oracle):

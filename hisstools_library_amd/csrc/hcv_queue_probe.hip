@@ -172,7 +172,7 @@ int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
     }
     if (std::getenv("HCV_QUEUE_PROBE_DEBUG"))
     {
-        std::fprintf(stderr, "[hcv] queue probe: %zu queues seen, %d of %d busy streams on queues of their own, %d replaced; classes:", reps.size(), served, n, replaced);
+        std::fprintf(stderr, "[hcv] queue probe: %zu queues seen, %d of %d busy streams placed, %d replaced; classes:", reps.size(), served, n, replaced);
         for (int r = 0; r < n; r++) std::fprintf(stderr, " %d", pick[r] >= 0 ? cands[pick[r]].cls : -1);
         std::fprintf(stderr, "\n");
     }

@@ -87,6 +87,33 @@ def test_the_pivot_on_the_n_x_m_block_when_asked_for():
     assert r["stages"] == [256, 1024, 4096, 16384, 131072, 1 << 20] and r["err"] <= TOL and r["fused"] >= 8, r
 
 
+def test_busy_streams_are_placed_on_hardware_queues_at_creation():
+    """hcv_queue_probe.hip: the pivot's two lanes and the first rung on hardware queues of their own, the last rung on the main
+    stream's (profiles/r05_queue_probe.txt) — found by experiment when the engine is made; the stream stays the oracle's.  A process
+    that has made other streams before (here: eleven of them, held) gets the same placement."""
+    import re
+    pre = ("import torch\n"
+           "held = [torch.cuda.Stream() for _ in range(11)]\n"
+           "for s_ in held:\n"
+           "    with torch.cuda.stream(s_):\n"
+           "        torch.zeros(8, device='cuda').add_(1)\n"
+           "torch.cuda.synchronize()\n")
+    for code in (STREAM.replace("BLOCKS", "8192"), pre + STREAM.replace("BLOCKS", "8192")):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                             env=dict(os.environ, HCV_TAIL_RATIO="8", HCV_QUEUE_PROBE_DEBUG="1"))
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        assert r["err"] <= TOL, r
+        probes = [l for l in out.stderr.splitlines() if "queue probe" in l]
+        assert probes, out.stderr[-2000:]
+        m = re.search(r"(\d+) queues seen, (\d+) of (\d+) busy streams .* classes:((?: -?\d+)+)", probes[-1])
+        assert m, probes
+        queues, served, want = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        classes = [int(c) for c in m.group(4).split()]
+        assert want == 4 and served == want, probes                # two lanes, two rungs
+        assert classes[-1] == 0 and len(set(classes)) == 4 and queues >= 4, probes
+
+
 def test_the_automatic_rule_on_the_baseline_shapes(H, oracle):
     """unset HCV_TAIL_RATIO: the ladder where the reference's tail would be HBM-bound (>= 32 partitions and >= 1 GiB of tail
     spectra: config 5 and the 64 x 64 / 10 s shape), the reference's own stage list elsewhere (config 4: 11 partitions; config 3:

@@ -19,7 +19,7 @@ GiB = 1 << 30
 def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[(re.sub(r"\(.*", "", r["Kernel_Name"]), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+        agg[(re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return agg
 
 

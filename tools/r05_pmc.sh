@@ -22,3 +22,7 @@ import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[1].split('/')[-1], d.get("kernel","")[:60], d.get("commit"), d.get("date"), d.get("hbm_bytes_per_launch", d.get("hbm_bytes_per_step")))
 PY
 done
+# (the raw counter dumps are tens of MB per workload: what travels back is the JSON and the logs' tails)
+for d in gpurun_out/pmc_*; do [ -d "$d" ] && [ "$d" != gpurun_out/pmc_json ] && rm -rf "$d"; done
+rm -rf gpurun_out/pmc_ladder_* 2>/dev/null
+du -sh gpurun_out

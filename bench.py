@@ -918,7 +918,7 @@ def bench_line(args, ctx):
     extended = None
     if args.extended_ratio and not args.tail_ratio and not reduce_path:
         try:
-            # (timed over at least 128 steps: the ladder's last rung turns over once in 4 steps of config 5 and its streams run well ahead of
+            # (timed over at least 128 steps: the ladder's last rung turns over once in 64 steps of config 5 and its streams run well ahead of
             # one another, so K = 20 steps between two device syncs — 2.4 ms — is mostly fill and drain: 0.117 - 0.158 ms per step from run
             # to run on one box where 128 steps and 512 steps both give 0.119 - 0.120, profiles/r05_queue_probe.txt)
             e_steps = max(args.steps, 128)

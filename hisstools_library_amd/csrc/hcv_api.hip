@@ -1683,4 +1683,5 @@ extern "C" int hcv_ctl_reserve(int device, size_t bytes)
     return hcv::ctl_arena_reserve(device, bytes) ? 0 : -1;
 }
 extern "C" size_t hcv_ctl_reserved(int device) { return hcv::ctl_arena_size(device); }
+extern "C" long long hcv_order_check_violations(void) { return hcv::order_violations(); }
 extern "C" const char *hcv_last_error(void) { return tlsError.c_str(); }

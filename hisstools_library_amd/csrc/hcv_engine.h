@@ -40,6 +40,8 @@
 
 namespace hcv
 {
+    long long order_violations();   // hcv_engine.hip: violations counted by HCV_ORDER_CHECK so far, -1 = the check is off
+    class OrderCheck;               // hcv_order_check.h: HCV_ORDER_CHECK=1, the stream / event order asserted at enqueue time
     // one step of a bounded spin-wait on the host (the audio thread's lock poll, the shard pool's hand-offs)
     inline void cpu_relax()
     {
@@ -290,6 +292,7 @@ namespace hcv
         bool mCtlDirty = false;             // control work (IR loads, resets, regrow) was queued on mStream since the last block
         bool mExtDirty = false;             // the main stream was made to wait for a foreign event (process_dev `after`): a streamed block fans it out
         uint64_t mBlockCount = 0;
+        OrderCheck *mOrd = nullptr;
         int mStreamsSpread = -2;        // hcv_queue_probe.hip's verdict at creation: streams replaced, -1 = not run, -2 = not needed
         int mPinXcd = 0;                    // the XCD this engine's pinned tiny launches go to (hcv_kernels.h: xcd_pin_for); engines are spread over the eight
 

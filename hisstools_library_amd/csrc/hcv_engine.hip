@@ -97,6 +97,8 @@ bool Engine::fail(const char *what, hipError_t e)
     return false;
 }
 
+long long order_violations() { return order_mode() > 0 ? order_registry().violations.load() : -1; }
+
 Engine *Engine::create(const EngineCfg &cfg, std::string *err)
 {
     Engine *e = new Engine();
@@ -296,18 +298,33 @@ bool Engine::init(const EngineCfg &cfg)
     {
         Stage &pv = *mStages[mPivot];
         std::vector<hipStream_t *> roles;
-        static const int share_env = std::getenv("HCV_QUEUE_SHARE") ? std::atoi(std::getenv("HCV_QUEUE_SHARE")) : -2;
         int share = -1;
         if (pv.stream2)
         {
             roles.push_back(&pv.stream);
             roles.push_back(&pv.stream2);
             for (size_t k = mPivot + 1; k < mStages.size() && roles.size() < 4; k++) roles.push_back(&mStages[k]->stream);
-            share = share_env >= -1 ? std::min(share_env, (int) roles.size() - 1) : (int) roles.size() - 1;
+            share = (int) roles.size() - 1;
         }
         else if (pv.nxm_helped)
             roles.push_back(&mPipeStream);
         if (!roles.empty()) mStreamsSpread = spread_streams(mStream, roles.data(), (int) roles.size(), share);
+    }
+    if (order_mode() > 0)
+    {
+        // (HCV_ORDER_CHECK: this engine's streams by name; from here on every record / wait / declared access on them is followed)
+        mOrd = new OrderCheck();
+        order_register(mOrd, mStream, "main");
+        order_register(mOrd, mTdStream, "head");
+        order_register(mOrd, mInStream, "input");
+        order_register(mOrd, mCtlStream, "control");
+        order_register(mOrd, mPipeStream, "pipe");
+        static const char *stage_names[] = {"stage 0", "stage 1", "stage 2", "stage 3", "stage 4", "stage 5", "stage 6", "stage 7"};
+        for (size_t k = 0; k < mStages.size() && k < 8; k++)
+        {
+            order_register(mOrd, mStages[k]->stream, stage_names[k]);
+            if (mStages[k]->stream2) order_register(mOrd, mStages[k]->stream2, "pivot lane 2");
+        }
     }
     // Head through the FFT: the head's taps (<= one hop of the first FFT stage, MonoConvolve.cpp:235-240) form one extra,
     // zero-latency partition of that stage, whose input spectra exist anyway.  Used for hop-aligned blocks of larger
@@ -470,6 +487,12 @@ void Engine::free_stage(Stage &st)
 Engine::~Engine()
 {
     DeviceGuard dg(mDevice);
+    if (mOrd)
+    {
+        order_unregister(mOrd);
+        delete mOrd;
+        mOrd = nullptr;
+    }
     if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);
     if (mPipeStream) (void) hipStreamSynchronize(mPipeStream);
     if (mInStream) (void) hipStreamSynchronize(mInStream);
@@ -921,7 +944,7 @@ hipError_t Engine::ctl_alloc(void **p, size_t bytes)
                 return hipSuccess;
             }
         }
-    static const bool arena_debug = std::getenv("HCV_ARENA_DEBUG") != nullptr;
+    static const bool arena_debug = std::getenv("HCV_VERBOSE") != nullptr;
     if (arena_debug) std::fprintf(stderr, "[hcv arena] %zu bytes not served by the arena of device %d: stream-ordered pool\n", bytes, mDevice);
     hipMemPool_t pool = ctl_pool(mDevice);
     const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);

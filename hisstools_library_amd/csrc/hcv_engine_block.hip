@@ -678,13 +678,12 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // The n x m fused block (hcv_fused_nxm.hip): a steady-state one-hop block of a serial engine with several outputs whose last stage
     // is the reference's 16384-point tail with a lead slot — one rank's share of a strong-scaled matrix (64 x 8 of config 4 over 8 GPUs)
     // is the shape it was built for.  Forward transforms on the pipe stream, ONE multiply-accumulate + inverse launch on the main
-    // stream, no event between them (HCV_COOP_NXM = 0 / HCV_COOP = 0: the separate kernels).
+    // stream, no event between them (HCV_COOP = 0: the separate kernels).
     blk.nxm = false;
-    // Streamed engines (a GB and more of tail spectra) keep the separate kernels: measured with HCV_NXM_BIG = 1 on one box, 64 x 64 (512
+    // Streamed engines (a GB and more of tail spectra) keep the separate kernels: measured with the block forced on, one box, 64 x 64 (512
     // workgroups in two rounds) gains nothing with 2 s IRs (0.553 -> 0.551 ms per step) and loses 3 % with 10 s; c5's 16 x 16 / 703 partitions
     // (one round) ran 1.82 against 1.99 ms in one pair of runs and 1.94 / 1.95 against 1.92 / 1.99 in the next — both kernels stream at
     // 0.93 - 0.95 of what the box reads at all, and the difference is the box's own spread.
-    static const int nxm_big = std::getenv("HCV_NXM_BIG") ? std::atoi(std::getenv("HCV_NXM_BIG")) : 0;
     // The pivot stage of an extended ladder can take it (HCV_NXM_LADDER = 1; its hop then goes into the stage's timeline, which emit adds to
     // the rungs') but does not by default.  Measured, c5 on the ladder, ms per step: ONE lane 0.147 / 0.153 with it against 0.137 / 0.140
     // without (one workgroup per CU with most of its registers crowds the rungs' slices out while it runs); TWO lanes (enqueue_stage) as the
@@ -694,7 +693,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // lanes alone run 0.118 - 0.125 there (0.60 - 0.64 of HBM for the ladder's 601 MB per step), so that is the default.
     static const int nxm_ladder_env = std::getenv("HCV_NXM_LADDER") ? std::atoi(std::getenv("HCV_NXM_LADDER")) : 0;
     const bool nxm_ladder = nxm_ladder_env != 0;
-    if ((serial || nxm_big != 0 || (rungs && nxm_ladder)) && whole_hops && direct_in && (blk.direct_out || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
+    if ((serial || (rungs && nxm_ladder)) && whole_hops && direct_in && (blk.direct_out || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
         blk.full_matrix && mPipeStream && B == mStages[last]->M)
     {
         const Stage &tl = *mStages[last];
@@ -723,7 +722,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         }
         if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw && mBlockCount >= tl.nxm_off_until)
             blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan) &&
-                      (serial || nxm_big > 0 || rungs);
+                      (serial || rungs);
     }
     if (blk.nxm)
     {

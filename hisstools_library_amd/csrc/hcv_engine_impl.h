@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "hcv_order_check.h"         // (last: it routes the event / wait / synchronize calls of the engine's translation units through its hooks)
+
 namespace hcv
 {
 

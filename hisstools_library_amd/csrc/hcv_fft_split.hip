@@ -23,6 +23,7 @@
 
 #include "hcv_engine.h"
 #include "hcv_fft_split_device.h"
+#include "hcv_order_check.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -309,6 +310,7 @@ hipError_t launch_rifft_emit_split(int log2n, const float2 *Y, int ksplit, long 
                                    const float2 *tw, hipStream_t st, unsigned long long *started, int started_marks, unsigned long long started_seq)
 {
     const int lr = split_radix_log2(log2n);
+    ORD_ACCESS(st, Y, 0, 1, 0, false, "partial spectra (inverse transform)");
 #define HCV_SPLIT_I(LN, LR) if (log2n == LN && lr == LR) return launch_rifft_split_t<LN, LR>(Y, ksplit, ks_stride, T, nout, out, out_stride, tw, st, started, started_marks, started_seq)
     HCV_SPLIT_I(14, 4); HCV_SPLIT_I(12, 3);
 #undef HCV_SPLIT_I

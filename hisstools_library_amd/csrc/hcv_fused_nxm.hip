@@ -42,6 +42,7 @@
 
 #include "hcv_engine.h"
 #include "hcv_fft_frames_device.h"
+#include "hcv_order_check.h"
 
 #include <algorithm>
 #include <atomic>
@@ -300,8 +301,7 @@ namespace
 
     bool nxm_enabled()
     {
-        static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0) &&
-                               !(std::getenv("HCV_COOP_NXM") && std::atoi(std::getenv("HCV_COOP_NXM")) == 0);
+        static const bool on = !(std::getenv("HCV_COOP") && std::atoi(std::getenv("HCV_COOP")) == 0);
         return on;
     }
 }
@@ -319,8 +319,6 @@ bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, F
     // (one workgroup per CU, all of them resident at once: with 512 of them in two rounds — and twice the partial spectra for the inverse to add
     // up — the 64 x 8 block took 0.085 ms against 0.083; with 128, half the CUs idle, 0.097)
     while (base * ms * 2 <= 256 && K / (kNxmWaves * ms * 2) >= 6 && (size_t) (ms * 2) * nout * M <= y_elems && ms * 2 <= 8) ms *= 2;
-    static const int ms_env = std::getenv("HCV_NXM_MS") ? std::atoi(std::getenv("HCV_NXM_MS")) : 0;      // (A/B aid)
-    if (ms_env > 0) ms = ms_env;
     if ((size_t) ms * nout * M > y_elems || nin > kFusedFwdTasks) return false;
     pl->ms = ms;
     pl->tiles = tiles;
@@ -349,6 +347,13 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) allowed[dev].store(true, std::memory_order_release);
     }
+    // (HCV_ORDER_CHECK: the forward launch's accesses on its stream, then the hand-over the counters make, then the meeting launch's)
+    ORD_ACCESS(fwd_stream, hist, (h - 1) * (long long) M, h * (long long) M, hist_mask + 1, false, "history ring (the hop before the caller's block)");
+    ORD_ACCESS(fwd_stream, hist, n0, n0 + (long long) M, hist_mask + 1, true, "history ring (the caller's block filed by the forward launch)");
+    ORD_ACCESS(fwd_stream, X, h, h + 1, (long long) Rring, true, "input-spectrum ring slot (n x m forward launch)");
+    ORD_MEET(fwd_stream, st);
+    ORD_ACCESS(st, X, std::max<long long>(0, h - (P - 1)), h + 1, (long long) Rring, false, "input-spectrum ring slots (n x m multiply-accumulate)");
+    ORD_ACCESS(st, Y, 0, 1, 0, true, "partial spectra (n x m multiply-accumulate)");
     FusedNxmParams a;
     a.hist = hist; a.in = in; a.X = X; a.H = H; a.Y = Y; a.tw = tw;
     a.hist_stride = hist_stride; a.in_stride = in_stride; a.hist_mask = hist_mask; a.n0 = n0; a.h = h;
@@ -362,8 +367,7 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     // (a forward launch is normally through tens of microseconds before it is needed: a shorter wait than the one-output blocks' — ~0.1 ms —
     // before the multiply-accumulate's workgroups do the transforms themselves)
     a.sy.spin = std::min(a.sy.spin, 256);
-    static const bool hint_on = !(std::getenv("HCV_NXM_HINT") && std::atoi(std::getenv("HCV_NXM_HINT")) == 0);
-    a.hint_wait = (chained && hint_on && out) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
+    a.hint_wait = (chained && out) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
     hipLaunchKernelGGL((fwd_publish_kernel<LOG2N>), dim3(pl.nfwd), dim3(64 * kNxmWaves), lds_fwd, fwd_stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;                          // (nothing ran: the counters stand where they stood)

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "hcv_fft_frames_device.h"
+#include "hcv_order_check.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -876,6 +877,11 @@ hipError_t launch_rfft_frames(int log2n, const float *hist, long long hist_strid
                               float2 *X, int R, const float2 *tw, const BigFFTWork *big, hipStream_t st)
 {
     if (T <= 0 || nin <= 0) return hipSuccess;
+    {
+        const long long M_ = 1ll << (log2n - 1);
+        ORD_ACCESS(st, hist, (h_first - 1) * M_, (h_first + T) * M_, hist_mask + 1, false, "history ring (frames of a forward transform)");
+        ORD_ACCESS(st, X, h_first, h_first + T, (long long) R, true, "input-spectrum ring slots (forward transform)");
+    }
     if (is_big_fft(log2n)) return big ? big_rfft_frames(log2n, hist, hist_stride, hist_mask, h_first, T, nin, X, R, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
@@ -893,6 +899,12 @@ hipError_t launch_rfft_frames_direct(int log2n, float *hist, long long hist_stri
 {
     if (T <= 0 || nin <= 0) return hipSuccess;
     if (is_big_fft(log2n)) return hipErrorInvalidValue;
+    {
+        const long long M_ = 1ll << (log2n - 1);
+        ORD_ACCESS(st, hist, (h_first - 1) * M_, h_first * M_, hist_mask + 1, false, "history ring (the hop before the caller's block)");
+        ORD_ACCESS(st, hist, n0, n0 + (long long) T * M_, hist_mask + 1, true, "history ring (the caller's block filed by the forward transform)");
+        ORD_ACCESS(st, X, h_first, h_first + T, (long long) R, true, "input-spectrum ring slots (forward transform)");
+    }
     if (fft_split_applies(log2n, T * nin)) return launch_rfft_frames_direct_split(log2n, hist, hist_stride, hist_mask, in, in_stride, n0, h_first, T, nin, X, R, tw, st);
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
@@ -956,6 +968,11 @@ hipError_t launch_rifft_overlap_add(int log2n, const float2 *Y, int ksplit, long
                                     float *timeline, long long tl_stride, long long tl_mask, const float2 *tw, const BigFFTWork *big, hipStream_t st)
 {
     if (T <= 0 || nout <= 0) return hipSuccess;
+    {
+        const long long M_ = 1ll << (log2n - 1);
+        ORD_ACCESS(st, Y, 0, 1, 0, false, "partial spectra (inverse transform)");
+        ORD_ACCESS(st, timeline, (h_first + 1) * M_, (h_first + 1 + T) * M_, tl_mask + 1, true, "stage timeline (overlap-add)");
+    }
     if (is_big_fft(log2n))      // the caller has already reduced the split-K partials (ksplit == 1)
         return (big && ksplit == 1) ? big_rifft_overlap_add(log2n, Y, h_first, T, nout, timeline, tl_stride, tl_mask, tw, *big, st) : hipErrorInvalidValue;
     HCV_FFT_DISPATCH(log2n - 1, {
@@ -975,6 +992,7 @@ hipError_t launch_rifft_emit(int log2n, const float2 *Y, int ksplit, long long k
 {
     if (T <= 0 || nout <= 0) return hipSuccess;
     if (is_big_fft(log2n)) return hipErrorInvalidValue;
+    ORD_ACCESS(st, Y, 0, 1, 0, false, "partial spectra (inverse transform)");
     if (fft_split_applies(log2n, T * nout)) return launch_rifft_emit_split(log2n, Y, ksplit, ks_stride, T, nout, out, out_stride, tw, st);
     HCV_FFT_DISPATCH(log2n - 1, {
         using Gm = FFTGeom<L>;
@@ -992,6 +1010,8 @@ hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, lo
     if (elems <= 0 || ksplit < 1) return hipSuccess;
     if (!dst) dst = Y;
     if (ksplit == 1 && dst == Y) return hipSuccess;            // (one slice elsewhere: the launch is the copy)
+    ORD_ACCESS(st, Y, 0, 1, 0, dst == Y, "partial spectra (reduction)");
+    if (dst != Y) ORD_ACCESS(st, dst, 0, 1, 0, true, "partial spectra (reduction's sum)");
     const long long n4 = elems / 2;
     const int grid = (int) ((n4 + 255) / 256);
     const int pin = xcd_pin_for(grid);
@@ -1027,6 +1047,10 @@ hipError_t launch_fir_head(const float *hist, long long hist_stride, long long h
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
     if (ring && !(emit && din)) return hipErrorInvalidValue;
+    ORD_ACCESS(st, hist, n0 - Lpad, din ? n0 : n0 + B, hist_mask + 1, false, "history ring (time-domain head)");
+    if (ring) ORD_ACCESS(st, ring, n0, n0 + B, hist_mask + 1, true, "history ring (a plain small call files its samples)");
+    if (emit)
+        for (int k_ = 0; k_ < emit->count; k_++) ORD_ACCESS(st, emit->timeline[k_], n0, n0 + B, emit->mask[k_] + 1, true, "stage timeline (read and cleared by a plain small call)");
     if (emit && !fir_head_is_small(B, nin, Lpad, diag)) return hipErrorInvalidValue;
     // small calls of matrices with several inputs: taps split over the threads, a batch of inputs staged at once (HCV_FIR_SMALL = 0:
     // the general kernel everywhere)
@@ -1071,6 +1095,7 @@ hipError_t launch_scatter_input(const float *in, long long in_stride, int B, int
                                 long long n0, hipStream_t st)
 {
     if (B <= 0 || nin <= 0) return hipSuccess;
+    ORD_ACCESS(st, hist, n0, n0 + B, hist_mask + 1, true, "history ring (scatter)");
     dim3 grid(std::min((B + 255) / 256, 64), nin);
     hipLaunchKernelGGL(scatter_input_kernel, grid, dim3(256), 0, st, in, in_stride, B, hist, hist_stride, hist_mask, n0);
     return hipGetLastError();
@@ -1080,6 +1105,7 @@ hipError_t launch_emit(const EmitSources &src, long long n0, int B, int nout, co
                        long long out_stride, hipStream_t st)
 {
     if (B <= 0 || nout <= 0) return hipSuccess;
+    for (int k_ = 0; k_ < src.count; k_++) ORD_ACCESS(st, src.timeline[k_], n0, n0 + B, src.mask[k_] + 1, true, "stage timeline (read and cleared by emit)");
     dim3 grid(std::min((B + 255) / 256, 64), nout);
     hipLaunchKernelGGL(emit_kernel, grid, dim3(256), 0, st, src, n0, B, td, td_stride, out, out_stride);
     return hipGetLastError();

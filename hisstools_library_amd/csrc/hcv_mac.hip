@@ -28,6 +28,7 @@
 #include "hcv_kernels.h"
 #include "hcv_fft_device.h"
 #include "hcv_mac_params.h"
+#include "hcv_order_check.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -354,6 +355,8 @@ hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float
                                long long h_first, bool check, hipStream_t st)
 {
     if (s.T <= 0 || s.nout <= 0) return hipSuccess;
+    ORD_ACCESS(st, X, std::max<long long>(0, h_first - (s.P - 1)), h_first + s.T, (long long) s.R, false, "input-spectrum ring slots (multiply-accumulate)");
+    ORD_ACCESS(st, Y, 0, 1, 0, true, "partial spectra (multiply-accumulate)");
     MacParams a;
     a.X = reinterpret_cast<const float4 *>(X);
     a.H = reinterpret_cast<const float4 *>(H);

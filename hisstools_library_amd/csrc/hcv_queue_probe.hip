@@ -170,7 +170,7 @@ int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
         c.made = false;                                             // (taken: not the cleanup's any more)
         replaced++;
     }
-    if (std::getenv("HCV_QUEUE_PROBE_DEBUG"))
+    if (std::getenv("HCV_VERBOSE"))
     {
         std::fprintf(stderr, "[hcv] queue probe: %zu queues seen, %d of %d busy streams placed, %d replaced; classes:", reps.size(), served, n, replaced);
         for (int r = 0; r < n; r++) std::fprintf(stderr, " %d", pick[r] >= 0 ? cands[pick[r]].cls : -1);

@@ -68,6 +68,10 @@ HCV_API const char *hcv_last_error(void);                 /* thread-local text o
  * (returns -1 once one exists); hcv_ctl_reserved reports what the device holds (0: no arena yet / none). */
 HCV_API int hcv_ctl_reserve(int device, size_t bytes);
 HCV_API size_t hcv_ctl_reserved(int device);
+/* HCV_ORDER_CHECK=1 (debug aid, MI355X extension): while the engines enqueue, the order DESIGN.md section 2 states — program order on a
+ * stream, event records and waits, ring depths — is followed with vector clocks and every declared buffer access checked against it;
+ * a violation is reported on stderr.  Returns the number of violations so far in this process, -1 when the check is off. */
+HCV_API long long hcv_order_check_violations(void);
 
 /* ---------------------------------------------------------------- HISSTools_FFT (float real transforms on the path)
  * hisstools_rfft 5-arg  HISSTools_FFT.cpp:226-230   (zero-padding unzip + real FFT, output x2, vDSP packing)

@@ -9,7 +9,7 @@ Every case runs in a child process under a hard timeout (the launches spin-wait 
 box) with DENSE decaying-noise impulse responses on every pair, against the CPU oracle (bit-identical to the unmodified reference
 on the golden vectors).  Tolerance: 1e-5 of the channel's peak (many-input sums).  HCV_COOP_SPIN=0 makes every
 in-launch wait run out at once, so the helping path — the multiply-accumulate workgroups doing the forward transforms themselves —
-computes the block: the same bits.  HCV_COOP_NXM=0 takes the separate kernels: the same stream to rounding.
+computes the block: the same bits.  HCV_COOP=0 takes the separate kernels: the same stream to rounding.
 """
 import json
 import os
@@ -39,7 +39,7 @@ def test_64x8_dense_vs_oracle_host_calls():
     r = _run(64, 8, 96000, 16, "host")
     assert r["max_err"] < TOL and r["tail_err"] < TOL, r
     assert r["fused_launches"] >= 3, r                      # the steady-state blocks took the fused launch, not the four-launch chain
-    off = _run(64, 8, 96000, 16, "host", extra_env={"HCV_COOP_NXM": "0"})
+    off = _run(64, 8, 96000, 16, "host", extra_env={"HCV_COOP": "0"})
     assert off["fused_launches"] == 0 and off["max_err"] < TOL, off
 
 

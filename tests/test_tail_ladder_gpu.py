@@ -100,7 +100,7 @@ def test_busy_streams_are_placed_on_hardware_queues_at_creation():
            "torch.cuda.synchronize()\n")
     for code in (STREAM.replace("BLOCKS", "8192"), pre + STREAM.replace("BLOCKS", "8192")):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT,
-                             env=dict(os.environ, HCV_TAIL_RATIO="8", HCV_QUEUE_PROBE_DEBUG="1"))
+                             env=dict(os.environ, HCV_TAIL_RATIO="8", HCV_VERBOSE="1"))
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
         r = json.loads(out.stdout.strip().splitlines()[-1])
         assert r["err"] <= TOL, r

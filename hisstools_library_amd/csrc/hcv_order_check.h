@@ -94,8 +94,9 @@ public:
         }
         else if (ring > 0)
         {
+            const long long len = hi - lo;
             lo = ((lo % ring) + ring) % ring;
-            hi = lo + (hi - lo);
+            hi = lo + len;
         }
         std::deque<Acc> &h = mHist[buf];
         for (const Acc &a : h)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "hcv_ctl_reserve": (C.c_int, [C.c_int, C.c_size_t]),
     "hcv_ctl_reserved": (C.c_size_t, [C.c_int]),
     "hcv_order_check_violations": (C.c_longlong, []),
+    "hcv_debug_native_backtrace_on_crash": (None, []),
     "hcv_get_default_device": (C.c_int, []),
     "hcv_last_error": (C.c_char_p, []),
     "hcv_rfft_f32": (C.c_int, [f32p, usz, usz, usz, C.c_uint, f32p, f32p]),

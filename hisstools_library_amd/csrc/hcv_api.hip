@@ -1684,4 +1684,41 @@ extern "C" int hcv_ctl_reserve(int device, size_t bytes)
 }
 extern "C" size_t hcv_ctl_reserved(int device) { return hcv::ctl_arena_size(device); }
 extern "C" long long hcv_order_check_violations(void) { return hcv::order_violations(); }
+
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace
+{
+struct sigaction gPrevAct[3];
+const int gCrashSigs[3] = {SIGSEGV, SIGABRT, SIGBUS};
+void crash_backtrace(int sig, siginfo_t *info, void *ctx)
+{
+    static const char head[] = "\n[hcv] native call stack of the thread that took the signal:\n";
+    (void) !write(2, head, sizeof(head) - 1);
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    for (int k = 0; k < 3; k++)
+        if (gCrashSigs[k] == sig)
+        {
+            sigaction(sig, &gPrevAct[k], nullptr);      // (the previous owner — Python's faulthandler — gets the re-raised signal)
+            break;
+        }
+    (void) info;
+    (void) ctx;
+    raise(sig);
+}
+}  // namespace
+extern "C" void hcv_debug_native_backtrace_on_crash(void)
+{
+    for (int k = 0; k < 3; k++)
+    {
+        struct sigaction sa = {};
+        sa.sa_sigaction = crash_backtrace;
+        sa.sa_flags = SA_SIGINFO | SA_NODEFER | SA_ONSTACK;
+        sigemptyset(&sa.sa_mask);
+        sigaction(gCrashSigs[k], &sa, &gPrevAct[k]);
+    }
+}
 extern "C" const char *hcv_last_error(void) { return tlsError.c_str(); }

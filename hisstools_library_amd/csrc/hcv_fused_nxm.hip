@@ -66,6 +66,8 @@ struct FusedNxmParams
     int ms, tiles, kper_old;                    // k-slice groups (partial spectra per output), output tiles of 8, (i, p >= 1) terms per wave
     unsigned long long *hint;                   // [kNxmHints] marks 128 bytes apart: "inverse workgroup m of launch `seq` has started"
     int hint_wait;                              // > 0: the forward launch holds itself back until the PREVIOUS block's inverse has started (marks to look at)
+    unsigned long long *progress;               // the sequence number of the newest multiply-accumulate launch whose first workgroup is through (see
+                                                // fwd_publish_kernel: a forward launch that arrives four blocks late keeps its hands off the rings)
     unsigned *helped;                           // host memory (mapped): launches whose wait for the forward transforms ran out — the engine's cue to
                                                 // take the separate kernels for a while (enqueue_stage)
 };
@@ -76,7 +78,8 @@ namespace
 {
     constexpr int kNxmLog2N = 14, kNxmOT = 8, kNxmWaves = 8;
     constexpr int kNxmHints = 64, kNxmHintStride = 16, kNxmHintBase = 8192;     // (inside the stage's flag array, behind the forward tasks' marks)
-    static_assert(kNxmHintBase + kNxmHints * kNxmHintStride <= kFusedFwdTasks, "");
+    constexpr int kNxmProgress = kNxmHintBase + (kNxmHints + 1) * kNxmHintStride;      // (a line of its own behind the hint marks)
+    static_assert(kNxmProgress + kNxmHintStride <= kFusedFwdTasks, "");
 
     // The forward transform of input i's new frame, whole, by one thread group of 512: the engine's own whole-frame transform
     // (hcv_kernels.hip: rfft_frames_direct_kernel — LDS Stockham, the new hop read from the caller's block and filed in the history ring
@@ -89,6 +92,14 @@ namespace
         const DirectFrameLoadT<true> ld = { a.hist + (long long) i * a.hist_stride, a.in + (long long) i * a.in_stride, (a.h - 1) * (long long) M, a.hist_mask, a.n0, M / 2, true };
         LdsFFT<LOG2M, TG>::run(ld, LdsIO<float2>{ s }, s, tid, a.tw);
         real_post_store<LOG2M, TG, true>(s, tid, a.tw, a.X + ((long long) i * a.Rring + a.slot) * M);
+    }
+
+    // (test aid, HCV_NXM_TEST_DELAY_US: holds the forward stream back in front of every forward launch — the stream stuck behind other
+    // engines' packets, made to order)
+    __global__ void nxm_delay_kernel(unsigned long long ticks)
+    {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
     }
 
     // One workgroup of the forward kernel = input i (task i, the helping path's numbering)
@@ -116,7 +127,18 @@ namespace
             }
             __syncthreads();
         }
-        forward_frame<LOG2N>(a, dynf, tid, task);
+        // Nothing makes the MAIN stream wait for this one: a multiply-accumulate launch whose wait runs out does the transforms itself and
+        // goes on, so with this stream held up — behind other engines' packets in a shared hardware queue — the main stream can be blocks
+        // ahead when this launch finally runs, and its transform would then file an OLD hop over a newer one in the history ring (eight
+        // hops deep) and an old spectrum into a ring slot that has come round.  The main stream says how far it is (mac_meet_kernel's first
+        // workgroup, as it ends); a workgroup that finds it four blocks past its own block — everything that could read this block's
+        // spectrum as NEW is long through, the helpers have written every value this launch would write — only counts itself in.
+        // (tests/test_fused_nxm_gpu.py::test_four_engines_at_once with every wait forced out: one run in some dozens gave garbage once the
+        // forward stream no longer shared the main stream's queue.)
+        __shared__ int stale_b;
+        if (tid == 0) stale_b = (long long) (__hip_atomic_load(a.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (a.sy.seq + 4)) >= 0;
+        __syncthreads();
+        if (!stale_b) forward_frame<LOG2N>(a, dynf, tid, task);
         grid_publish_sharded(tid, a.sy.flagF + task, a.sy.seq, a.sy.bar, task);
     }
 
@@ -280,6 +302,7 @@ namespace
         NxmMac<LOG2N> b = { *ka, dyn, tid, nyq };
         b.mac_old(m);
         b.mac_new(m);
+        if (m == 0 && tid == 0) __hip_atomic_store(ka->progress, sy.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     template <int LOG2N>
@@ -297,6 +320,7 @@ namespace
             return;
         }
         b.mac_new(m);
+        if (m == 0 && tid == 0) __hip_atomic_store(a.progress, a.sy.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (how far the main stream is: fwd_publish_kernel)
     }
 
     bool nxm_enabled()
@@ -363,11 +387,14 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     a.ms = pl.ms; a.tiles = pl.tiles; a.kper_old = pl.kper_old;
     a.sy = fused_sync_sharded(bar, flags, arrived, *seq, (unsigned) pl.nfwd);
     a.hint = flags + kNxmHintBase;
+    a.progress = flags + kNxmProgress;
     a.helped = fused_spin() > 0 ? helped : nullptr;      // (HCV_COOP_SPIN=0 is the test suite's way to run the helping path on purpose)
     // (a forward launch is normally through tens of microseconds before it is needed: a shorter wait than the one-output blocks' — ~0.1 ms —
     // before the multiply-accumulate's workgroups do the transforms themselves)
     a.sy.spin = std::min(a.sy.spin, 256);
     a.hint_wait = (chained && out) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
+    static const int test_delay_us = std::getenv("HCV_NXM_TEST_DELAY_US") ? std::atoi(std::getenv("HCV_NXM_TEST_DELAY_US")) : 0;
+    if (test_delay_us > 0) hipLaunchKernelGGL(nxm_delay_kernel, dim3(1), dim3(64), 0, fwd_stream, (unsigned long long) test_delay_us * 100ull);
     hipLaunchKernelGGL((fwd_publish_kernel<LOG2N>), dim3(pl.nfwd), dim3(64 * kNxmWaves), lds_fwd, fwd_stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;                          // (nothing ran: the counters stand where they stood)

@@ -72,6 +72,9 @@ HCV_API size_t hcv_ctl_reserved(int device);
  * stream, event records and waits, ring depths — is followed with vector clocks and every declared buffer access checked against it;
  * a violation is reported on stderr.  Returns the number of violations so far in this process, -1 when the check is off. */
 HCV_API long long hcv_order_check_violations(void);
+/* Debug aid: on SIGSEGV / SIGABRT / SIGBUS print the faulting thread's native call stack to stderr (glibc backtrace), then hand the signal
+ * on to whoever had it before (Python's faulthandler, the default action).  tests/conftest.py installs it when HCV_NATIVE_BACKTRACE=1. */
+HCV_API void hcv_debug_native_backtrace_on_crash(void);
 
 /* ---------------------------------------------------------------- HISSTools_FFT (float real transforms on the path)
  * hisstools_rfft 5-arg  HISSTools_FFT.cpp:226-230   (zero-padding unzip + real FFT, output x2, vDSP packing)

@@ -19,6 +19,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # HCV_NATIVE_BACKTRACE=1: should the process die of a signal, the faulting thread's native call stack goes to stderr in front of
+    # faulthandler's Python stacks (a crash in a runtime thread shows no Python frame at all)
+    if os.environ.get("HCV_NATIVE_BACKTRACE"):
+        import faulthandler
+        faulthandler.enable()
+        import hisstools_library_amd as H
+        H.load().hcv_debug_native_backtrace_on_crash()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle bindings (builds oracle/libhcv_oracle.so on first use)."""

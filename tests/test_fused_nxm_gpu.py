@@ -73,3 +73,19 @@ def test_four_engines_at_once():
     assert r["max_err"] < TOL and r["all_same"] and r["fused_launches"] >= 3, r
     h = _run(16, 8, 48000, 16, "many", engines=4, extra_env={"HCV_COOP_SPIN": "0"})
     assert h["max_err"] < TOL and h["all_same"] and h["sha"] == r["sha"], (h, r)
+
+
+def test_a_forward_stream_that_falls_blocks_behind_keeps_off_the_rings():
+    """Nothing makes the main stream wait for the forward stream: a multiply-accumulate launch whose wait runs out does the transforms
+    itself and goes on.  With the forward stream held back 0.3 ms in front of every launch (HCV_NXM_TEST_DELAY_US, a test aid: the
+    stream stuck behind other engines' packets) and no wait granted at all, the main stream is a dozen blocks ahead when the forward
+    launches arrive — late launches that would file an old hop over a newer one in the history ring and an old spectrum into a ring
+    slot that has come round.  They must notice and keep off (fwd_publish_kernel: `progress`): the same bits as the undisturbed run."""
+    r = _run(16, 8, 96000, 40, "dev")
+    assert r["max_err"] < TOL and r["all_same"], r
+    d = _run(16, 8, 96000, 40, "dev", extra_env={"HCV_COOP_SPIN": "0", "HCV_NXM_TEST_DELAY_US": "300"})
+    assert d["max_err"] < TOL and d["all_same"] and d["sha"] == r["sha"] and d["fused_launches"] >= 20, (d, r)
+    # (and with the ordinary bounded waits: three launches whose wait ran out and the stage stands the block down for the separate kernels —
+    # hcv_stage_stats.fused_stood_down — so the repetitions agree to rounding, not bit for bit)
+    s = _run(16, 8, 96000, 40, "dev", extra_env={"HCV_NXM_TEST_DELAY_US": "300"})
+    assert s["max_err"] < TOL, (s, r)

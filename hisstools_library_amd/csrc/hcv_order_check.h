@@ -11,7 +11,9 @@
 // those clocks.  Anything else is reported on stderr and counted (hcv_order_check_violations()); HCV_ORDER_CHECK=2 aborts at the first.
 //
 // What it does not see: hand-overs inside a launch (the fused blocks' counters; the n x m block's two launches are joined by ORD_MEET where
-// the counters join them), other engines' streams, and knowledge one host thread gains by synchronizing (taken as everybody's).
+// the counters join them — the other direction of that pair, a forward launch that arrives blocks late, is settled on the device by
+// fwd_publish_kernel's look at `progress` and is outside this model), other engines' streams, and knowledge one host thread gains by
+// synchronizing (taken as everybody's).
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -15,6 +15,7 @@ namespace
 {
     struct CtlArena;
     CtlArena *arena_of(int device, bool create);       // the device's control arena (below, with ctl_alloc)
+    void arena_reap_all(int device);                   // every parked block of the device's arena back to its free list, waiting for their events
 }
 
 static int ilog2(uint64_t v)
@@ -526,6 +527,10 @@ Engine::~Engine()
     if (mPinOut) (void) hipHostFree(mPinOut);
     if (mIrBuf) ctl_free(mIrBuf);
     if (mCtlStream) (void) hipStreamSynchronize(mCtlStream);        // the stream-ordered frees above have run
+    // (... and the arena blocks parked behind events recorded on that stream go back NOW: an event must not outlive the stream it was
+    // recorded on — a later query reaches into the destroyed stream's signal pool.  Suspected in two full-suite runs that died inside
+    // the create / destroy cycles of tests/test_gpu_parity.py, one with an abort in a destructor, one with a fault on a runtime thread.)
+    arena_reap_all(mDevice);
     if (mTaps) (void) hipFree(mTaps);
     if (mHeadSpec) (void) hipFree(mHeadSpec);
     for (int k = 0; k < 2; k++)
@@ -907,6 +912,18 @@ namespace
         }
         gArenas[device] = a;
         return a;
+    }
+}
+
+namespace
+{
+    void arena_reap_all(int device)
+    {
+        if (CtlArena *a = arena_of(device, false))
+        {
+            std::lock_guard<std::mutex> g(a->mtx);
+            a->reap(true);
+        }
     }
 }
 

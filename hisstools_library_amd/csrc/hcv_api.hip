@@ -1686,19 +1686,21 @@ extern "C" size_t hcv_ctl_reserved(int device) { return hcv::ctl_arena_size(devi
 extern "C" long long hcv_order_check_violations(void) { return hcv::order_violations(); }
 
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <unistd.h>
 namespace
 {
 struct sigaction gPrevAct[3];
+int gCrashFd = 2;           // HCV_NATIVE_BACKTRACE=<path with a slash>: a file of its own (pytest captures descriptor 2 while a test runs)
 const int gCrashSigs[3] = {SIGSEGV, SIGABRT, SIGBUS};
 void crash_backtrace(int sig, siginfo_t *info, void *ctx)
 {
     static const char head[] = "\n[hcv] native call stack of the thread that took the signal:\n";
-    (void) !write(2, head, sizeof(head) - 1);
+    (void) !write(gCrashFd, head, sizeof(head) - 1);
     void *frames[64];
     const int n = backtrace(frames, 64);
-    backtrace_symbols_fd(frames, n, 2);
+    backtrace_symbols_fd(frames, n, gCrashFd);
     for (int k = 0; k < 3; k++)
         if (gCrashSigs[k] == sig)
         {
@@ -1712,6 +1714,12 @@ void crash_backtrace(int sig, siginfo_t *info, void *ctx)
 }  // namespace
 extern "C" void hcv_debug_native_backtrace_on_crash(void)
 {
+    if (const char *p = std::getenv("HCV_NATIVE_BACKTRACE"))
+        if (std::strchr(p, '/'))
+        {
+            const int fd = open(p, O_WRONLY | O_CREAT | O_APPEND, 0644);
+            if (fd >= 0) gCrashFd = fd;
+        }
     for (int k = 0; k < 3; k++)
     {
         struct sigaction sa = {};

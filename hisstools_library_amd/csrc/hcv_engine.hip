@@ -98,6 +98,35 @@ bool Engine::fail(const char *what, hipError_t e)
     return false;
 }
 
+namespace
+{
+    std::mutex gStreamPoolMutex;
+    std::map<int, std::vector<hipStream_t>> gStreamPool;             // per device: idle streams
+}
+
+hipError_t stream_take(int device, hipStream_t *s)
+{
+    {
+        std::lock_guard<std::mutex> g(gStreamPoolMutex);
+        std::vector<hipStream_t> &pool = gStreamPool[device];
+        if (!pool.empty())
+        {
+            *s = pool.back();
+            pool.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+// (the caller has synchronized the stream, or never used it)
+void stream_give(int device, hipStream_t s)
+{
+    if (!s) return;
+    std::lock_guard<std::mutex> g(gStreamPoolMutex);
+    gStreamPool[device].push_back(s);
+}
+
 long long order_violations() { return order_mode() > 0 ? order_registry().violations.load() : -1; }
 
 Engine *Engine::create(const EngineCfg &cfg, std::string *err)
@@ -175,14 +204,14 @@ bool Engine::init(const EngineCfg &cfg)
         nmax = std::max(nmax, sc.fft_size);
     }
 
-    HCV_TRY(hipStreamCreateWithFlags(&mStream, hipStreamNonBlocking));
+    HCV_TRY(stream_take(mDevice, &mStream));
     mOneStream = one_stream_mode(mCfg);
     if (mOneStream)
         mTdStream = mInStream = mStream;
     else
     {
-        HCV_TRY(hipStreamCreateWithFlags(&mTdStream, hipStreamNonBlocking));
-        HCV_TRY(hipStreamCreateWithFlags(&mInStream, hipStreamNonBlocking));
+        HCV_TRY(stream_take(mDevice, &mTdStream));
+        HCV_TRY(stream_take(mDevice, &mInStream));
     }
     for (int k = 0; k < 2; k++)
     {
@@ -193,11 +222,11 @@ bool Engine::init(const EngineCfg &cfg)
     HCV_TRY(hipEventCreateWithFlags(&mEvCtl, hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvSerial, hipEventDisableTiming));
     // control work that must not delay the audio thread (IR upload + FFTs into staging, capacity growth) has its own stream
-    HCV_TRY(hipStreamCreateWithFlags(&mCtlStream, hipStreamNonBlocking));
+    HCV_TRY(stream_take(mDevice, &mCtlStream));
     HCV_TRY(hipEventCreateWithFlags(&mEvSwapDone, hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvSnap, hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvHostDone, hipEventDisableTiming));
-    HCV_TRY(hipStreamCreateWithFlags(&mPipeStream, hipStreamNonBlocking));
+    HCV_TRY(stream_take(mDevice, &mPipeStream));
     for (int k = 0; k < 2; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipe[k], hipEventDisableTiming));
     for (int k = 0; k < 4; k++) HCV_TRY(hipEventCreateWithFlags(&mEvPipeEnd[k], hipEventDisableTiming));
     HCV_TRY(hipEventCreateWithFlags(&mEvFwd, hipEventDisableTiming));
@@ -418,10 +447,10 @@ bool Engine::alloc_stage(Stage &st)
         st.stream = mStream;
     else
     {
-        HCV_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking));
+        HCV_TRY(stream_take(mDevice, &st.stream));
         // (the second lane of an extended ladder's pivot stage: created where the layout has rungs behind this stage)
         static const bool two_lanes = !(std::getenv("HCV_PIVOT_LANES") && std::atoi(std::getenv("HCV_PIVOT_LANES")) == 1);
-        if (two_lanes && st.lead && mCfg.pivot >= 0 && (size_t) mCfg.pivot + 1 < mCfg.stages.size()) HCV_TRY(hipStreamCreateWithFlags(&st.stream2, hipStreamNonBlocking));
+        if (two_lanes && st.lead && mCfg.pivot >= 0 && (size_t) mCfg.pivot + 1 < mCfg.stages.size()) HCV_TRY(stream_take(mDevice, &st.stream2));
     }
     for (int k = 0; k < 2; k++)
     {
@@ -474,8 +503,8 @@ void Engine::free_stage(Stage &st)
     st.big.a = st.big.b = st.big_ctl.a = st.big_ctl.b = nullptr;
     for (int k = 0; k < 2; k++)
         if (st.done[k]) (void) hipEventDestroy(st.done[k]);
-    if (st.stream && st.stream != mStream) (void) hipStreamDestroy(st.stream);
-    if (st.stream2) (void) hipStreamDestroy(st.stream2);
+    if (st.stream && st.stream != mStream) stream_give(mDevice, st.stream);
+    if (st.stream2) stream_give(mDevice, st.stream2);
     st.stream2 = nullptr;
     st.Hs = st.X = st.Y = nullptr;
     st.stream = nullptr;
@@ -553,8 +582,8 @@ Engine::~Engine()
     if (mStageTaps) (void) hipFree(mStageTaps);
     if (mStageHead) (void) hipFree(mStageHead);
     if (mStageTailHead) (void) hipFree(mStageTailHead);
-    if (mCtlStream) (void) hipStreamDestroy(mCtlStream);
-    if (mPipeStream) (void) hipStreamDestroy(mPipeStream);
+    if (mCtlStream) stream_give(mDevice, mCtlStream);
+    if (mPipeStream) stream_give(mDevice, mPipeStream);
     for (int k = 0; k < 2; k++)
     {
         if (mEvPipe[k]) (void) hipEventDestroy(mEvPipe[k]);
@@ -565,9 +594,9 @@ Engine::~Engine()
     if (mRetireTmp) (void) hipFree(mRetireTmp);
     if (mGhostPin) (void) hipHostFree(mGhostPin);
     if (mGhostUploaded) (void) hipEventDestroy(mGhostUploaded);
-    if (mInStream && mInStream != mStream) (void) hipStreamDestroy(mInStream);
-    if (mTdStream && mTdStream != mStream) (void) hipStreamDestroy(mTdStream);
-    if (mStream) (void) hipStreamDestroy(mStream);
+    if (mInStream && mInStream != mStream) stream_give(mDevice, mInStream);
+    if (mTdStream && mTdStream != mStream) stream_give(mDevice, mTdStream);
+    if (mStream) stream_give(mDevice, mStream);
 }
 
 uint64_t Engine::stage_capacity(size_t s) const

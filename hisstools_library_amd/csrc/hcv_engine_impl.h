@@ -17,6 +17,13 @@ namespace hcv
 // hcv_queue_probe.hip: fresh streams swapped until they feed different hardware queues (roles[share] the anchor's own)
 int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share);
 
+// hcv_engine.hip: the engines' streams come from a per-device pool and go back to it, idle, when their engine goes — never destroyed.  A
+// stream is a queue handle: an idle one carries nothing over.  Creating and destroying a dozen streams per engine was where two full-suite
+// runs and two knob-matrix runs died (glibc abort on a free inside hipStreamDestroy, no heap error in the instrumented host code under
+// AddressSanitizer: profiles/r05_stream_pool.txt), and a pooled stream keeps the hardware queue it was given.
+hipError_t stream_take(int device, hipStream_t *s);
+void stream_give(int device, hipStream_t s);
+
 #define HCV_TRY(expr)                                                                                                  \
     do                                                                                                                 \
     {                                                                                                                  \

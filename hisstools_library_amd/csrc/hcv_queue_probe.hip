@@ -84,6 +84,8 @@ struct Probe
 // not be run (nothing changed).
 int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
 {
+    int device = 0;
+    (void) hipGetDevice(&device);
     static const bool allow = !(std::getenv("HCV_QUEUE_PROBE") && std::atoi(std::getenv("HCV_QUEUE_PROBE")) == 0);
     if (!allow || n <= 0 || n > 6) return -1;
     Probe px;
@@ -110,7 +112,7 @@ int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
     auto cleanup = [&](int rc)
     {
         for (Cand &c : cands)
-            if (c.made && c.s) (void) hipStreamDestroy(c.s);
+            if (c.made && c.s) stream_give(device, c.s);              // (idle: every experiment ends with its streams synchronized)
         return rc;
     };
     for (int r = 0; r < n; r++)
@@ -150,11 +152,12 @@ int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
     for (int extra = 0; served < n && extra < 10; extra++)
     {
         hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        if (stream_take(device, &s) != hipSuccess) break;
         const int cls = classify(s);
         if (cls < 0)
         {
-            (void) hipStreamDestroy(s);
+            (void) hipStreamSynchronize(s);
+            stream_give(device, s);
             return cleanup(-1);
         }
         cands.push_back({s, cls, true});
@@ -165,7 +168,7 @@ int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
     {
         if (pick[r] < n) continue;                                  // (served by its own stream, or not served: it keeps what it had)
         Cand &c = cands[pick[r]];
-        (void) hipStreamDestroy(*roles[r]);
+        stream_give(device, *roles[r]);
         *roles[r] = c.s;
         c.made = false;                                             // (taken: not the cleanup's any more)
         replaced++;

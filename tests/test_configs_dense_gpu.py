@@ -73,5 +73,5 @@ def test_config4_dense_rows_vs_oracle(H, oracle):
         assert rel_err(y[o], y_ref[k]) < TOL_SUM, (o, rel_err(y[o], y_ref[k]))
         assert rel_err(y[o][-3 * B:], y_ref[k][-3 * B:]) < TOL_SUM
     tail = c.stage_stats()[-1]
-    assert tail["partitions"] == 11 and tail["out_tile"] == 8 and tail["ksplit"] > 1 and tail["hop_tile"] == 1
+    assert tail["partitions"] == 11 and tail["out_tile"] == 8 and (tail["ksplit"] > 1 or tail["fused_launches"] > 0) and tail["hop_tile"] == 1
     assert tail["mac_steady_launches"] >= 3, tail

@@ -92,7 +92,7 @@ def test_config5_full_depth_steady_state(H, torch):
     L, hops = 5760000, 712
     tail, worst = _sparse_device_case(H, torch, 16, 16, L, hops, 3, seed=55, spread=(L - 3 * 8192, L))
     assert tail["fft_size"] == 16384 and tail["partitions"] == 703
-    assert tail["out_tile"] == 8 and tail["hop_tile"] == 1 and tail["ksplit"] > 1
+    assert tail["out_tile"] == 8 and tail["hop_tile"] == 1 and (tail["ksplit"] > 1 or tail["fused_launches"] > 0), tail     # (HCV_SERIAL=1: the n x m block)
     assert tail["mac_launches"] == hops
     # every hop from the 703rd on runs the unchecked instantiation with nontemporal loads
     assert tail["mac_steady_launches"] >= hops - 704, tail
@@ -137,7 +137,7 @@ def test_north_star_shape_64x64_10s_steady_state(H, torch):
     """The north-star target shape (64x64, 10 s @ 48 kHz: P = 58, 15.7 GB of spectra): 64 hops, two taps per pair."""
     tail, worst = _sparse_device_case(H, torch, 64, 64, 480000, 64, 2, seed=64)
     assert tail["fft_size"] == 16384 and tail["partitions"] == 58
-    assert tail["out_tile"] == 8 and tail["hop_tile"] == 1 and tail["ksplit"] > 1
+    assert tail["out_tile"] == 8 and tail["hop_tile"] == 1 and (tail["ksplit"] > 1 or tail["fused_launches"] > 0), tail     # (HCV_SERIAL=1: the n x m block)
     assert tail["mac_steady_launches"] >= 4, tail
 
 
@@ -168,7 +168,7 @@ def test_dense_irs_16x16_steady_state_vs_oracle(H, oracle, torch):
         assert rel_err(y[o], y_ref[k]) < TOL_SUM, (o, rel_err(y[o], y_ref[k]))
         assert rel_err(y[o][-8 * B:], y_ref[k][-8 * B:]) < TOL_SUM
     tail = c.stage_stats()[-1]
-    assert tail["partitions"] == 40 and tail["out_tile"] == 8 and tail["ksplit"] > 1 and tail["hop_tile"] == 1
+    assert tail["partitions"] == 40 and tail["out_tile"] == 8 and (tail["ksplit"] > 1 or tail["fused_launches"] > 0) and tail["hop_tile"] == 1
     assert tail["mac_steady_launches"] >= hops - 41, tail
 
 
@@ -216,7 +216,7 @@ def test_config5_depth_dense_irs_vs_oracle(H, oracle, torch):
         assert rel_err(y[k], y_ref[k]) < TOL_SUM, (o, rel_err(y[k], y_ref[k]))
         assert rel_err(y[k][-8 * B:], y_ref[k][-8 * B:]) < TOL_SUM, (o, rel_err(y[k][-8 * B:], y_ref[k][-8 * B:]))
     tail = c.stage_stats()[-1]
-    assert tail["fft_size"] == 16384 and tail["partitions"] == 703 and tail["out_tile"] == 8 and tail["ksplit"] > 1 and tail["hop_tile"] == 1
+    assert tail["fft_size"] == 16384 and tail["partitions"] == 703 and tail["out_tile"] == 8 and (tail["ksplit"] > 1 or tail["fused_launches"] > 0) and tail["hop_tile"] == 1
     assert tail["mac_launches"] == hops and tail["mac_steady_launches"] >= hops - 704, tail
 
 

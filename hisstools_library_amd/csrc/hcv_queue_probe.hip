@@ -6,7 +6,7 @@
 // ladder as bench.py's second engine: 0.150 ms per step in such processes against 0.118 in the others, profiles/r05_queue_probe.txt).
 //
 // There is no API that tells the queue of a stream; there is an experiment: hold stream A with a kernel that waits for a word in host
-// memory (bounded: 0.3 ms), send an empty kernel down stream B and watch whether it gets through.  spread_streams() runs that experiment
+// memory (bounded: 2 ms, released after ~0.15), send an empty kernel down stream B and watch whether it gets through.  spread_streams() runs that experiment
 // at engine creation — on fresh streams, nothing of the engine is enqueued yet — and swaps the busy streams for others until they feed
 // different queues.
 #include "hcv_engine_impl.h"
@@ -57,7 +57,7 @@ struct Probe
             ev.push_back(e);
         }
         *reinterpret_cast<volatile unsigned *>(flag) = 0;
-        hold_kernel<<<1, 64, 0, c>>>(flag_dev, 30000ull);
+        hold_kernel<<<1, 64, 0, c>>>(flag_dev, 200000ull);           // (2 ms at most; released below after ~0.15 ms)
         for (size_t i = 0; i < reps.size(); i++)
         {
             touch_kernel<<<1, 64, 0, reps[i]>>>();
@@ -68,6 +68,10 @@ struct Probe
         while (pending && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150))
             for (size_t i = 0; i < reps.size(); i++)
                 if ((pending >> i & 1) && hipEventQuery(ev[i]) == hipSuccess) pending &= ~(1l << i);
+        // (one more look after the window: a host thread that lost its core inside it comes back to find everything that COULD get through
+        // through, while what sits behind the held kernel still waits — the kernel holds for 2 ms on its own)
+        for (size_t i = 0; i < reps.size(); i++)
+            if ((pending >> i & 1) && hipEventQuery(ev[i]) == hipSuccess) pending &= ~(1l << i);
         (void) hipGetLastError();                                   // (hipErrorNotReady of the queries)
         *reinterpret_cast<volatile unsigned *>(flag) = 1;
         bool fine = hipStreamSynchronize(c) == hipSuccess;

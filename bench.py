@@ -1159,7 +1159,7 @@ def also_leg(workload, device, steps=40, warmup=5, timeout=420, rt=True):
     rt = ["--realtime-block", "128", "--realtime-extra", "64,32"] if rt and workload in ("ns64", "c4") else ["--realtime-block", "0"]
     # (the north-star shape also on the extended ladder: what an unchanged caller of the reference API gets for it, hcv_api.hip's rule)
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "", "--leg",
-           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "8" if workload == "ns64" else "0"] + rt
+           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "4" if workload == "ns64" else "0"] + rt
     env = dict(os.environ, LOCAL_RANK=str(device), RANK="0", WORLD_SIZE="1")     # the same GPU as the headline
     t0 = time.perf_counter()
     try:

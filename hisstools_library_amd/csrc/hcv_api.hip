@@ -288,7 +288,9 @@ namespace
             const uint64_t latency = zeroLatency ? 0 : sizes[0] >> 1;
             uint64_t cur = largest, curOffset = tailOffset;
             const int ownTail = (int) fixedStages.size();
-            while (cur * ratio <= (uint64_t(1) << 20))
+            // (at most three rungs: the engine holds kMaxStages = 8 stages, the reference's own ladder is up to four of them and the head one —
+            // ratio 2 past a long impulse response asked for six and the object could not be made)
+            while (cur * ratio <= (uint64_t(1) << 20) && (int) fixedStages.size() - ownTail < 3)
             {
                 const uint64_t next = cur * ratio, nextOffset = (next >> 1) - latency;
                 if (nextOffset >= maxLength) break;
@@ -387,7 +389,18 @@ namespace
             if (!base.build(args.zero, args.A, args.B, args.C, args.D) || base.largest != 16384 || length <= base.tailOffset) return 0;
             const uint64_t hop = base.largest >> 1, parts = (length - base.tailOffset + hop - 1) / hop;
             const uint64_t bytes = parts * hop * 8 * (uint64_t) nout * (diag ? 1 : nin);
-            return (parts >= kLadderMinParts && bytes >= kLadderMinBytes) ? 8u : 0u;
+            if (!(parts >= kLadderMinParts && bytes >= kLadderMinBytes)) return 0u;
+            // Which ratio: every stage reads its partitions once per hop of ITS size, so per 8192 samples a ladder moves (sum of its
+            // partitions) x pairs x 64 KiB whatever the stages' sizes — a smaller ratio means fewer partitions per rung but more rungs, and
+            // a rung is a chain of launches (~15 us per 8192 samples beside the others).  Measured per 8192-sample step, ratios 8 / 4 / 2
+            // (explicit constructors: three rungs at most, no boundary bound):
+            //   16 x 16, 60 s @ 96 kHz   0.1175 / 0.1232 / 0.333 ms   (26 / 21 / 92 partitions)
+            //   64 x 64, 10 s @ 48 kHz   0.690  / 0.511  / 0.616 ms   (15 / 10 / 11 partitions; ratio 4 has a 262144-point rung whose boundary
+            //                                                           call streams 4.3 GB, beyond the bound below; ratio 2 stays within it)
+            // The RULE keeps ratio 8: the paced real-time behaviour of the three-rung ratio-2 layout (three boundaries instead of one) has
+            // not been measured yet, and that is what the bound exists for.  Callers after throughput ask for their ratio
+            // (hcv_convolver_create_extended, HCV_TAIL_RATIO): bench.py's extended leg of the 64 x 64 / 10 s shape takes 4.
+            return 8u;
         }
 
         // An EMPTY object (no pair loaded) asked to hold a longer impulse response than its stage list was laid out for: lay the

@@ -184,16 +184,18 @@ def test_relayout_of_an_empty_object_under_a_running_stream(H, oracle):
     assert rel_err(yg, yr) <= TOL
 
 
-@pytest.mark.parametrize("nin,nout,L,hops,taps,stages", [
-    (64, 64, 480000, 72, 2, [256, 1024, 4096, 16384, 131072]),                 # the 64 x 64 / 10 s @ 48 kHz shape north_star names
-    (8, 1, 240000, 48, 3, [256, 1024, 4096, 16384, 131072]),                   # BASELINE config 3
+@pytest.mark.parametrize("nin,nout,L,hops,taps,stages,ratio", [
+    (64, 64, 480000, 72, 2, [256, 1024, 4096, 16384, 131072], 8),              # the 64 x 64 / 10 s @ 48 kHz shape north_star names
+    (64, 64, 480000, 72, 2, [256, 1024, 4096, 16384, 32768, 65536, 131072], 2),    # ... on three rungs of ratio 2 (0.616 ms per step against 0.690)
+    (64, 64, 480000, 72, 2, [256, 1024, 4096, 16384, 65536, 262144], 4),       # ... and as bench.py's extended leg asks for it (1010 - 1026 Msamples/s)
+    (8, 1, 240000, 48, 3, [256, 1024, 4096, 16384, 131072], 8),                # BASELINE config 3
 ])
-def test_baseline_long_tail_shapes_on_the_ladder(H, torch, nin, nout, L, hops, taps, stages):
+def test_baseline_long_tail_shapes_on_the_ladder(H, torch, nin, nout, L, hops, taps, stages, ratio):
     """full-size long-tail shapes with the ladder on (config 5 is test_steady_state_gpu.py::test_config5_extended_ladder_full_depth),
     sparse taps over the WHOLE impulse response against the exact float64 answer, hop-sized calls: the pivot stage's whole-hop
     convolution plus the rungs' deferred schedule"""
     from test_steady_state_gpu import _sparse_device_case
-    stats, worst = _sparse_device_case(H, torch, nin, nout, L, hops, taps, seed=77 + nin, spread=(L - 2 * 8192, L), tail_ratio=8)
+    stats, worst = _sparse_device_case(H, torch, nin, nout, L, hops, taps, seed=77 + nin, spread=(L - 2 * 8192, L), tail_ratio=ratio)
     assert [s["fft_size"] for s in stats] == stages
     assert worst < TOL
 

@@ -344,6 +344,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default c5 (the config the metric's HBM clause is quoted on)")
     ap.add_argument("--block", type=int, default=8192)
     ap.add_argument("--batched-block", type=int, default=65536, help="also time offline-style calls of this many samples (0 = skip)")
+    ap.add_argument("--offline-hops", type=int, default=64,
+                    help="also time OFFLINE calls (B = S): an engine made for calls of this many tail hops, one process() call per step, its output "
+                         "checked against hop-sized calls of the timed engine on the same input (0 = skip; matrices with two outputs or more)")
     ap.add_argument("--tail-ratio", type=int, default=0, help="run the HEADLINE on the extended far-tail ladder (0 = reference partitioning)")
     ap.add_argument("--extended-ratio", type=int, default=8, help="also measure the extended far-tail ladder with this ratio (0 = skip)")
     ap.add_argument("--ir-file", default="", help="WAVE / AIFF / AIFC file with real impulse responses instead of the synthetic ones")
@@ -487,6 +490,10 @@ def flat_scalars(line):
         out["batched_block"] = cfg["batched"].get("block")
         out["batched_msamples_per_s"] = cfg["batched"].get("msamples_per_s")
         out["batched_mac_hbm_frac"] = (line.get("roofline_batched") or {}).get("hbm_frac")
+    of = cfg.get("offline") or {}
+    if of:
+        out.update({"offline_block": of.get("block"), "offline_msamples_per_s": of.get("msamples_per_s"), "offline_bound": of.get("bound"),
+                    "offline_frac": of.get("frac"), "offline_max_rel_err": of.get("max_rel_err_vs_hop_calls"), "offline_error": of.get("error")})
     ex = cfg.get("extended_layout") or {}
     if ex:
         out.update({"extended_tail_ratio": ex.get("tail_ratio"), "extended_msamples_per_s": ex.get("msamples_per_s"), "extended_ms_per_step": ex.get("ms_per_step"),
@@ -521,6 +528,12 @@ def flat_scalars(line):
         if ex and not ex.get("error"):
             out[k + "_extended_msamples_per_s"] = ex.get("msamples_per_s")
             out[k + "_extended_max_rel_err"] = (ex.get("self_check") or {}).get("max_rel_err")
+        of = d.get("offline") or {}
+        if of and not of.get("error"):
+            out[k + "_offline_msamples_per_s"] = of.get("msamples_per_s")
+            out[k + "_offline_bound_frac"] = f"{of.get('bound')} {of.get('frac')}"
+        elif of:
+            out[k + "_offline_error"] = str(of.get("error"))[:100]
         sb = (d.get("realtime") or {}).get("small_blocks") or {}
         hp = (d.get("realtime") or {}).get("host_pointers") or {}
         if hp:
@@ -564,7 +577,7 @@ def emit(line):
         keep["c4_strong_ms_per_step"] = cfg["c4_strong"].get("ms_per_step")      # (the keys above quote the faster layout)
     keep["workload"] = str(keep.get("workload", "")).replace(", audio + spectra resident in HBM", "").replace("process block", "block")
     keep["details_file"] = path
-    for k in [k for k, v in keep.items() if v is None or k.endswith("_bound")]:      # (a leg's bound shows in what it carries: mac_frac or kernel)
+    for k in [k for k, v in keep.items() if v is None or (k.endswith("_bound") and k != "offline_bound")]:      # (a leg's bound shows in what it carries: mac_frac or kernel)
         if k not in ("max_rel_err",):
             keep.pop(k)
     short["config"] = keep
@@ -591,7 +604,7 @@ def strong_leg(workload, args, ctx, steps=40, warmup=5, sharding="rows"):
     a = copy.copy(args)
     a.workload, a.scaling, a.sharding = workload, "strong", sharding
     a.steps, a.warmup = min(args.steps, steps), min(args.warmup, warmup)
-    a.batched_block, a.extended_ratio, a.realtime_block, a.realtime_extra, a.tail_ratio = 0, 0, 0, "", 0
+    a.batched_block, a.extended_ratio, a.realtime_block, a.realtime_extra, a.tail_ratio, a.offline_hops = 0, 0, 0, "", 0, 0
     a.no_all_cores, a.no_cpu_baseline, a.leg = True, False, True         # (the bounded CPU leg is this leg's checker; --no-self-check skips both)
     if args.no_self_check:
         a.no_cpu_baseline = True
@@ -632,6 +645,9 @@ def digest_of(d):
     ex = d.get("config", {}).get("extended_layout")
     if ex:
         out["extended_layout"] = ex
+    of = d.get("config", {}).get("offline")
+    if of:
+        out["offline"] = of
     return out
 
 
@@ -676,10 +692,9 @@ def bench_line(args, ctx):
 
     rccl_direct = reduce_path and backend == "nccl" and not os.environ.get("BENCH_TORCH_ALLREDUCE")
 
-    def run(tail_ratio, steps, warmup, batched_block, keep=False):
-        """Build an engine (reference partitioning, or the extended far-tail ladder), load the synthetic IRs (decaying
-        noise, unit L2 norm) into HBM, reach steady state, then time `steps` process calls of B samples."""
-        conv = H.Convolver(nin, nout, 0, device=local, maxBlock=max(B, batched_block), tailRatio=tail_ratio,
+    def build(max_block, tail_ratio):
+        """An engine for calls of up to `max_block` samples with the workload's synthetic IRs (decaying noise, unit L2 norm) in HBM"""
+        conv = H.Convolver(nin, nout, 0, device=local, maxBlock=max_block, tailRatio=tail_ratio,
                            custom=(L, layout[0], layout[1], layout[2], layout[3], layout[4]))
         t_load = time.perf_counter()
         synth = None if file_irs is not None else IrSynth(L, dev, [(in_lo + i, out_lo + o) for o in range(nout) for i in range(nin)])
@@ -697,9 +712,13 @@ def bench_line(args, ctx):
                     raise SystemExit(f"set_dev failed with ConvolveError {rc}")
         if synth is not None:
             synth.close()
-        t_load = time.perf_counter() - t_load
-        torch.cuda.synchronize()
+        return conv, time.perf_counter() - t_load
 
+    def run(tail_ratio, steps, warmup, batched_block, keep=False):
+        """Build an engine (reference partitioning, or the extended far-tail ladder), load the synthetic IRs (decaying
+        noise, unit L2 norm) into HBM, reach steady state, then time `steps` process calls of B samples."""
+        conv, t_load = build(max(B, batched_block), tail_ratio)
+        torch.cuda.synchronize()
         # reduce path over RCCL: the library enqueues ncclAllReduce on the engine's own stream behind the block — no host
         # synchronisation between convolution and collective, so the exchange overlaps the next block's FFTs and MAC.  The
         # communicator of a row group is made from a unique id its first rank draws (distributed through torch's store).
@@ -905,6 +924,18 @@ def bench_line(args, ctx):
             realtime = realtime_leg(conv, np, torch, dev, nin, nout, fs, args.realtime_block, stages, extra_blocks=extra)
         except Exception as e:
             realtime = {"error": str(e)}
+
+    # ---- offline calls (B = S, SURVEY section 7 "streaming vs batched", 8d "report at B = S"; PartitionedConvolve.cpp:298-299, 321-348 loops
+    # the hops of any numSamples): an engine made for calls of `offline_hops` tail hops.  One such call re-uses every IR spectrum over all
+    # its hops, and the multiply-accumulate becomes a dense contraction per bin on the f32 matrix cores (hcv_mac_mfma.hip) — its bound is
+    # the f32 MFMA / VALU peak (157.3 TFLOP/s), or HBM where the IRs are short.  Checked against the timed engine fed the same samples in
+    # hop-sized calls.
+    offline = None
+    if args.offline_hops and world == 1 and not reduce_path and not args.tail_ratio and nout >= 2:
+        try:
+            offline = offline_leg(conv, build, np, torch, dev, nin, nout, in_lo, stages, args.offline_hops, B, args.steps)
+        except Exception as e:
+            offline = {"error": f"{type(e).__name__}: {e}"}
     del conv
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_all_cores:
@@ -1030,6 +1061,7 @@ def bench_line(args, ctx):
                 "self_check": self_check,
                 "max_rel_err": None if self_check is None else self_check.get("max_rel_err"),
                 "batched": batched,
+                "offline": offline,
                 "realtime": realtime,
                 "extended_layout": extended,
                 "tail_ratio": args.tail_ratio,
@@ -1159,7 +1191,8 @@ def also_leg(workload, device, steps=40, warmup=5, timeout=420, rt=True):
     rt = ["--realtime-block", "128", "--realtime-extra", "64,32"] if rt and workload in ("ns64", "c4") else ["--realtime-block", "0"]
     # (the north-star shape also on the extended ladder: what an unchanged caller of the reference API gets for it, hcv_api.hip's rule)
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--also", "", "--leg",
-           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "4" if workload == "ns64" else "0"] + rt
+           "--no-all-cores", "--batched-block", "0", "--extended-ratio", "4" if workload == "ns64" else "0",
+           "--offline-hops", "64" if workload in ("ns64", "c4") else "0"] + rt
     env = dict(os.environ, LOCAL_RANK=str(device), RANK="0", WORLD_SIZE="1")     # the same GPU as the headline
     t0 = time.perf_counter()
     try:
@@ -1173,6 +1206,66 @@ def also_leg(workload, device, steps=40, warmup=5, timeout=420, rt=True):
     dg = digest_of(d)
     dg["seconds"] = round(time.perf_counter() - t0, 1)
     return dg
+
+
+def offline_leg(conv, build, np, torch, dev, nin, nout, in_lo, stages, hops, B, steps):
+    """Offline calls: a second engine whose blocks are `hops` tail hops long (maxBlock), one process_dev call per step.  The engine and
+    `conv` (the timed engine, reset) are fed the same samples from silence — the one in `hops`-hop calls, the other in B-sample calls —
+    until every partition of the tail is live and the offline engine's multiply-accumulate takes its steady-state (matrix-core)
+    instantiation; the last call's outputs are compared.  Then `ksteps` calls are timed with the launch's HIP events on."""
+    F_PEAK = 157.3          # f32 MFMA = f32 VALU peak, TFLOP/s (MI355X_MICROARCH.md)
+    tail_fft, tail_p = stages[-1]
+    Hh = tail_fft // 2
+    OB = hops * Hh
+    ocv, t_load = build(OB, 0)
+    nblk = -(-(tail_p + 3) // hops) + 1                 # calls until the last one runs with every partition live
+    xo = torch.from_numpy(np.stack([synth_audio(in_lo + i, 2 * OB) for i in range(nin)])).to(dev)
+    yo = torch.zeros((nout, 2 * OB), device=dev, dtype=torch.float32)
+    yh = torch.zeros((nout, 2 * OB), device=dev, dtype=torch.float32)
+    conv.reset()
+    for k in range(nblk):
+        off = (k & 1) * OB
+        ocv.process_dev(xo.data_ptr() + 4 * off, 2 * OB, yo.data_ptr() + 4 * off, 2 * OB, nin, nout, OB)
+        for pos in range(off, off + OB, B):
+            conv.process_dev(xo.data_ptr() + 4 * pos, 2 * OB, yh.data_ptr() + 4 * pos, 2 * OB, nin, nout, B)
+    ocv.synchronize()
+    conv.synchronize()
+    last = slice(((nblk - 1) & 1) * OB, ((nblk - 1) & 1) * OB + OB)
+    a, b = yo[:, last].double(), yh[:, last].double()
+    err = float(((a - b).abs().amax(dim=1) / b.abs().amax(dim=1).clamp_min(1e-30)).max().item())
+    ksteps = max(3, min(steps, 6))
+    ocv.clear_stats()
+    ocv.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(ksteps):
+        off = (k & 1) * OB
+        ocv.process_dev(xo.data_ptr() + 4 * off, 2 * OB, yo.data_ptr() + 4 * off, 2 * OB, nin, nout, OB)
+    ocv.synchronize()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / ksteps
+    st = ocv.stage_stats()[-1]
+    ocv.set_profiling(False)
+    del ocv
+    launches = max(1, st["mac_launches"])
+    parts = max(st["partitions"], st.get("launch_partitions", 0))
+    mac_ms = st["mac_ms"] / launches
+    flops = 8.0 * Hh * parts * nin * nout * hops
+    tiles = -(-hops // max(1, st["hop_tile"]))
+    ot = max(1, st["out_tile"])
+    nbytes = (8.0 * Hh * parts * nin * nout * tiles + 8.0 * Hh * (parts + hops) * nin * (-(-nout // ot)) + 8.0 * Hh * nout * hops * max(1, st["ksplit"]))
+    f_frac = flops / (mac_ms * 1e-3) / 1e12 / F_PEAK if mac_ms > 0 else 0.0
+    h_frac = nbytes / (mac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mac_ms > 0 else 0.0
+    bound = "mfma" if f_frac >= h_frac else "hbm"
+    return {"block": OB, "hops": hops, "steps": ksteps, "msamples_per_s": round(nout * OB / dt / 1e6, 1), "ms_per_call": round(1e3 * dt, 3),
+            "bound": bound, "frac": round(max(f_frac, h_frac), 4),
+            "kernel": f"spectral_mac_mfma_kernel (tail stage, FFT {tail_fft}, P={parts}, hop tile {st['hop_tile']}, out tile {ot}, ksplit {st['ksplit']})"
+                      if st["hop_tile"] >= 32 else f"spectral_mac (hop tile {st['hop_tile']}, out tile {ot}, ksplit {st['ksplit']})",
+            "mac_ms_per_launch": round(mac_ms, 4), "mac_tflops": round(flops / (mac_ms * 1e-3) / 1e12, 1) if mac_ms > 0 else None,
+            "mac_f32_peak_frac": round(f_frac, 4), "mac_hbm_frac": round(h_frac, 4), "mac_share_of_call": round(mac_ms / (1e3 * dt), 3),
+            "peaks": {"f32_mfma_tflops": F_PEAK, "hbm_gbs": HBM_PEAK_GBS}, "ir_load_s": round(t_load, 2),
+            "max_rel_err_vs_hop_calls": float(f"{err:.3e}"), "tolerance": 1e-5, "ok": bool(err <= 1e-5),
+            "checked": f"last of {nblk} calls from silence (every partition live) against {B}-sample calls of the timed engine on the same samples"}
 
 
 def realtime_leg(conv, np, torch, dev, nin, nout, fs, RB, stages, seconds=1.0, extra_blocks=()):

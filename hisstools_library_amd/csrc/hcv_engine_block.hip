@@ -364,6 +364,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
                                 /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
                                 /* T */ T, /* max_ksplit */ (int) ks_cap);
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
+        sw.steady = (!wcheck && !st.gh_count) ? 1 : 0;      // (offline calls of 32 hops or more: the matrix cores, hcv_mac_mfma.hip)
         MacPlan pw;
         mac_plan(sw, pw);
         if (!begin_event()) return false;
@@ -433,6 +434,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
                             /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ mCfg.diag ? 1 : 0,
                             /* T */ T, /* max_ksplit */ (int) std::max<size_t>(1, st.y_elems / ((size_t) T * nout_act * st.M)));
     const bool check = (h_first - st.max_hv) < (long long) st.P - 1;
+    sh.steady = (!check && !st.gh_count && p_live == (long long) st.P) ? 1 : 0;
     const long long y_elems = (long long) T * nout_act * st.M;
 
     const bool defer = allow_defer && st.P > 0 && T == 1 && B < st.M && st.P > 1 && p_live >= 1 && nout_act == mCfg.nout &&

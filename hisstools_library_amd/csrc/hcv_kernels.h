@@ -125,6 +125,7 @@ namespace hcv
         int max_ksplit;     // 0 = unlimited (bounded by the Y partial buffer)
         int target_blocks;  // 0 = default; > 0 = aim for this many workgroups (background work keeps a small footprint)
         int ot_cap;         // 0 = none; > 0 = at most this many outputs per thread (more, smaller workgroups for launches without k-slices)
+        int steady = 0;     // the launch will run unchecked (every pair sees all P partitions): the offline shapes may take the matrix cores
     };
     struct MacPlan
     {
@@ -134,7 +135,11 @@ namespace hcv
         int nt;                     // stream H with nontemporal loads
         int inwg;                   // > 0: the k-slices are the waves of ONE workgroup (this many, 64 lanes = 128 bins each) and are added
                                     // up in LDS — ksplit = 1, no partial sums in memory, no reduce_partials launch (small engines)
+        int mfma = 0;               // > 0: the offline kernel on the matrix cores (hcv_mac_mfma.hip), tiles of 32 x this many hops; ot = 16
     };
+    // hcv_mac_mfma.hip: offline calls (>= 32 hops per launch, steady state, a matrix) as one dense contraction per bin on the f32 MFMA
+    bool mac_mfma_applies(const MacShape &s);
+    void mac_mfma_plan(const MacShape &s, MacPlan &pl);
     void mac_plan(const MacShape &s, MacPlan &pl);
     // (dst: where the sum goes; nullptr = slice 0 of Y itself)
     hipError_t launch_reduce_partials(float2 *Y, int ksplit, long long ks_stride, long long elems, hipStream_t st, float2 *dst = nullptr);

@@ -249,6 +249,12 @@ __global__ __launch_bounds__(INWG ? 1024 : 256) void spectral_mac_kernel(MacPara
 
 void mac_plan(const MacShape &s, MacPlan &pl)
 {
+    pl.mfma = 0;
+    if (mac_mfma_applies(s))
+    {
+        mac_mfma_plan(s, pl);               // offline calls: the matrix cores (hcv_mac_mfma.hip)
+        return;
+    }
     constexpr int target_blocks = 768;      // workgroups to aim for (3 per CU)
     // hop tiling pays through H reuse on long reductions; the short head stages run leaner (fewer registers, so they
     // co-reside with the tail's workgroups)
@@ -376,6 +382,12 @@ hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float
     a.kper = pl.kper;
     a.binblocks = pl.binblocks;
     a.ks_stride4 = (long long) s.T * s.nout * (s.M / 2);
+    if (pl.mfma)
+    {
+        if (check) return hipErrorInvalidValue;             // (planned for a steady launch only: MacShape::steady)
+        a.pin = -1;
+        return launch_mac_mfma(pl, a, st);
+    }
     a.pin = (pl.outtiles == 1 && pl.tz == 1) ? xcd_pin_for((long long) pl.binblocks * pl.ksplit * (pl.inwg > 0 ? pl.inwg / 4 : 1)) : -1;
     const int key = pl.ot * 16 + pl.tt;
     switch (key)

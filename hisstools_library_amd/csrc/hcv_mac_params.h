@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "hcv_kernels.h"
+
 namespace hcv
 {
 
@@ -25,5 +27,8 @@ struct MacParams
 
 // the software-pipelined hop-tiled kernel (hcv_mac_tiled.hip): (OT, TT) in {1, 4} x {2, 4, 8}
 hipError_t launch_mac_tiled(int ot, int tt, bool nt, dim3 grid, dim3 block, const MacParams &a, hipStream_t st);
+
+// the offline kernel on the matrix cores (hcv_mac_mfma.hip); a.binblocks = 16-bin blocks per spectrum
+hipError_t launch_mac_mfma(const MacPlan &pl, const MacParams &a, hipStream_t st);
 
 } // namespace hcv

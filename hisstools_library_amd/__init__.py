@@ -11,5 +11,5 @@ from ._lib import LIB_PATH, load, last_error  # noqa: F401
 from .convolver import (  # noqa: F401
     Convolver, NToMonoConvolve, MonoConvolve, PartitionedConvolve, TimeDomainConvolve,
     LatencyMode, kLatencyZero, kLatencyShort, kLatencyMedium, ConvolveError,
-    hisstools_rfft, hisstools_rifft, spectral_processor, EdgeMode, rccl_unique_id, host_register, host_unregister,
+    hisstools_rfft, hisstools_rifft, spectral_processor, EdgeMode, rccl_unique_id, host_register, host_unregister, ctl_reserve, ctl_reserved,
 )

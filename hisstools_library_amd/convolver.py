@@ -204,6 +204,16 @@ def host_register(a: np.ndarray):
     _check(_lib.load().hcv_host_register(a.ctypes.data, a.nbytes), "host_register")
 
 
+def ctl_reserve(device: int, nbytes: int):
+    """hcv_ctl_reserve: the least the control arena of `device` holds while the device has an object (set / resize beside a running stream
+    then never has the driver map memory: include/hisstools_amd.h).  0 = what the objects ask for themselves."""
+    _check(_lib.load().hcv_ctl_reserve(device, nbytes), "ctl_reserve")
+
+
+def ctl_reserved(device: int) -> int:
+    return int(_lib.load().hcv_ctl_reserved(device))
+
+
 def host_unregister(a: np.ndarray):
     _check(_lib.load().hcv_host_unregister(a.ctypes.data), "host_unregister")
 
@@ -501,7 +511,8 @@ class Convolver:
                "Convolver.process_dev_allreduce")
 
     def rt_stats(self):
-        """Audio-thread contract counters since the last clear_stats(): {lock_contended, lock_wait_ns_max, blocks_muted}"""
+        """Audio-thread contract counters since the last clear_stats(): {start_collisions, mailbox_runs, mailbox_ns_max, mailbox_ns_total,
+        ctl_sections} (include/hisstools_amd.h: hcv_rt_stats)"""
         st = _lib.RtStats()
         _check(self.L.hcv_convolver_rt_stats(self.h, C.byref(st)), "Convolver.rt_stats")
         return {k: getattr(st, k) for k, _ in _lib.RtStats._fields_}

@@ -1572,20 +1572,30 @@ extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
     });
 }
 
+// (the audio-thread counters are atomics of the engine: read without the state mutex — a set() in progress holds that for its whole
+// length, posted section included — through the same hold on the engine the process calls take)
 extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
 {
     if (!out) return -1;
-    out->lock_contended = out->lock_wait_ns_max = out->blocks_muted = out->mailbox_runs = out->ctl_turns = 0;
+    out->start_collisions = out->mailbox_runs = out->mailbox_ns_max = out->mailbox_ns_total = out->ctl_sections = 0;
     auto add = [&](Engine &e)
     {
         const Engine::RtStats r = e.rt_stats();
-        out->lock_contended += r.lock_contended;
-        out->lock_wait_ns_max = std::max<uint64_t>(out->lock_wait_ns_max, r.lock_wait_ns_max);
-        out->blocks_muted += r.blocks_muted;
+        out->start_collisions += r.start_collisions;
         out->mailbox_runs += r.mailbox_runs;
-        out->ctl_turns += r.ctl_turns;
+        out->mailbox_ns_max = std::max<uint64_t>(out->mailbox_ns_max, r.mailbox_ns_max);
+        out->mailbox_ns_total += r.mailbox_ns_total;
+        out->ctl_sections += r.ctl_sections;
     };
-    each_engine(h, add);
+    auto visit = [&](Matrix &m)
+    {
+        EngineUse use(m);
+        if (use.ok) add(*m.engine);
+    };
+    if (h->sh)
+        for (hcv_shard &x : h->sh->s) visit(*x.m);
+    else
+        visit(*h->m);
     return 0;
 }
 

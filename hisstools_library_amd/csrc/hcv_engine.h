@@ -20,8 +20,9 @@
 //     taps     [nout][nin_alloc][2048] float   time-domain head taps, zero padded
 //     ghost spectra, pooled                    per restart of single pairs and stage: [inputs restarted][2][M] float2 (hcv_ghost.hip)
 //
-// Control calls stage their work outside the engine lock (set_ir: upload + FFTs into staging buffers on a control stream, then
-// a pointer-swap section; ensure_stage_capacity: new buffers filled beside the running audio thread), process() try-locks.
+// Control calls stage their work beside the audio thread (set_ir: upload + FFTs into staging buffers on a control stream, then
+// a swap section; ensure_stage_capacity: new buffers filled beside the running audio thread); process() never waits for them:
+// the engine's host state has an owner, not a lock (Engine::mOwner).
 //
 // Source files: hcv_engine.hip (set-up, IR loading, capacity growth), hcv_engine_block.hip (the per-block scheduler:
 // enqueue_chunk -> enqueue_stage, streams, serial blocks, deferred slices), hcv_engine_restart.hip (exact per-pair restart:
@@ -138,13 +139,17 @@ namespace hcv
         // last stage's stream, which is why a dependency of the NEXT call's writes on foreign work goes through process_dev's `after`.
         hipStream_t main_stream() const { return mStream; }
 
-        // The audio-thread contract (MemorySwap::attempt, MonoConvolve.cpp:181-183): process never waits for a control call's
-        // upload, allocation or device work — only, at most, for the short host-only section in which a control call swaps
-        // its staged result in.  These count what that cost: calls that found the engine lock taken, the longest such wait,
-        // and blocks given up as silence after kAudioLockBudgetNs (never observed; the reference mutes the pair instead).
-        struct RtStats { uint64_t lock_contended, lock_wait_ns_max, blocks_muted, mailbox_runs, ctl_turns; };
-        RtStats rt_stats() const { return { mLockContended.load(), mLockWaitNsMax.load(), mBlocksMuted.load(), mMailboxRuns.load(), mCtlTurns.load() }; }
-        void clear_rt_stats() { mLockContended = 0; mLockWaitNsMax = 0; mBlocksMuted = 0; mMailboxRuns = 0; mCtlTurns = 0; }
+        // The audio-thread contract (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:181-183; ThreadLocks.hpp:51-87): process
+        // never waits for a control call.  There is no lock on the path: the engine's host state is OWNED — by the thread inside a process
+        // call's enqueue, or, only while no stream is running, by a control thread inside a swap section (mOwner, one compare-exchange,
+        // no loop).  While a stream is running control threads never take the ownership: they post their section and the audio thread
+        // runs it between two of its blocks (mailbox_runs; what that cost it: mailbox_ns_max / mailbox_ns_total).  start_collisions counts
+        // the one case left in which a process call cannot have the state: the FIRST call of a stream (no call for kStreamingWindowNs
+        // before it) arriving while a control thread is inside a section it began during the pause — that call's block is silent, as every
+        // pair under a set() is in the reference, and the call after it proceeds.
+        struct RtStats { uint64_t start_collisions, mailbox_runs, mailbox_ns_max, mailbox_ns_total, ctl_sections; };
+        RtStats rt_stats() const { return { mStartCollisions.load(), mMailboxRuns.load(), mMailboxNsMax.load(), mMailboxNsTotal.load(), mCtlSections.load() }; }
+        void clear_rt_stats() { mStartCollisions = 0; mMailboxRuns = 0; mMailboxNsMax = 0; mMailboxNsTotal = 0; mCtlSections = 0; }
 
         void set_profiling(bool on);
         // HCV_REFERENCE_QUIRKS (hcv_api.hip): the next blocks leave the time-domain head out — what MonoConvolve::process does to it in a
@@ -170,53 +175,56 @@ namespace hcv
         bool fence_background(bool keep_plan = false);
         bool fence_chains(bool keep_forward = false);
         bool join_forward_stream();
+        bool input_behind_forward();
         bool ensure_staging(Stage &st, uint32_t parts);
         // control-path device memory: stream-ordered allocation on the control stream (hipMallocAsync / hipFreeAsync).  The
         // synchronous calls take runtime-wide locks and, for hipFree, wait for the whole device: an audio thread's launches
         // stood behind them for up to 19 ms while a control thread regrew a stage.  (ctl_alloc'ed memory: ctl_free only.)
         hipError_t ctl_alloc(void **p, size_t bytes);
         void ctl_free(void *p);
-        bool lock_for_audio(std::unique_lock<std::mutex> &lk);
-        // The control mailbox.  A control call's swap section (set_ir phase B, the pointer swap of a regrow) must run between
-        // two blocks, exclusive of the audio thread's enqueue.  While a stream is running (a process call within the last
-        // kStreamingWindowNs) the control thread never takes the engine lock for it: it POSTS the section and the audio thread runs
-        // it at the start of its next call, inside the lock it holds anyway — so no process call of a running stream can find the
-        // lock taken by a set / resize / reset (MemorySwap::attempt never waits either, MemorySwap.h:182-185; the reference mutes
-        // the pair meanwhile, here the pair plays its previous IR until the swap).  With no stream running the control thread takes
-        // the lock itself.  Control calls are serialised by mSetMutex, so one slot suffices.
-        //
-        // Control TURNS (round 4).  The section is a few dozen HIP calls — retiring kernels, device-to-device copies, the restart's
-        // fence and ghost spectra: 0.1 - 0.3 ms of host time that the mailbox puts into an audio call.  A PACED stream (a real-time
-        // host: the calls' period leaves the engine lock free for most of it — mAudioPeriodNs, mAudioHoldNs) gets them off its thread
-        // altogether: the control thread waits for the audio thread to release the lock at the end of its next enqueue
-        // (mEnqueueSeq), takes the lock right behind it and runs the section AND the restart it raises itself, in the gap before
-        // the next call — at the same block boundary, on the same streams, as the audio thread would have at the start of that
-        // call.  The audio thread's part is nothing.  Should the section overrun the gap (a preempted control thread) the next call
-        // polls for the lock like any contended call, bounded, and is counted (rt_stats); a stream without gaps (back-to-back
-        // asynchronous calls) keeps the mailbox.
+        // Ownership of the engine's host state and enqueue order (the streams' program order, the rings' bookkeeping).  kOwnerAudio: a
+        // process call between audio_enter and audio_leave; kOwnerControl: a control thread inside a section, taken only when no process
+        // call was made for kStreamingWindowNs (and given up again at once if one turns out to have started).  The audio thread tries ONCE.
+        enum : uint32_t { kOwnerFree = 0, kOwnerAudio = 1, kOwnerControl = 2 };
+        std::atomic<uint32_t> mOwner { kOwnerFree };
+        // The control mailbox.  A control call's swap section (set_ir phase B, the pointer swap of a regrow, a fence for synchronize) must
+        // run between two blocks.  While a stream is running (a process call within the last kStreamingWindowNs) the control thread
+        // POSTS the section and waits for it (control threads may wait); the audio thread runs it at the start — or the end — of its
+        // next call, inside the ownership it holds anyway (the reference mutes the pair meanwhile, here the pair plays its previous
+        // IR until the swap).  With no stream running the control thread takes the ownership itself.  Control calls are serialised by
+        // mSetMutex and readers of the statistics by mQueryMutex, each posting one section at a time: two slots.
         struct CtlJob
         {
             std::function<bool()> fn;
             std::atomic<bool> done { false };
             bool ok = false;
         };
-        bool run_exclusive(std::function<bool()> fn, long long turn_budget_ns = -1);       // control threads
-        std::atomic<long long> mTurnCostNs { 0 };           // what the sections run in control turns have taken (smoothed, quick to rise)
-        void audio_enter();                                 // audio thread, engine lock held: timestamp + run a posted section
-        std::atomic<CtlJob *> mMailbox { nullptr };
+        bool run_exclusive(std::function<bool()> fn, int slot = 0);        // control threads
+        bool audio_enter();                                 // audio thread: stamp, take the ownership (false: a stream-start collision), run posted sections
+        void audio_leave();                                 // audio thread: posted sections once more, stamp, ownership back
+        void run_mailbox();
+        // the ownership of a process call, given back on every way out of it (an error return included)
+        struct OwnerGuard
+        {
+            Engine *e;
+            explicit OwnerGuard(Engine *eng) : e(eng) {}
+            void leave() { if (e) { e->audio_leave(); e = nullptr; } }
+            ~OwnerGuard() { leave(); }
+            OwnerGuard(const OwnerGuard &) = delete;
+            OwnerGuard &operator=(const OwnerGuard &) = delete;
+        };
+        std::atomic<CtlJob *> mMailbox[2] = { { nullptr }, { nullptr } };
         std::atomic<long long> mLastAudioNs { 0 };
         std::atomic<size_t> mAudioThread { 0 };             // (hash of) the thread that made the last process call
         std::atomic<uint64_t> mMailboxRuns { 0 };           // sections the audio thread ran for control threads
-        std::atomic<uint64_t> mCtlTurns { 0 };              // sections control threads ran themselves between two calls of a paced stream
-        std::atomic<uint64_t> mEnqueueSeq { 0 };            // process calls that have released the engine lock
-        std::atomic<long long> mAudioPeriodNs { 0 }, mAudioHoldNs { 0 };    // smoothed: start-to-start of the calls, lock held per call
-        long long mCallStartNs = 0;                         // (audio thread) start of the call in progress
-        void audio_leave(std::unique_lock<std::mutex> &lk); // audio thread: end of a call's enqueue — stamp, release the lock, announce it
+        std::atomic<uint64_t> mMailboxNsMax { 0 }, mMailboxNsTotal { 0 };   // ... and what they took of its calls
+        std::atomic<uint64_t> mCtlSections { 0 };           // sections control threads ran themselves (no stream running)
+        std::atomic<uint64_t> mStartCollisions { 0 };
         bool apply_pending_resets();
         std::atomic<uint32_t> mResetAllGen { 0 };           // reset_all() calls so far
         uint32_t mResetAllSeen = 0;                         // ... applied so far (audio side)
+        std::vector<size_t> mRestartScratch;                // ... and the pairs that restart (likewise)
         std::vector<uint8_t> mTaken;                        // apply_pending_resets: the flags taken this block (no allocation on the audio thread)
-        void apply_resets_in_a_turn();
         bool update_active_matrix(uint32_t rows_in, uint32_t nout_act);
         struct Block;
         bool enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B);
@@ -226,6 +234,7 @@ namespace hcv
         bool catch_up_stage(const Block &blk, Stage &st, long long h_first, bool rebuild_spectra);
         size_t pair_index(uint32_t in, uint32_t out) const { return (size_t) out * mNinAlloc + (mCfg.diag ? 0 : in); }
         void collect_events();
+        void collect_events_owned();
         // exact per-pair restart (hcv_ghost.hip): ghost spectra of the input before the restart, the pair's pending output retired
         struct GhostEvent;
         bool mac(Stage &st, const MacShape &s, const MacPlan &pl, const float2 *H, float2 *Y, long long h_first, bool check, hipStream_t stream);
@@ -242,8 +251,8 @@ namespace hcv
         int mDevice = 0;
         uint32_t mMaxBlock = 0, mNinAlloc = 1;
         std::vector<Stage *> mStages;
-        std::mutex mMutex;          // host-side engine state + enqueue order
-        std::mutex mSetMutex;       // serialises set_ir (shared IR staging buffer)
+        std::mutex mSetMutex;       // serialises the control calls (shared IR staging buffer, one mailbox slot)
+        std::mutex mQueryMutex;     // serialises the readers of statistics / synchronize (the other mailbox slot)
         std::string mErr;
 
         // mStream: control + emit (and the D2H copy of the host path); mInStream: input scatter (and the H2D copy);
@@ -259,7 +268,6 @@ namespace hcv
         bool mHostMuted = false;            // host path: the block between process_begin and process_end was given up
         float *mStageTaps = nullptr;        // staging of set_ir: head taps, head spectrum, tail-head spectrum
         float2 *mStageHead = nullptr, *mStageTailHead = nullptr;
-        std::atomic<uint64_t> mLockContended { 0 }, mLockWaitNsMax { 0 }, mBlocksMuted { 0 };
         hipEvent_t mEvSerial = nullptr;     // end of a run of serial blocks (see enqueue_chunk)
         bool mPrevSerial = false;           // the previous block ran serially on the main stream
         // small engines, whole-hop blocks: the forward transforms of block k+1 run on a second stream beside block k's
@@ -281,11 +289,11 @@ namespace hcv
         uint32_t mNxmEvery = 3;             // ... every how many of them record their end (from the rings' depth, enqueue_chunk)
         hipEvent_t mEvNxmEnd[4] = { nullptr, nullptr, nullptr, nullptr };    // ends of every mNxmEvery-th such block (back-pressure on the pipe stream, enqueue_chunk)
         hipEvent_t mEvFwd = nullptr;
-        std::atomic<uint32_t> mLateMask { 0 };              // the last block's boundary chains still running past its emit (bit 2 * stage + parity)
-        bool late_chains_done() const;
         hipEvent_t mEmitFirstEv = nullptr;                  // the last block's emit event when it was enqueued in front of late chains
         hipEvent_t mHostWait = nullptr;                     // what process_end waits for
         bool mCallWaits = false;            // the call being enqueued waits for its result (host pointers, sync = true): nothing to pipeline
+        long long mArenaWant = 0;           // bytes this engine asked the device's control arena to hold (init; taken back by the destructor)
+        std::atomic<uint64_t> mArenaMisses { 0 };   // control-path allocations the arena could not serve (stream-ordered pool: may stall the streams)
         std::vector<void *> mParked;        // buffers replaced by a regrow whose hipFree would stall the device: freed with the engine
         bool mPrevDirect = false;           // the previous block's history was written by its last stage's forward FFTs (direct input)
         bool mPrevPlain = false;            // the previous block was a plain small call: its samples were filed in the ring from the MAIN stream
@@ -336,7 +344,7 @@ namespace hcv
         long long mGhostPruneAt = -1;       // sample count at which the oldest restart stops mattering (-1: none)
         uint32_t mLastNin = 0, mLastNout = 0;   // active matrix of the previous block
         long long mN = 0;                   // samples since the last global reset
-        bool mProfiling = false;
+        std::atomic<bool> mProfiling { false };
         std::atomic<bool> mDropHead { false };
         bool mOneStream = false;            // every kernel on mStream (small engines: dependency hops cost more than overlap gains)
         std::vector<EventPair *> mEvents;

@@ -16,6 +16,7 @@ namespace
     struct CtlArena;
     CtlArena *arena_of(int device, bool create);       // the device's control arena (below, with ctl_alloc)
     void arena_reap_all(int device);                   // every parked block of the device's arena back to its free list, waiting for their events
+    void arena_engine(int device, long long want);     // an engine of the device comes (its want of arena bytes) or goes (minus it)
 }
 
 static int ilog2(uint64_t v)
@@ -177,7 +178,6 @@ bool Engine::init(const EngineCfg &cfg)
         return false;
     }
     DeviceGuard dg(mDevice);
-    (void) arena_of(mDevice, true);             // (the control arena of this device: mapped now, before any stream runs)
 
     mMaxBlock = cfg.max_block;
     if (!mMaxBlock)
@@ -373,6 +373,15 @@ bool Engine::init(const EngineCfg &cfg)
             HCV_TRY(hipMalloc(&mStageHead, sizeof(float2) * s0.M));
         }
     }
+    {
+        // what this engine wants held in the device's control arena (see CtlArena): its largest stage regrown by half — new spectra and
+        // ring beside the old ones — plus a pair's staging and IR upload; 16 MiB .. 1 GiB.  hcv_ctl_reserve / HCV_CTL_RESERVE_MB for more.
+        size_t most = 0;
+        for (const Stage *st : mStages)
+            most = std::max(most, sizeof(float2) * ((size_t) mCfg.nout * mNinAlloc * (st->Pcap + st->lead) + (size_t) mCfg.nin * st->R + 3 * (size_t) st->Pcap) * st->M);
+        mArenaWant = (long long) std::min<size_t>(size_t(1) << 30, std::max<size_t>(size_t(16) << 20, most + most / 2));
+        arena_engine(mDevice, mArenaWant);
+    }
     HCV_TRY(hipDeviceSynchronize());
     return true;
 }
@@ -560,6 +569,11 @@ Engine::~Engine()
     // recorded on — a later query reaches into the destroyed stream's signal pool.  Suspected in two full-suite runs that died inside
     // the create / destroy cycles of tests/test_gpu_parity.py, one with an abort in a destructor, one with a fault on a runtime thread.)
     arena_reap_all(mDevice);
+    if (mArenaWant)
+    {
+        arena_engine(mDevice, -mArenaWant);      // (its want goes with it; chunks nothing lives in and nobody wants go back to the driver)
+        mArenaWant = 0;
+    }
     if (mTaps) (void) hipFree(mTaps);
     if (mHeadSpec) (void) hipFree(mHeadSpec);
     for (int k = 0; k < 2; k++)
@@ -829,68 +843,112 @@ static hipMemPool_t ctl_pool(int device)
     return pool;
 }
 
-// The control ARENA (round 5): device memory for the control path that is mapped BEFORE any stream runs.  Obtaining new device memory
+// The control ARENA: device memory for the control path that is mapped BEFORE the stream it serves runs.  Obtaining new device memory
 // from the driver — a regrown stage's spectra: up to a gigabyte in the contract test — stalls every HIP call of the process while the
 // driver maps it: the audio thread's next launch stood behind that for 19 - 49 ms, whichever allocator asked (hipMalloc, or the stream-
-// ordered pool when it held nothing that large yet).  So each device gets ONE block at the creation of its first engine
-// (HCV_CTL_RESERVE_MB, default 4096; 0 = none; hcv_ctl_reserve() sizes it explicitly before the first engine) and the control path's
-// buffers — regrown spectra and rings, staging buffers, the IR upload buffer — are carved out of it: first fit over a coalescing free
-// list, host-only.  A freed block goes back behind an event recorded on the freeing engine's control stream (ctl_free is stream-ordered
-// like hipFreeAsync: the block's last users are ordered in front of that point) and is handed out again only once that event has
+// ordered pool when it held nothing that large yet).  So each device keeps an arena the control path's buffers — regrown spectra and
+// rings, staging buffers, the IR upload buffer — are carved out of: first fit over coalescing free lists, host-only.
+//
+// Round 6: the arena is sized by the engines that use it, not 4 GiB for everyone.  Every engine states at its creation what
+// it wants held for it — by default one regrow of its largest stage by half plus a pair's staging, 16 MiB .. 1 GiB (Engine::init) — and the
+// device's arena grows by a chunk, THEN (a creation maps memory anyway), whenever the engines' wants together exceed what it holds; an
+// engine's going takes its want back and releases the chunks nothing lives in and nobody wants; the last engine's going releases all.
+// A host that will load longer impulse responses than its objects were created for reserves explicitly: hcv_ctl_reserve(device, bytes) /
+// HCV_CTL_RESERVE_MB raise the floor of what the device holds while it has an engine (0 = the engines' wants only).
+// A freed block goes back behind an event recorded on the freeing engine's control stream (ctl_free is stream-ordered like
+// hipFreeAsync: the block's last users are ordered in front of that point) and is handed out again only once that event has
 // completed, so any engine of the device may take it.  Requests the arena cannot serve fall back to the stream-ordered pool (and may
-// stall: a host that must never see that reserves what it will need).
+// stall every stream of the process while the driver maps them: what the reserve is for).
 namespace
 {
     struct CtlArena
     {
-        std::mutex mtx;
-        char *base = nullptr;
-        size_t size = 0;
-        std::map<size_t, size_t> free;                                  // offset -> length
-        std::map<size_t, size_t> live;                                  // offset -> length
-        struct Pending { size_t off; hipEvent_t ev; };
-        std::vector<Pending> pending;
-        bool tried = false;
-
-        void release(size_t off, size_t len)
+        struct Chunk
         {
-            auto it = free.emplace(off, len).first;
-            auto nx = std::next(it);
-            if (nx != free.end() && it->first + it->second == nx->first)
+            char *base = nullptr;
+            size_t size = 0;
+            std::map<size_t, size_t> free, live;                        // offset -> length
+            void release(size_t off, size_t len)
             {
-                it->second += nx->second;
-                free.erase(nx);
-            }
-            if (it != free.begin())
-            {
-                auto pv = std::prev(it);
-                if (pv->first + pv->second == it->first)
+                auto it = free.emplace(off, len).first;
+                auto nx = std::next(it);
+                if (nx != free.end() && it->first + it->second == nx->first)
                 {
-                    pv->second += it->second;
-                    free.erase(it);
+                    it->second += nx->second;
+                    free.erase(nx);
+                }
+                if (it != free.begin())
+                {
+                    auto pv = std::prev(it);
+                    if (pv->first + pv->second == it->first)
+                    {
+                        pv->second += it->second;
+                        free.erase(it);
+                    }
+                }
+            }
+            void *take(size_t bytes)
+            {
+                for (auto it = free.begin(); it != free.end(); ++it)
+                    if (it->second >= bytes)
+                    {
+                        const size_t off = it->first, len = it->second;
+                        free.erase(it);
+                        if (len > bytes) free.emplace(off + bytes, len - bytes);
+                        live.emplace(off, bytes);
+                        return base + off;
+                    }
+                return nullptr;
+            }
+            bool holds(const void *p) const { return static_cast<const char *>(p) >= base && static_cast<const char *>(p) < base + size; }
+        };
+        std::mutex mtx;
+        std::vector<Chunk *> chunks;
+        struct Pending { void *p; hipEvent_t ev; };
+        std::vector<Pending> pending;
+        size_t wanted = 0;                                              // sum of the live engines' wants
+        int engines = 0;
+
+        size_t capacity() const
+        {
+            size_t c = 0;
+            for (const Chunk *k : chunks) c += k->size;
+            return c;
+        }
+        Chunk *chunk_of(const void *p) const
+        {
+            for (Chunk *k : chunks)
+                if (k->holds(p)) return k;
+            return nullptr;
+        }
+        void give_back(void *p)
+        {
+            if (Chunk *k = chunk_of(p))
+            {
+                auto lv = k->live.find((size_t) (static_cast<char *>(p) - k->base));
+                if (lv != k->live.end())
+                {
+                    k->release(lv->first, lv->second);
+                    k->live.erase(lv);
                 }
             }
         }
-        // blocks whose last users are through go back to the free list (wait = block for those that are not)
-        void reap(bool wait)
+        // blocks whose last users are through go back to the free lists; `wait`: the events still pending are handed to the caller, which
+        // waits for them WITHOUT the arena's mutex (every other engine's ctl_alloc / ctl_free stood behind one engine's device work)
+        void reap(std::vector<Pending> *still_pending)
         {
             for (size_t k = 0; k < pending.size();)
             {
-                hipError_t e = wait ? hipEventSynchronize(pending[k].ev) : hipEventQuery(pending[k].ev);
-                if (e == hipErrorNotReady)
+                if (hipEventQuery(pending[k].ev) == hipErrorNotReady)
                 {
                     (void) hipGetLastError();
+                    if (still_pending) still_pending->push_back(pending[k]);
                     k++;
                     continue;
                 }
                 (void) hipGetLastError();
                 (void) hipEventDestroy(pending[k].ev);
-                auto lv = live.find(pending[k].off);
-                if (lv != live.end())
-                {
-                    release(lv->first, lv->second);
-                    live.erase(lv);
-                }
+                give_back(pending[k].p);
                 pending[k] = pending.back();
                 pending.pop_back();
             }
@@ -898,22 +956,56 @@ namespace
         void *take(size_t bytes)
         {
             bytes = (bytes + 255) & ~size_t(255);
-            for (auto it = free.begin(); it != free.end(); ++it)
-                if (it->second >= bytes)
-                {
-                    const size_t off = it->first, len = it->second;
-                    free.erase(it);
-                    if (len > bytes) free.emplace(off + bytes, len - bytes);
-                    live.emplace(off, bytes);
-                    return base + off;
-                }
+            for (Chunk *k : chunks)
+                if (void *p = k->take(bytes)) return p;
             return nullptr;
+        }
+        bool grow(size_t bytes)
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 2) bytes = free_b / 2;      // (never more than half of what is left)
+            bytes &= ~size_t(255);
+            void *p = nullptr;
+            if (!bytes || hipMalloc(&p, bytes) != hipSuccess || !p)
+            {
+                (void) hipGetLastError();
+                return false;
+            }
+            Chunk *k = new Chunk();
+            k->base = static_cast<char *>(p);
+            k->size = bytes;
+            k->free.emplace(0, bytes);
+            chunks.push_back(k);
+            return true;
+        }
+        // chunks nothing lives in, while the rest still covers `floor`
+        void shrink(size_t floor)
+        {
+            for (size_t k = chunks.size(); k-- > 0;)
+            {
+                Chunk *c = chunks[k];
+                if (!c->live.empty() || capacity() - c->size < floor) continue;
+                bool parked = false;
+                for (const Pending &pe : pending) parked = parked || c->holds(pe.p);
+                if (parked) continue;
+                (void) hipFree(c->base);
+                delete c;
+                chunks.erase(chunks.begin() + (long) k);
+            }
         }
     };
     std::mutex gArenaMutex;
     std::map<int, CtlArena *> gArenas;
-    std::map<int, size_t> gArenaWanted;                                 // hcv_ctl_reserve: bytes asked for per device (before its first engine)
+    std::map<int, size_t> gArenaFloor;                                  // hcv_ctl_reserve: bytes the device holds at least while it has an engine
 
+    size_t arena_floor(int device)
+    {
+        size_t f = 0;
+        if (const char *env = std::getenv("HCV_CTL_RESERVE_MB")) f = (size_t) std::max(0, std::atoi(env)) << 20;
+        auto w = gArenaFloor.find(device);
+        if (w != gArenaFloor.end()) f = std::max(f, w->second);
+        return f;
+    }
     CtlArena *arena_of(int device, bool create)
     {
         std::lock_guard<std::mutex> g(gArenaMutex);
@@ -921,26 +1013,33 @@ namespace
         if (it != gArenas.end()) return it->second;
         if (!create) return nullptr;
         CtlArena *a = new CtlArena();
-        size_t want = size_t(4096) << 20;
-        if (const char *env = std::getenv("HCV_CTL_RESERVE_MB")) want = (size_t) std::max(0, std::atoi(env)) << 20;
-        auto w = gArenaWanted.find(device);
-        if (w != gArenaWanted.end()) want = w->second;
-        if (want)
-        {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b / 2) want = free_b / 2;      // (never more than half of what is left)
-            void *p = nullptr;
-            if (want && hipMalloc(&p, want) == hipSuccess && p)
-            {
-                a->base = static_cast<char *>(p);
-                a->size = want;
-                a->free.emplace(0, want);
-            }
-            else
-                (void) hipGetLastError();
-        }
         gArenas[device] = a;
         return a;
+    }
+    // an engine comes (want > 0) or goes (want < 0) — the calling thread's current device is the arena's
+    void arena_engine(int device, long long want)
+    {
+        CtlArena *a = arena_of(device, true);
+        size_t floor;
+        {
+            std::lock_guard<std::mutex> g(gArenaMutex);
+            floor = arena_floor(device);
+        }
+        std::lock_guard<std::mutex> g(a->mtx);
+        if (want >= 0)
+        {
+            a->engines++;
+            a->wanted += (size_t) want;
+            const size_t target = std::max(a->wanted, floor);
+            if (a->capacity() < target) (void) a->grow(target - a->capacity());
+        }
+        else
+        {
+            a->engines--;
+            a->wanted -= std::min(a->wanted, (size_t) -want);
+            a->reap(nullptr);
+            a->shrink(a->engines > 0 ? std::max(a->wanted, floor) : 0);
+        }
     }
 }
 
@@ -950,48 +1049,76 @@ namespace
     {
         if (CtlArena *a = arena_of(device, false))
         {
+            std::vector<CtlArena::Pending> waitfor;
+            {
+                std::lock_guard<std::mutex> g(a->mtx);
+                a->reap(&waitfor);
+            }
+            for (const CtlArena::Pending &pe : waitfor) (void) hipEventSynchronize(pe.ev);
             std::lock_guard<std::mutex> g(a->mtx);
-            a->reap(true);
+            a->reap(nullptr);
         }
     }
 }
 
-// (C ABI, hcv_api.hip: hcv_ctl_reserve) what the control arena of `device` is to hold; takes effect if the device has no engine yet
+// (C ABI, hcv_api.hip: hcv_ctl_reserve) what the control arena of `device` holds at least while the device has an engine; an arena that
+// exists grows to it now (a control call: the driver maps memory under whatever stream is running)
 bool ctl_arena_reserve(int device, size_t bytes)
 {
-    std::lock_guard<std::mutex> g(gArenaMutex);
-    if (gArenas.count(device)) return false;
-    gArenaWanted[device] = bytes;
+    CtlArena *a = nullptr;
+    {
+        std::lock_guard<std::mutex> g(gArenaMutex);
+        gArenaFloor[device] = bytes;
+        auto it = gArenas.find(device);
+        if (it != gArenas.end()) a = it->second;
+    }
+    if (a)
+    {
+        DeviceGuard dg(device);
+        std::lock_guard<std::mutex> g(a->mtx);
+        if (a->engines > 0 && a->capacity() < bytes) return a->grow(bytes - a->capacity());
+    }
     return true;
 }
 
 size_t ctl_arena_size(int device)
 {
     CtlArena *a = arena_of(device, false);
-    return a ? a->size : 0;
+    if (!a) return 0;
+    std::lock_guard<std::mutex> g(a->mtx);
+    return a->capacity();
 }
 
 hipError_t Engine::ctl_alloc(void **p, size_t bytes)
 {
     if (CtlArena *a = arena_of(mDevice, false))
-        if (a->base)
+    {
+        std::vector<CtlArena::Pending> waitfor;
+        void *q = nullptr;
         {
             std::lock_guard<std::mutex> g(a->mtx);
-            a->reap(false);
-            void *q = a->take(bytes);
-            if (!q && !a->pending.empty())
-            {
-                a->reap(true);              // (the control thread may wait for the device: blocks freed a moment ago, not yet through)
-                q = a->take(bytes);
-            }
-            if (q)
-            {
-                *p = q;
-                return hipSuccess;
-            }
+            a->reap(nullptr);
+            q = a->take(bytes);
+            if (!q) a->reap(&waitfor);
         }
+        if (!q && !waitfor.empty())
+        {
+            // (the control thread may wait for the device — blocks freed a moment ago, not yet through — but not with the arena's mutex)
+            for (const CtlArena::Pending &pe : waitfor) (void) hipEventSynchronize(pe.ev);
+            (void) hipGetLastError();
+            std::lock_guard<std::mutex> g(a->mtx);
+            a->reap(nullptr);
+            q = a->take(bytes);
+        }
+        if (q)
+        {
+            *p = q;
+            return hipSuccess;
+        }
+    }
     static const bool arena_debug = std::getenv("HCV_VERBOSE") != nullptr;
     if (arena_debug) std::fprintf(stderr, "[hcv arena] %zu bytes not served by the arena of device %d: stream-ordered pool\n", bytes, mDevice);
+    mArenaMisses.fetch_add(1, std::memory_order_relaxed);
     hipMemPool_t pool = ctl_pool(mDevice);
     const hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, mCtlStream) : hipMallocAsync(p, bytes, mCtlStream);
     if (e != hipSuccess) (void) hipGetLastError();
@@ -1002,7 +1129,13 @@ void Engine::ctl_free(void *p)
 {
     if (!p) return;
     if (CtlArena *a = arena_of(mDevice, false))
-        if (a->base && static_cast<char *>(p) >= a->base && static_cast<char *>(p) < a->base + a->size)
+    {
+        bool ours;
+        {
+            std::lock_guard<std::mutex> g(a->mtx);
+            ours = a->chunk_of(p) != nullptr;
+        }
+        if (ours)
         {
             hipEvent_t ev = nullptr;
             const bool have = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, mCtlStream) == hipSuccess;
@@ -1015,20 +1148,13 @@ void Engine::ctl_free(void *p)
                 ev = nullptr;
             }
             std::lock_guard<std::mutex> g(a->mtx);
-            const size_t off = (size_t) (static_cast<char *>(p) - a->base);
             if (ev)
-                a->pending.push_back({ off, ev });
+                a->pending.push_back({ p, ev });
             else
-            {
-                auto lv = a->live.find(off);
-                if (lv != a->live.end())
-                {
-                    a->release(lv->first, lv->second);
-                    a->live.erase(lv);
-                }
-            }
+                a->give_back(p);
             return;
         }
+    }
     (void) hipFreeAsync(p, mCtlStream);
 }
 
@@ -1130,14 +1256,24 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
         // what the pair still has to deliver belongs to the spectra about to be replaced: take it out of the timelines now
         if (mLoaded[pair] && !mRetired[pair] && !retire_pair(pair)) return false;
         mRetired[pair] = 1;                                                         // (an empty pair has nothing pending)
+        // (the copies of the staged spectra / taps into place and the zeroing of what the old IR had beyond the new one: ONE launch —
+        // this section runs on the audio thread while a stream is running; segments the plan cannot take go the long way)
         bool any = false;
+        SwapPlan plan;
+        auto put = [&](void *dst, const void *src, size_t copy, size_t zero) -> bool
+        {
+            if (plan.add(dst, src, (long long) copy, (long long) zero)) return true;
+            if (copy) HCV_TRY(hipMemcpyAsync(dst, src, copy, hipMemcpyDeviceToDevice, mStream));
+            if (zero) HCV_TRY(hipMemsetAsync(static_cast<char *>(dst) + copy, 0, zero, mStream));
+            return true;
+        };
         for (size_t si = 0; si < mStages.size(); si++)
         {
             Stage &st = *mStages[si];
             const uint32_t newP = std::min(newPs[si], st.Pcap), oldP = st.pact[pair];
             float2 *dst = st.Ht() + pair * st.hstride();
-            if (newP) HCV_TRY(hipMemcpyAsync(dst, st.stage_spec, sizeof(float2) * (size_t) newP * st.M, hipMemcpyDeviceToDevice, mStream));
-            if (oldP > newP) HCV_TRY(hipMemsetAsync(dst + (size_t) newP * st.M, 0, sizeof(float2) * (size_t) (oldP - newP) * st.M, mStream));
+            if (newP || oldP > newP)
+                if (!put(dst, st.stage_spec, sizeof(float2) * (size_t) newP * st.M, oldP > newP ? sizeof(float2) * (size_t) (oldP - newP) * st.M : 0)) return false;
             st.live_parts += newP;
             st.live_parts -= oldP;
             st.pact[pair] = newP;
@@ -1146,17 +1282,15 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
         }
         if (mCfg.has_td)
         {
-            HCV_TRY(hipMemcpyAsync(mTaps + pair * 2048, mStageTaps, sizeof(float) * 2048, hipMemcpyDeviceToDevice, mStream));
-            if (mHeadFFT)
-                HCV_TRY(hipMemcpyAsync(mHeadSpec + pair * (size_t) mStages[0]->M, mStageHead, sizeof(float2) * mStages[0]->M, hipMemcpyDeviceToDevice, mStream));
+            if (!put(mTaps + pair * 2048, mStageTaps, sizeof(float) * 2048, 0)) return false;
+            if (mHeadFFT && !put(mHeadSpec + pair * (size_t) mStages[0]->M, mStageHead, sizeof(float2) * mStages[0]->M, 0)) return false;
             mTdCount[pair] = (uint32_t) taps;
             uint32_t mx = *std::max_element(mTdCount.begin(), mTdCount.end());
             mTdLpad = ((mx + 15) / 16) * 16;
             any = any || taps;
         }
-        if (mLeadSlot)
-            HCV_TRY(hipMemcpyAsync(mStages[mPivot]->Hs + pair * mStages[mPivot]->hstride(), mStageTailHead, sizeof(float2) * mStages[mPivot]->M,
-                                   hipMemcpyDeviceToDevice, mStream));
+        if (mLeadSlot && !put(mStages[mPivot]->Hs + pair * mStages[mPivot]->hstride(), mStageTailHead, sizeof(float2) * mStages[mPivot]->M, 0)) return false;
+        HCV_TRY(launch_swap_in(plan, mStream));
         mLoaded[pair] = any ? 1 : 0;
         __atomic_store_n(&mPending[pair], (uint8_t) 1, __ATOMIC_RELEASE);           // set() always ends in reset()
         mCtlDirty = true;
@@ -1166,7 +1300,12 @@ bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bo
 }
 
 // A section that must run between two blocks, exclusive of the audio thread's enqueue (see CtlJob in hcv_engine.h).
-constexpr long long kStreamingWindowNs = 20000000;      // "a stream is running": a process call within the last 20 ms
+//
+// "A stream is running": a process call within the last kStreamingWindowNs.  The window is what keeps control threads away from the
+// ownership while an audio thread exists at all — a paced real-time host calls every 0.7 - 2.7 ms, an offline loop back to back; only
+// a stream that has been silent for this long (stopped, or not started yet) is taken for stopped.  A control call that arrives within
+// the window of a stream that HAS just stopped waits it out (control threads may wait) before it serves itself.
+constexpr long long kStreamingWindowNs = 400000000;
 
 static inline long long steady_ns()
 {
@@ -1180,164 +1319,119 @@ void set_thread_audio_identity(size_t id) { tlsAudioIdentity = id; }
 size_t current_thread_identity() { return std::hash<std::thread::id>()(std::this_thread::get_id()) | 1; }
 static inline size_t this_thread_hash() { return tlsAudioIdentity ? tlsAudioIdentity : current_thread_identity(); }
 
-constexpr long long kTurnMinGapNs = 350000;             // a paced stream: the lock is free for at least this long per call period
-
-// Control threads, without the engine lock: has the device finished the boundary chains the last call left running?  (The `done`
-// events live as long as their stage; stages are only added or removed by control calls, which mSetMutex serialises with this one.)
-bool Engine::late_chains_done() const
+// test aid (tests/cpp/audio_contract.cpp, tests/test_audio_thread_contract_gpu.py): a control thread sleeps this long INSIDE its part of
+// every posted section's hand-over — after posting, before it looks for the result — and inside every section it runs itself: a
+// preempted control thread, on demand.  Nothing of it is on the audio thread's path.
+static inline long long test_ctl_stall_us()
 {
-    const uint32_t mask = mLateMask.load(std::memory_order_acquire);
-    for (size_t si = 0; si < mStages.size() && si < 16; si++)
-        for (int p = 0; p < 2; p++)
-            if ((mask >> (2 * si + (size_t) p)) & 1u)
-                if (hipEventQuery(mStages[si]->done[p]) == hipErrorNotReady) return false;
-    return true;
+    static const long long us = std::getenv("HCV_TEST_CTL_STALL_US") ? std::atoll(std::getenv("HCV_TEST_CTL_STALL_US")) : 0;
+    return us;
 }
 
-// turn_budget_ns >= 0: only a control TURN is wanted, and only if one comes within that time — otherwise nothing is run and the
-// call returns false (the resets of a control thread: their flags are consumed by the audio thread's next block anyway)
-bool Engine::run_exclusive(std::function<bool()> fn, long long turn_budget_ns)
+bool Engine::run_exclusive(std::function<bool()> fn, int slot)
 {
     // a caller that IS the audio thread (one thread making both kinds of call: offline use, most tests) cannot be inside a
-    // process call: it takes the lock directly
+    // process call: it takes the ownership directly
     const bool same_thread = mAudioThread.load(std::memory_order_acquire) == this_thread_hash();
     for (;;)
     {
-        if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_acquire) < kStreamingWindowNs)
+        const long long since = steady_ns() - mLastAudioNs.load(std::memory_order_seq_cst);
+        if (!same_thread && since < kStreamingWindowNs)
         {
-            const long long period = mAudioPeriodNs.load(std::memory_order_relaxed), hold = mAudioHoldNs.load(std::memory_order_relaxed);
-            // (the gap must hold the section with room to spare — what the sections of earlier turns took, measured, and a quarter more and
-            // 0.1 ms — or the audio thread's next call would find the lock taken by a thread it may even outrank: the mailbox cannot do
-            // that to it)
-            const long long cost = mTurnCostNs.load(std::memory_order_relaxed);
-            const long long need = std::max(kTurnMinGapNs, cost + cost / 4 + 100000);
-            // (a turn refused for the estimate alone lets the estimate age: one slow section — a preempted control thread — must not
-            // keep every later one out)
-            if (period > 0 && period - hold >= kTurnMinGapNs && period - hold < need) mTurnCostNs.store(cost - cost / 8, std::memory_order_relaxed);
-            if (period > 0 && period - hold >= need)
-            {
-                // a paced stream: a control TURN — behind the audio thread's next release of the lock, in the gap before its next call
-                uint64_t seq = mEnqueueSeq.load(std::memory_order_acquire);
-                const long long t0 = steady_ns();
-                int spins = 0;
-                bool stopped = false;
-                for (;;)
-                {
-                    const uint64_t now_seq = mEnqueueSeq.load(std::memory_order_acquire);
-                    // (a call's boundary chains run on into the gap: the section waits for the device inside the lock here and there
-                    // — the ghost staging of a restart — so it takes its turn when they are through, or in a later gap)
-                    if (now_seq != seq && late_chains_done())
-                    {
-                        std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
-                        if (lk.owns_lock())
-                        {
-                            const long long ts = steady_ns();
-                            bool ok = fn();
-                            // the restart the section raised (set() always ends in reset()) is applied here too, at this very block
-                            // boundary: what the audio thread would otherwise do at the start of its next call
-                            ok = ok && apply_pending_resets();
-                            mCtlTurns++;
-                            // (what a section costs, for the gap rule above: quick to rise, slow to fall)
-                            const long long cost = steady_ns() - ts, prev = mTurnCostNs.load(std::memory_order_relaxed);
-                            mTurnCostNs.store(cost > prev ? cost : prev + (cost - prev) / 8, std::memory_order_relaxed);
-                            return ok;
-                        }
-                        seq = now_seq;                      // (the next call is in already: behind that one, then)
-                    }
-                    if ((++spins & 63) == 0)
-                    {
-                        const long long waited = steady_ns() - t0;
-                        if (turn_budget_ns >= 0 && waited > turn_budget_ns) return false;
-                        if (waited > 2 * kStreamingWindowNs) { stopped = true; break; }
-                        if (waited > 3000000) std::this_thread::sleep_for(std::chrono::microseconds(30));     // (a slow stream: stop burning the core)
-                    }
-                    cpu_relax();
-                }
-                if (stopped)
-                {
-                    if (turn_budget_ns >= 0) return false;
-                    continue;                               // no call came: the stream has stopped — look at the clock again
-                }
-            }
-            if (turn_budget_ns >= 0) return false;          // (no turn to be had: the flags wait for the audio thread's next block)
-            // a stream without gaps: hand the section to the audio thread's next call and wait for it (this is the control thread)
+            // a stream is running: hand the section to the audio thread's next call and wait for it (this is the control thread).
+            // (slot 0: the control calls, one at a time under mSetMutex; slot 1: everyone else — synchronize, statistics — one at a time
+            // under mQueryMutex, taken HERE only: a caller that is the audio thread never comes this way)
+            std::unique_lock<std::mutex> one_at_a_time;
+            if (slot == 1) one_at_a_time = std::unique_lock<std::mutex>(mQueryMutex);
             CtlJob job;
             job.fn = fn;
-            mMailbox.store(&job, std::memory_order_release);
-            const long long t0 = steady_ns();
+            mMailbox[slot].store(&job, std::memory_order_release);
+            if (const long long us = test_ctl_stall_us()) std::this_thread::sleep_for(std::chrono::microseconds(us));
+            bool withdrawn = false;
             while (!job.done.load(std::memory_order_acquire))
             {
-                if (steady_ns() - t0 > 2 * kStreamingWindowNs)
+                if (steady_ns() - mLastAudioNs.load(std::memory_order_acquire) > kStreamingWindowNs)
                 {
                     // no call came: the stream has stopped.  Take the section back — unless the audio thread picked it up just now
                     CtlJob *expect = &job;
-                    if (mMailbox.compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel)) break;
+                    if (mMailbox[slot].compare_exchange_strong(expect, nullptr, std::memory_order_acq_rel))
+                    {
+                        withdrawn = true;
+                        break;
+                    }
                 }
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
-            if (job.done.load(std::memory_order_acquire)) return job.ok;
-            continue;                                       // withdrawn: look at the clock again
+            if (!withdrawn) return job.ok;
+            continue;                                       // look at the clock again
         }
-        // no stream: the control thread takes the lock itself (a process call that starts right now polls for this short,
-        // host-only section — lock_for_audio — the one case left in which the audio thread can find the lock taken by a control call)
-        if (turn_budget_ns >= 0) return false;
-        std::unique_lock<std::mutex> lk(mMutex, std::try_to_lock);
-        if (lk.owns_lock())
+        // no stream: the control thread owns the engine for the section.  (Dekker with audio_enter: that side stamps mLastAudioNs, then
+        // tries the ownership; this side takes the ownership, then reads the stamp — a call that started meanwhile is seen here, and the
+        // ownership goes back before anything was touched.  Only a call that starts AFTER this check, inside the section, finds the
+        // engine owned: the first call of a stream — start_collisions.)
+        uint32_t expect = kOwnerFree;
+        if (mOwner.compare_exchange_strong(expect, kOwnerControl, std::memory_order_seq_cst))
         {
-            if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_acquire) < kStreamingWindowNs) continue;   // a stream started meanwhile: post it
-            return fn();
+            if (!same_thread && steady_ns() - mLastAudioNs.load(std::memory_order_seq_cst) < kStreamingWindowNs)
+            {
+                mOwner.store(kOwnerFree, std::memory_order_release);
+                continue;                                   // a stream started meanwhile: post it
+            }
+            if (const long long us = test_ctl_stall_us())
+                if (!same_thread) std::this_thread::sleep_for(std::chrono::microseconds(us));
+            const bool ok = fn();
+            mCtlSections.fetch_add(1, std::memory_order_relaxed);
+            mOwner.store(kOwnerFree, std::memory_order_release);
+            return ok;
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        std::this_thread::sleep_for(std::chrono::microseconds(20));    // (another control thread's section, or a process call of the same thread's... never: a control thread waits)
     }
 }
 
-// audio thread, engine lock held, before it looks at the engine's state
-void Engine::audio_enter()
+// audio thread: sections posted by control threads, between two blocks
+void Engine::run_mailbox()
+{
+    for (int slot = 0; slot < 2; slot++)
+    {
+        if (!mMailbox[slot].load(std::memory_order_acquire)) continue;
+        if (CtlJob *job = mMailbox[slot].exchange(nullptr, std::memory_order_acq_rel))
+        {
+            const long long t0 = steady_ns();
+            job->ok = job->fn();
+            const uint64_t took = (uint64_t) (steady_ns() - t0);
+            mMailboxRuns.fetch_add(1, std::memory_order_relaxed);
+            mMailboxNsTotal.fetch_add(took, std::memory_order_relaxed);
+            uint64_t prev = mMailboxNsMax.load(std::memory_order_relaxed);
+            while (took > prev && !mMailboxNsMax.compare_exchange_weak(prev, took, std::memory_order_relaxed)) {}
+            job->done.store(true, std::memory_order_release);
+        }
+    }
+}
+
+// audio thread, first thing in a process call: ONE attempt at the ownership, no loop, no lock, no device call
+bool Engine::audio_enter()
 {
     const long long now = steady_ns();
-    const long long since = now - mCallStartNs;
-    if (mCallStartNs && since > 0 && since < kStreamingWindowNs)
-    {
-        // start-to-start of the calls, smoothed (1/8): what a control thread reads to tell a paced stream from back-to-back calls
-        const long long p = mAudioPeriodNs.load(std::memory_order_relaxed);
-        mAudioPeriodNs.store(p ? p + (since - p) / 8 : since, std::memory_order_relaxed);
-    }
-    else if (since >= kStreamingWindowNs)
-        mAudioPeriodNs.store(0, std::memory_order_relaxed);         // (a new stream: no estimate yet)
-    mCallStartNs = now;
-    mLastAudioNs.store(now, std::memory_order_release);
+    note_device_streaming(mDevice, now);
+    mLastAudioNs.store(now, std::memory_order_seq_cst);
     mAudioThread.store(this_thread_hash(), std::memory_order_release);
-    if (mMailbox.load(std::memory_order_acquire))
+    uint32_t expect = kOwnerFree;
+    if (!mOwner.compare_exchange_strong(expect, kOwnerAudio, std::memory_order_seq_cst))
     {
-        if (CtlJob *job = mMailbox.exchange(nullptr, std::memory_order_acq_rel))
-        {
-            job->ok = job->fn();
-            mMailboxRuns++;
-            job->done.store(true, std::memory_order_release);
-        }
+        mStartCollisions.fetch_add(1, std::memory_order_relaxed);
+        return false;
     }
+    run_mailbox();
+    return true;
 }
 
-// audio thread, end of a call's enqueue: the lock goes back and control threads waiting for a turn hear of it
-void Engine::audio_leave(std::unique_lock<std::mutex> &lk)
+// audio thread, end of a call's enqueue: a section posted while the call was being enqueued runs now (between this block and the
+// next, as at the start of a call), then the ownership goes back
+void Engine::audio_leave()
 {
-    const long long now = steady_ns();
-    const long long held = now - mCallStartNs;
-    const long long h = mAudioHoldNs.load(std::memory_order_relaxed);
-    mAudioHoldNs.store(h ? h + (held - h) / 8 : held, std::memory_order_relaxed);
-    mLastAudioNs.store(now, std::memory_order_release);
-    if (mMailbox.load(std::memory_order_acquire))
-    {
-        // (a section posted while this call was being enqueued: between this block and the next, as at the start of a call)
-        if (CtlJob *job = mMailbox.exchange(nullptr, std::memory_order_acq_rel))
-        {
-            job->ok = job->fn();
-            mMailboxRuns++;
-            job->done.store(true, std::memory_order_release);
-        }
-    }
-    if (lk.owns_lock()) lk.unlock();
-    mEnqueueSeq.fetch_add(1, std::memory_order_release);
+    run_mailbox();
+    mLastAudioNs.store(steady_ns(), std::memory_order_seq_cst);
+    mOwner.store(kOwnerFree, std::memory_order_release);
 }
 
 // (flag writes, no lock: consumed — exchanged — by the next block's apply_pending_resets)
@@ -1345,7 +1439,6 @@ void Engine::reset_pair(uint32_t in, uint32_t out)
 {
     if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return;
     __atomic_store_n(&mPending[pair_index(in, out)], (uint8_t) 1, __ATOMIC_RELEASE);
-    apply_resets_in_a_turn();
 }
 
 void Engine::reset_all()
@@ -1353,24 +1446,6 @@ void Engine::reset_all()
     // (ONE atomic generation count, not a flag per pair raised one after the other: the block that sees it restarts EVERY pair at the
     // same sample — a block racing the loop used to restart some pairs now and the rest one block later)
     mResetAllGen.fetch_add(1, std::memory_order_release);
-    apply_resets_in_a_turn();
-}
-
-// A control thread resetting pairs of a PACED stream applies the restart itself, in a control turn (its fence, retiring kernels and
-// ghost spectra are device work the audio thread need not enqueue); everywhere else the flags wait for the next block, as the
-// reference's reset flags do (MonoConvolve.cpp:148-152).  The reference's reset is a flag write; this one returns within two call
-// periods (5 ms at most) whether or not it got its turn — the flags are raised either way and the audio thread's next block consumes
-// what is left of them.
-void Engine::apply_resets_in_a_turn()
-{
-    if (mAudioThread.load(std::memory_order_acquire) == this_thread_hash()) return;
-    if (steady_ns() - mLastAudioNs.load(std::memory_order_acquire) >= kStreamingWindowNs) return;
-    const long long period = mAudioPeriodNs.load(std::memory_order_relaxed), hold = mAudioHoldNs.load(std::memory_order_relaxed);
-    if (!(period > 0 && period - hold >= kTurnMinGapNs)) return;
-    std::unique_lock<std::mutex> gs(mSetMutex, std::try_to_lock);       // (control calls are serialised; one in progress applies the flags itself)
-    if (!gs.owns_lock()) return;
-    DeviceGuard dg(mDevice);
-    (void) run_exclusive([]() -> bool { return true; }, std::min<long long>(2 * period, 5000000));
 }
 
 // Every loaded pair restarts: clear the rings and restart the hop clock.  The input-spectrum rings are not
@@ -1399,9 +1474,9 @@ bool Engine::synchronize()
 {
     DeviceGuard dg(mDevice);
     {
-        // (boundary chains the last small block left running past its emit: the main stream goes behind them first)
-        std::lock_guard<std::mutex> g(mMutex);
-        if (!fence_chains()) return false;
+        // (boundary chains the last small block left running past its emit: the main stream goes behind them first — a section, run
+        // between two blocks by whoever owns the engine then)
+        if (!run_exclusive([this]() -> bool { return fence_chains(); }, 1)) return false;
     }
     HCV_TRY(hipStreamSynchronize(mStream));
     if (mProfiling) collect_events();
@@ -1410,13 +1485,17 @@ bool Engine::synchronize()
 
 void Engine::set_profiling(bool on)
 {
-    std::lock_guard<std::mutex> g(mMutex);
-    mProfiling = on;
+    (void) run_exclusive([this, on]() -> bool { mProfiling = on; return true; }, 1);
 }
 
 void Engine::collect_events()
 {
-    std::lock_guard<std::mutex> g(mMutex);
+    (void) run_exclusive([this]() -> bool { collect_events_owned(); return true; }, 1);
+}
+
+// (owner of the engine's state)
+void Engine::collect_events_owned()
+{
     for (EventPair *ev : mEvents)
     {
         if (!ev->live) continue;
@@ -1434,34 +1513,40 @@ void Engine::collect_events()
 
 bool Engine::stage_stats(size_t s, StageStats *out)
 {
-    std::lock_guard<std::mutex> g(mMutex);
-    if (s >= mStages.size() || !out) return false;
-    const Stage &st = *mStages[s];
-    out->fft_size = st.N;
-    out->partitions = st.P;
-    out->nin = mCfg.diag ? 1 : mCfg.nin;
-    out->nout = mCfg.nout;
-    out->mac_launches = st.launches;
-    out->mac_hops = st.hops;
-    out->mac_ms = st.ms;
-    out->ksplit = st.last_ksplit;
-    out->out_tile = st.last_ot;
-    out->mac_steady_launches = st.steady_launches;
-    out->hop_tile = st.last_tt;
-    out->launch_partitions = st.last_parts;
-    out->fused_launches = st.fused_launches;
-    out->fused_stood_down = st.nxm_stood_down;
-    return true;
+    if (!out) return false;
+    return run_exclusive([this, s, out]() -> bool
+    {
+        if (s >= mStages.size()) return false;
+        const Stage &st = *mStages[s];
+        out->fft_size = st.N;
+        out->partitions = st.P;
+        out->nin = mCfg.diag ? 1 : mCfg.nin;
+        out->nout = mCfg.nout;
+        out->mac_launches = st.launches;
+        out->mac_hops = st.hops;
+        out->mac_ms = st.ms;
+        out->ksplit = st.last_ksplit;
+        out->out_tile = st.last_ot;
+        out->mac_steady_launches = st.steady_launches;
+        out->hop_tile = st.last_tt;
+        out->launch_partitions = st.last_parts;
+        out->fused_launches = st.fused_launches;
+        out->fused_stood_down = st.nxm_stood_down;
+        return true;
+    }, 1);
 }
 
 void Engine::clear_stats()
 {
-    std::lock_guard<std::mutex> g(mMutex);
-    for (Stage *st : mStages)
+    (void) run_exclusive([this]() -> bool
     {
-        st->launches = st->hops = st->steady_launches = st->fused_launches = 0;
-        st->ms = 0.0;
-    }
+        for (Stage *st : mStages)
+        {
+            st->launches = st->hops = st->steady_launches = st->fused_launches = 0;
+            st->ms = 0.0;
+        }
+        return true;
+    }, 1);
 }
 
 } // namespace hcv

@@ -550,7 +550,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
     return true;
 }
 
-// One block of at most max_block samples, everything device side.  Caller holds mMutex.
+// One block of at most max_block samples, everything device side.  Caller owns the engine (audio_enter).
 //
 // Stream plan for block k (q = k & 1; every event and the FIR output buffer exist twice, indexed by block parity):
 //
@@ -974,8 +974,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     }
     xcd_pin_hint(false);
     mEmitFirstEv = (blk.emit_first && !blk.direct_out) ? mEvEmit[q] : nullptr;
-    // (for control threads waiting for their turn: which `done` events the device is still working towards after this call — run_exclusive)
-    mLateMask.store(blk.late_mask, std::memory_order_release);
     mN += B;
     mBlockCount++;
     mLastNin = rows_in;
@@ -983,31 +981,16 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     return true;
 }
 
-// The audio thread takes the engine lock with try_lock (MemorySwap::attempt, MemorySwap.h:182-185).  Control calls hold it
-// only for host-only pointer-swap sections (set_ir phase B, the swap of ensure_stage_capacity, flag writes) — no upload, no
-// allocation, no device wait — so contention is polled out; past kAudioLockBudgetNs the block is given up as silence, the
-// whole-matrix form of the reference's muted pair (MonoConvolve.cpp:181-183).
-constexpr long long kAudioLockBudgetNs = 2000000;
-
-bool Engine::lock_for_audio(std::unique_lock<std::mutex> &lk)
+// The staging buffer of the host paths (mDevIn) is ONE buffer, rewritten by every call's upload.  The forward launches of n x m blocks read it
+// from the pipe stream with no event towards the main stream (hcv_fused_nxm.hip): one that arrives late — its block finished by the helping
+// path, the call returned — would otherwise still be reading while the next call's upload lands (the launch itself also stands
+// down once its tasks are marked done).  The upload goes behind the pipe stream: two calls, only while such launches are outstanding.
+bool Engine::input_behind_forward()
 {
-    lk = std::unique_lock<std::mutex>(mMutex, std::try_to_lock);
-    if (lk.owns_lock()) return true;
-    mLockContended++;
-    const auto t0 = std::chrono::steady_clock::now();
-    long long waited = 0;
-    bool got = false;
-    while (waited < kAudioLockBudgetNs)
-    {
-        for (int k = 0; k < 32; k++) cpu_relax();
-        got = lk.try_lock();
-        waited = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-        if (got) break;
-    }
-    uint64_t prev = mLockWaitNsMax.load();
-    while ((uint64_t) waited > prev && !mLockWaitNsMax.compare_exchange_weak(prev, (uint64_t) waited)) {}
-    if (!got) mBlocksMuted++;
-    return got;
+    if (!mFwdPending) return true;
+    HCV_TRY(hipEventRecord(mEvFwd, mPipeStream));
+    HCV_TRY(hipStreamWaitEvent(mStream, mEvFwd, 0));
+    return true;
 }
 
 // Host-pointer path, first half: stage the inputs, enqueue the block and the download of its result.  Small blocks (the
@@ -1023,13 +1006,12 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
     if (B > mMaxBlock) { mErr = "process_begin: block longer than max_block"; return false; }
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
     for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i], sizeof(float) * B);
-    std::unique_lock<std::mutex> lk;
-    if (!lock_for_audio(lk))
+    if (!audio_enter())
     {
-        mHostMuted = true;
+        mHostMuted = true;              // (a stream-start collision, hcv_engine.h: this block is silent, nothing of the engine's state is touched)
         return true;
     }
-    audio_enter();
+    OwnerGuard own(this);
     if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
     static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
     const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
@@ -1044,6 +1026,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         // main stream, a streamed one makes its input stream wait for it (enqueue_chunk, mCtlDirty)
         if (rows_in)
         {
+            if (!input_behind_forward()) return false;
             HCV_TRY(hipMemcpyAsync(mDevIn, mPinIn, sizeof(float) * rows_in * B, hipMemcpyHostToDevice, mStream));
             mCtlDirty = true;
         }
@@ -1060,7 +1043,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
         HCV_TRY(hipEventRecord(mEvHostDone, mStream));
         mHostWait = mEvHostDone;
     }
-    audio_leave(lk);                    // (the clock, a section posted meanwhile, the lock back and a waiting control thread's turn)
+    own.leave();                        // (a section posted meanwhile, the clock, the ownership back)
     return true;
 }
 
@@ -1121,16 +1104,16 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
     for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
     {
         const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
-        std::unique_lock<std::mutex> lk;
-        if (!lock_for_audio(lk))
+        if (!audio_enter())
         {
             for (uint32_t o = 0; o < nout_act; o++) std::memset(outs_host + (size_t) o * out_stride + pos, 0, sizeof(float) * B);
             continue;
         }
-        audio_enter();
+        OwnerGuard own(this);
         if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
         if (rows_in)
         {
+            if (!input_behind_forward()) return false;
             // (a packed block is ONE transfer; a pitched one is moved row by row by the copy engine, a few microseconds per row)
             if (in_stride == (int64_t) B)
                 HCV_TRY(hipMemcpyAsync(mDevIn, ins_host + pos, sizeof(float) * (size_t) B * rows_in, hipMemcpyHostToDevice, mStream));
@@ -1147,7 +1130,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
             HCV_TRY(hipMemcpy2DAsync(outs_host + pos, sizeof(float) * (size_t) out_stride, mDevOut, sizeof(float) * B, sizeof(float) * B, nout_act,
                                      hipMemcpyDeviceToHost, mStream));
         HCV_TRY(hipEventRecord(mEvHostDone, mStream));
-        audio_leave(lk);
+        own.leave();
         HCV_TRY(hipEventSynchronize(mEvHostDone));
     }
     if (mProfiling) collect_events();
@@ -1162,15 +1145,14 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
     nin_act = std::min(nin_act, mCfg.nin);
     if (!nout_act || !n) return true;
     {
-        std::unique_lock<std::mutex> lk;
-        if (!lock_for_audio(lk))
+        if (!audio_enter())
         {
-            // given up: silence for this call (see lock_for_audio); nothing of the engine's state is touched
+            // a stream-start collision (hcv_engine.h): silence for this call; nothing of the engine's state is touched
             HCV_TRY(hipMemset2DAsync(outs, sizeof(float) * (size_t) out_stride, 0, sizeof(float) * n, nout_act, mStream));
             if (sync) HCV_TRY(hipStreamSynchronize(mStream));
             return true;
         }
-        audio_enter();
+        OwnerGuard own(this);
         if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(mCfg.diag ? nout_act : nin_act, nout_act) || !apply_pending_resets()) return false;
         if (after)
         {
@@ -1185,9 +1167,16 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
             const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
             if (!enqueue_chunk(ins + pos, in_stride, outs + pos, out_stride, nin_act, nout_act, B)) return false;
         }
-        audio_leave(lk);
+        // (a call that waits: the main stream goes behind the boundary chains the block left running here, inside the ownership the call
+        // holds anyway, and the wait below needs none)
+        if (sync && !fence_chains()) return false;
+        own.leave();
     }
-    if (sync) return synchronize();
+    if (sync)
+    {
+        HCV_TRY(hipStreamSynchronize(mStream));
+        if (mProfiling) collect_events();
+    }
     return true;
 }
 

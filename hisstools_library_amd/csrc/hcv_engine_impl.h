@@ -16,6 +16,7 @@ namespace hcv
 
 // hcv_queue_probe.hip: fresh streams swapped until they feed different hardware queues (roles[share] the anchor's own)
 int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share);
+void note_device_streaming(int device, long long now_ns);      // (Engine::audio_enter: no experiment beside a running stream)
 
 // hcv_engine.hip: the engines' streams come from a per-device pool and go back to it, idle, when their engine goes — never destroyed.  A
 // stream is a queue handle: an idle one carries nothing over.  Creating and destroying a dozen streams per engine was where two full-suite

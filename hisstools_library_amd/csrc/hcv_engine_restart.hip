@@ -338,7 +338,19 @@ bool Engine::apply_pending_resets()
         // the input spectra older than the hop in progress, and prepare the ghost spectra that make the fence exact to the
         // sample (hcv_ghost.hip).  The time-domain head is fenced per sample directly.
         mCtlDirty = true;
-        std::vector<size_t> restart;
+        std::vector<size_t> &restart = mRestartScratch;
+        restart.clear();
+        // (the pairs' fences — first hop / first sample each may see — go out in launches of kSwapFills values, not one launch per value)
+        SwapPlan fences;
+        auto fence = [&](long long *where, long long v) -> bool
+        {
+            if (fences.nfill == kSwapFills)
+            {
+                HCV_TRY(launch_swap_in(fences, mStream));
+                fences.nfill = 0;
+            }
+            return fences.set(where, v);
+        };
         for (size_t p = 0; p < taken.size(); p++)
         {
             if (!taken[p]) continue;
@@ -348,15 +360,16 @@ bool Engine::apply_pending_resets()
             for (Stage *st : mStages)
             {
                 const long long hvv = mN / st->M;
-                HCV_TRY(launch_fill_i64(st->hv + p, 1, hvv, mStream));
+                if (!fence(st->hv + p, hvv)) return false;
                 st->max_hv = std::max(st->max_hv, hvv);
             }
             if (mTdValid)
             {
-                HCV_TRY(launch_fill_i64(mTdValid + p, 1, mN, mStream));
+                if (!fence(mTdValid + p, mN)) return false;
                 mTdMaxValid = std::max(mTdMaxValid, mN);
             }
         }
+        HCV_TRY(launch_swap_in(fences, mStream));
         if (!make_ghost_event(restart)) return false;
         if (!rebuild_ghost_tables()) return false;
     }

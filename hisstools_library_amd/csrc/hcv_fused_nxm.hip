@@ -135,8 +135,15 @@ namespace
         // spectrum as NEW is long through, the helpers have written every value this launch would write — only counts itself in.
         // (tests/test_fused_nxm_gpu.py::test_four_engines_at_once with every wait forced out: one run in some dozens gave garbage once the
         // forward stream no longer shared the main stream's queue.)
+        // ... and a workgroup that arrives LESS late than that must not redo a task a helper has done either: the helper's
+        // values stand, the multiply-accumulate launch may be through and the main stream past it — and with it the caller's block,
+        // which the next call's upload (or the caller) is then free to overwrite: a transform of THAT would file the next block's
+        // samples as this hop.  So: the task's own mark carries this launch's number (a helper did it), or the multiply-accumulate
+        // launch of this block has started to end (`progress`, every task then done) — count in, write nothing.
         __shared__ int stale_b;
-        if (tid == 0) stale_b = (long long) (__hip_atomic_load(a.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (a.sy.seq + 4)) >= 0;
+        if (tid == 0)
+            stale_b = (long long) (__hip_atomic_load(a.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sy.seq) >= 0 ||
+                      (long long) (__hip_atomic_load(a.sy.flagF + task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.sy.seq) >= 0;
         __syncthreads();
         if (!stale_b) forward_frame<LOG2N>(a, dynf, tid, task);
         grid_publish_sharded(tid, a.sy.flagF + task, a.sy.seq, a.sy.bar, task);
@@ -343,7 +350,8 @@ bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, F
     // (one workgroup per CU, all of them resident at once: with 512 of them in two rounds — and twice the partial spectra for the inverse to add
     // up — the 64 x 8 block took 0.085 ms against 0.083; with 128, half the CUs idle, 0.097)
     while (base * ms * 2 <= 256 && K / (kNxmWaves * ms * 2) >= 6 && (size_t) (ms * 2) * nout * M <= y_elems && ms * 2 <= 8) ms *= 2;
-    if ((size_t) ms * nout * M > y_elems || nin > kFusedFwdTasks) return false;
+    // (the forward tasks' marks are flagF[0 .. nin): the hint and progress marks live in the same array from kNxmHintBase on — ADVICE r5)
+    if ((size_t) ms * nout * M > y_elems || nin > kNxmHintBase) return false;
     pl->ms = ms;
     pl->tiles = tiles;
     pl->kper_old = (int) std::max<long long>(1, (K + kNxmWaves * ms - 1) / (kNxmWaves * ms));

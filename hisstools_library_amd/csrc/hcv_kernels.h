@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 namespace hcv
 {
     constexpr int kMinFFTLog2 = 5;        // PartitionedConvolve.h:18
@@ -199,6 +201,29 @@ namespace hcv
     hipError_t launch_segment_op(float *out, const float *t, long long o_off, long long off, long long n, int op, hipStream_t st);
     hipError_t launch_fold_copy(float *dst, const float *in, long long n, long long fold, int off, hipStream_t st);
     hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st);
+    // a control call's swap section in one launch (pointers and byte counts multiples of 16)
+    constexpr int kSwapSegs = 12, kSwapFills = 12;
+    struct SwapSeg { void *dst; const void *src; long long copy, zero; };
+    struct SwapFill { long long *p; long long v; };
+    struct SwapPlan
+    {
+        SwapSeg seg[kSwapSegs];
+        SwapFill fill[kSwapFills];
+        int nseg = 0, nfill = 0;
+        bool add(void *dst, const void *src, long long copy, long long zero)
+        {
+            if (nseg >= kSwapSegs || ((copy | zero) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15) || (copy && (reinterpret_cast<uintptr_t>(src) & 15))) return false;
+            seg[nseg++] = { dst, src, copy, zero };
+            return true;
+        }
+        bool set(long long *p, long long v)
+        {
+            if (nfill >= kSwapFills) return false;
+            fill[nfill++] = { p, v };
+            return true;
+        }
+    };
+    hipError_t launch_swap_in(const SwapPlan &pl, hipStream_t st);
     hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st);
     hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st);
 }

@@ -1141,6 +1141,34 @@ hipError_t launch_fold_copy(float *dst, const float *in, long long n, long long 
     return hipGetLastError();
 }
 
+// ---- a control call's swap section as ONE launch: up to kSwapSegs segments, each `copy` bytes from src to dst followed by `zero`
+//      bytes of zeros (16-byte granularity), and up to kSwapFills 64-bit values.  The section runs on the audio thread while a stream is
+//      running (hcv_engine.h: the mailbox): a dozen hipMemcpyAsync / hipMemsetAsync calls were most of what it cost there.
+__global__ __launch_bounds__(256) void swap_in_kernel(SwapPlan pl)
+{
+    const int seg = blockIdx.y;
+    if (seg < pl.nseg)
+    {
+        const SwapSeg sg = pl.seg[seg];
+        const long long nc = sg.copy >> 4, nz = sg.zero >> 4;
+        const float4 *src = static_cast<const float4 *>(sg.src);
+        float4 *dst = static_cast<float4 *>(sg.dst);
+        for (long long e = blockIdx.x * (long long) blockDim.x + threadIdx.x; e < nc + nz; e += (long long) gridDim.x * blockDim.x)
+            dst[e] = e < nc ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int) threadIdx.x < pl.nfill) *pl.fill[threadIdx.x].p = pl.fill[threadIdx.x].v;
+}
+
+hipError_t launch_swap_in(const SwapPlan &pl, hipStream_t st)
+{
+    if (pl.nseg <= 0 && pl.nfill <= 0) return hipSuccess;
+    long long most = 0;
+    for (int k = 0; k < pl.nseg; k++) most = std::max(most, (pl.seg[k].copy + pl.seg[k].zero) >> 4);
+    const int gx = (int) std::max<long long>(1, std::min<long long>((most + 1023) / 1024, 512));
+    hipLaunchKernelGGL(swap_in_kernel, dim3(gx, std::max(1, pl.nseg)), dim3(256), 0, st, pl);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_i64(long long *p, long long n, long long v, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;

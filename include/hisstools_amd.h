@@ -62,10 +62,13 @@ HCV_API int hcv_set_default_device(int device);           /* device used by subs
 HCV_API int hcv_get_default_device(void);
 HCV_API const char *hcv_last_error(void);                 /* thread-local text of the last failure */
 /* The control arena (MI355X extension; the reference's MemorySwap allocates on the control thread, MemorySwap.h:187-229, and its malloc
- * never touches the audio thread): device memory for set / resize — regrown spectra, staging buffers — is carved out of ONE block per
- * device that is mapped at the creation of the device's first object, so that no later control call has the driver map memory under a
- * running audio thread.  Default size HCV_CTL_RESERVE_MB (4096); hcv_ctl_reserve sizes it explicitly BEFORE the device's first object
- * (returns -1 once one exists); hcv_ctl_reserved reports what the device holds (0: no arena yet / none). */
+ * never touches the audio thread): device memory for set / resize — regrown spectra, staging buffers — is carved out of an arena per
+ * device that is mapped when objects are CREATED, so that no later control call has the driver map memory under a running audio thread
+ * (which stalls every HIP call of the process for tens of milliseconds).  Every object asks for what one regrow of its largest stage by
+ * half needs (16 MiB .. 1 GiB); the arena shrinks again as objects go and is released with the device's last one.  A host that will load
+ * impulse responses far longer than its objects were created for reserves more: hcv_ctl_reserve(device, bytes) — any time; an existing
+ * arena grows at once — or HCV_CTL_RESERVE_MB set the least the device holds while it has an object.  hcv_ctl_reserved reports what it
+ * holds now. */
 HCV_API int hcv_ctl_reserve(int device, size_t bytes);
 HCV_API size_t hcv_ctl_reserved(int device);
 /* HCV_ORDER_CHECK=1 (debug aid, MI355X extension): while the engines enqueue, the order DESIGN.md section 2 states — program order on a
@@ -198,15 +201,19 @@ HCV_API int hcv_convolver_process_f32_dev_allreduce(hcv_convolver *h, const floa
 HCV_API int hcv_host_register(void *ptr, size_t bytes);
 HCV_API int hcv_host_unregister(void *ptr);
 
-/* The audio-thread contract (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:181-183): process never waits for a
- * control call's upload, allocation or device work, at most for the short host-only section in which a control call swaps its
- * staged result in.  Counters since the last hcv_convolver_clear_stats: process calls that found the engine lock taken, the
- * longest such wait in nanoseconds, and blocks given up as silence after 2 ms (the whole-matrix form of the muted pair). */
+/* The audio-thread contract (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:181-183; ThreadLocks.hpp:51-87): process never
+ * waits for a control call — there is no lock on its path.  The engine's host state has an OWNER: the thread inside a process call, or,
+ * only while no stream is running (no process call for 0.4 s), a control thread inside the short section that swaps its staged result
+ * in.  While a stream is running control calls post that section and the audio thread runs it between two of its blocks; the pair
+ * plays its previous impulse response until then (the reference mutes it).  Counters since the last hcv_convolver_clear_stats. */
 typedef struct hcv_rt_stats
 {
-    uint64_t lock_contended, lock_wait_ns_max, blocks_muted;
-    uint64_t mailbox_runs;      /* swap sections of control calls that the audio thread ran between two of its blocks (a stream without gaps) */
-    uint64_t ctl_turns;         /* swap sections control threads ran themselves, in the gap between two calls of a paced stream */
+    uint64_t start_collisions;  /* process calls that found a control thread inside a section: only the FIRST call of a stream (after a pause of
+                                 * 0.4 s or more) can; that call's block is silent — no wait, no retry — and the next call proceeds */
+    uint64_t mailbox_runs;      /* swap sections of control calls that the audio thread ran between two of its blocks */
+    uint64_t mailbox_ns_max;    /* ... the longest of them, nanoseconds of the audio thread's time */
+    uint64_t mailbox_ns_total;  /* ... and their sum */
+    uint64_t ctl_sections;      /* swap sections control threads ran themselves (no stream running) */
 } hcv_rt_stats;
 HCV_API int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out);
 

@@ -1,21 +1,20 @@
-"""The audio-thread contract of the reference (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:118-140,181-183):
-`process` never waits for a control thread's `set` / `resize` — not for the IR upload, not for an allocation, not for the
-device.  The reference mutes the pair being replaced for the blocks processed meanwhile; here the pair keeps playing its
-previous IR until the staged spectra are swapped in (engine.h: set_ir phases A / B).  The swap section itself — retiring kernels,
-device-to-device copies, the restart's fence and ghost spectra: a few dozen HIP calls — is not the audio thread's work either
-(round 4, hcv_engine.h "Control TURNS"): beside a PACED stream the control thread waits for the audio thread to release the
-engine lock at the end of its next enqueue, takes the lock right behind it and runs the section, and the restart it raises, in
-the gap before the next call — `ctl_turns` counts them; the audio thread's part is nothing, `mailbox_runs` (sections the audio
-thread ran itself: the form kept for streams without gaps) stays near zero, and a call finds the lock taken only if a section
-overruns the gap (a preempted control thread): `lock_contended` is expected 0 and tolerated up to 2 short waits, no block is ever
-given up.
+"""The audio-thread contract of the reference (MemorySwap::attempt, MemorySwap.h:182-185; MonoConvolve.cpp:118-140,181-183;
+ThreadLocks.hpp:51-87): `process` never waits for a control thread's `set` / `resize` — not for the IR upload, not for an allocation,
+not for the device, and not for a lock: the engine's host state has an OWNER (hcv_engine.h: Engine::mOwner), the audio thread makes
+one compare-exchange per call, and while a stream is running control calls POST their swap section — retiring kernels, the copies of
+the staged spectra, the restart's fence and ghost spectra — for the audio thread to run between two of its blocks (`mailbox_runs`,
+`mailbox_ns_max`).  The reference mutes the pair being replaced for the blocks processed meanwhile; here the pair keeps playing its
+previous IR until the swap.  A control thread that loses its core holds nothing the audio thread needs (tests/cpp/audio_contract.cpp
+is the same scenario from C++, SCHED_FIFO audio thread, with the control thread stalled on purpose).
 
 A control thread loops set(resize=True) with GROWING 10 s-class IRs on a 16x16 zero-latency engine — every growth re-strides the
-tail stage's whole spectrum store — while the audio thread issues paced 128-sample calls.  Asserted: the calls stay inside the
-2.67 ms real-time budget of 128 samples at 48 kHz (p99 below three quarters of it, none near the 19 - 49 ms a regrow's memory mapping
-used to cost, at most one in two hundred over it on a loaded host and none on a quiet one); no block was given up; the outputs whose pairs are NOT being replaced equal
-the CPU oracle's sample for sample (tolerance 1e-5) right through the swaps and regrows; the replaced pairs stay finite; and
-after the control thread has finished, a known IR set + reset gives the oracle's stream again.
+tail stage's whole spectrum store — while the audio thread issues paced 128-sample calls.  Asserted AT ANY LOAD, engine-exact: no
+call ever found the engine owned by a control thread (`start_collisions == 0`), every set()'s section ran on the audio thread, no
+control thread owned the engine while the stream ran; the outputs whose pairs are NOT being replaced equal the CPU oracle's sample
+for sample (tolerance 1e-5) right through the swaps and regrows; the replaced pairs stay finite; and after the control thread has
+finished, a known IR set + reset gives the oracle's stream again.  The wall-clock side (Python threads: the GIL and the host's
+scheduler are in it) is asserted on a quiet host only — p99 below three quarters of the budget, at most one call in two hundred
+over it, none near a stall — and printed otherwise; the C++ programme carries the strict form (no call over budget).
 """
 import os
 import threading
@@ -55,45 +54,26 @@ def test_process_never_waits_for_set_or_regrow(H, oracle, entry):
 
 def test_process_never_waits_for_set_or_regrow_at_32_samples_per_call(H, oracle):
     """The same contract at the smallest block size hosts use: 32-sample calls (0.67 ms budget), 4200 of them (2.8 s of audio), beside
-    ~700 set(resize) calls.  The same criteria (no block given up, the sections in control turns); of the wall-clock ones p99 stays
-    below 3/4 of the budget.  Measured with the sections in control turns: p50 0.056, p99 0.163, max 0.316 ms, none of 4200 over
-    budget (round 3, sections on the audio thread: 1 - 5 calls at 0.7 - 1.1 ms); round 5, regrown buffers out of the control arena: max
-    0.32 - 0.39 ms on a quiet box, none over budget."""
+    ~700 set(resize) calls.  The same criteria."""
     _scenario(H, oracle, "device_pointers", RB=32, ncalls=4200)
 
 
-def _timing_criteria(rt, sets, ts, budget, over_max):
-    # The lock is found taken only where a stream starts under a control call, or a control thread is late with its turn: a couple
-    # of times per run, for the length of a host-only section.  On a shared host under load (the pool's boxes run at load averages of
-    # 20 - 50 on 256 cores) the control thread — a Python thread — can lose its core INSIDE its section: one run in a few then shows
-    # a wait of 1 - 2 ms, and a wait that reaches the 2 ms bound gives the block up as silence, which is what the bound is for
-    # (profiles/r05_audio_contract_boxes.txt, box C: 3 runs at load 45, two such waits, one muted block in a fourth run).  There the
-    # criterion is "not systematically": at most one block given up and a handful of contended calls; on a quiet host, none.
-    loaded = os.getloadavg()[0] > 8.0
-    if loaded:
-        assert rt["blocks_muted"] <= 1 and rt["lock_contended"] <= max(4, len(ts) // 500) and rt["lock_wait_ns_max"] < 2_500_000, rt
-    else:
-        assert rt["blocks_muted"] == 0 and rt["lock_contended"] <= 2 and rt["lock_wait_ns_max"] < 1_000_000, rt
-    assert rt["ctl_turns"] + rt["mailbox_runs"] >= sets["n"] - 1 and rt["mailbox_runs"] <= max(2, sets["n"] // 20), (rt, sets["n"])
-    # The wall-clock side is measured from a Python thread on a shared host, where a preempted caller shows up as one slow call:
-    # all but a handful of the 1400 calls inside the budget, none that looks like a stall behind an upload or a regrow (tens to
-    # hundreds of milliseconds in round 1), p99 well inside it
-    # (round 4 tolerated up to 100 ms here and retried the scenario: the one call that met the driver mapping a regrown stage's new memory
-    # stalled with every other HIP call of the process, 19 to 49 ms by box.  Round 5: the regrown buffers come out of the control arena,
-    # mapped before any stream runs — hcv_engine.hip: no retry, and nothing is left that looks like that stall)
-    # What is asserted of the wall clock: p99 inside three quarters of the budget; no call anywhere near the stall's signature (19 ms and
-    # more); and at most one call in two hundred over the budget.  On a quiet box NONE is (profiles/r05_audio_contract_boxes.txt: three
-    # runs, max 0.29 - 0.98 ms at 128 samples, 0.32 - 0.39 at 32); on a shared host under load (256 cores, load average 22 - 34) the
-    # Python audio thread loses its core now and then and up to 16 of 4200 calls took 0.9 - 5 ms with every counter of the engine clean.
+def _engine_criteria(rt, sets):
+    """Exact counters of the engine: the same at any load"""
+    assert rt["start_collisions"] == 0, rt
+    assert rt["ctl_sections"] == 0, rt                                  # no control thread owned the engine while the stream ran
+    assert rt["mailbox_runs"] >= sets["n"] - 2, (rt, sets["n"])         # every set()'s section (a regrow's two more) ran on the audio thread
+
+
+def _wall_clock_criteria(ts, budget):
+    """p99 inside three quarters of the budget, at most one call in two hundred over it, none that looks like a stall behind an upload
+    or a regrow (19 ms and more: what a regrow's memory mapping cost before the control arena)"""
     over = int((ts > budget).sum())
-    # (a host at load 45 showed one call of 19.4 ms with a 19.6 ms set() beside it and every engine counter clean — both threads off their
-    # cores at once; the stall's signature is only told from that on a quiet host)
-    worst_allowed = 100.0 if loaded else 19.0
-    assert over <= max(over_max, len(ts) // 200) and ts.max() < worst_allowed, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
+    assert over <= len(ts) // 200 and ts.max() < 19.0, f"{over} process calls over the {budget:.2f} ms budget beside set(), worst {ts.max():.3f} ms"
     assert np.percentile(ts, 99) < 0.75 * budget, f"p99 {np.percentile(ts, 99):.3f} ms"
 
 
-def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=0):
+def _scenario(H, oracle, entry, RB=128, ncalls=1400):
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
     nin = nout = 16
@@ -102,6 +82,17 @@ def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=0):
     L_fix = 60000                                      # (ncalls = 1400 calls of 128 samples: 3.7 s of audio)
     S = ncalls * RB
     xs = np.stack([oracle.synth_audio(i, S) for i in range(nin)])
+    # The object is created for 1.25 s impulse responses and the control thread grows them eightfold beside the running stream: a host
+    # that does that reserves the control path's memory first (include/hisstools_amd.h: hcv_ctl_reserve), or the regrows have the driver
+    # map a gigabyte under the audio thread — 19 - 49 ms in which every HIP call of the process stalls.
+    H.ctl_reserve(0, 3 << 30)
+    try:
+        _scenario_body(H, oracle, entry, RB, ncalls, torch, dev, nin, nout, fs, steady, L_fix, S, xs)
+    finally:
+        H.ctl_reserve(0, 0)
+
+
+def _scenario_body(H, oracle, entry, RB, ncalls, torch, dev, nin, nout, fs, steady, L_fix, S, xs):
     # ("sharded": the same through ONE object driving two engines on the GPU — rows 0..7 on the first, 8..15, the ones being
     #  replaced, on the second: control calls and process calls meet per shard)
     c = H.Convolver(nin, nout, 0, maxBlock=8192, devices=[0, 0]) if entry.startswith("sharded") else H.Convolver(nin, nout, 0, maxBlock=8192)
@@ -152,42 +143,32 @@ def _scenario(H, oracle, entry, RB=128, ncalls=1400, over_max=0):
     th.start()
     try:
         ts = _paced(call, ncalls, RB / fs)
+        # (the counters as the stream ends: a set() still in flight then waits the streaming window out and serves itself, rightly)
+        rt = c.rt_stats()
     finally:
         stop.set()
         th.join()
     if entry == "device_pointers":
         ys = yd.cpu().numpy()
-    rt = c.rt_stats()
     budget = 1e3 * RB / fs
     print(f"[{entry}] over budget: {int((ts > 1e3 * RB / fs).sum())} of {ncalls} calls, slowest five {np.sort(ts)[-5:].round(3).tolist()}")
     print(f"[{entry}] {sets['n']} set(resize) calls (worst {sets['worst_ms']:.1f} ms each) beside {ncalls} paced calls: p50 {np.percentile(ts, 50):.3f} "
-          f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); lock contended {rt['lock_contended']}x, longest wait "
-          f"{rt['lock_wait_ns_max'] / 1e3:.1f} us, blocks muted {rt['blocks_muted']}, sections run by control threads in their turns "
-          f"{rt['ctl_turns']}, by the audio thread {rt['mailbox_runs']}")
+          f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); start collisions {rt['start_collisions']}, sections run by the "
+          f"audio thread {rt['mailbox_runs']} (longest {rt['mailbox_ns_max'] / 1e3:.1f} us, mean "
+          f"{rt['mailbox_ns_total'] / 1e3 / max(1, rt['mailbox_runs']):.1f} us), by control threads {rt['ctl_sections']}")
     assert not sets["errors"] and sets["n"] >= 8                         # every length was loaded at least once: the stage regrew
-    # the stream never stopped and is paced: every swap section ran in a control turn between two calls (at least one per set();
-    # a regrow's pointer swap is one more), next to none on the audio thread; no block was given up, and the lock was found taken
-    # at most twice, briefly (a section that overran the gap)
-    if os.environ.get("SAN_RUN"):
-        # (tools/sanitize/run.sh: an instrumented library is several times slower — sections overrun their gaps, calls their budgets; the
-        # wall-clock criteria are not that run's subject, the engine-exact ones below the timing block are)
-        assert rt["blocks_muted"] == 0 and not sets["errors"]
+    _engine_criteria(rt, sets)
+    load = os.getloadavg()[0]
+    if os.environ.get("SAN_RUN") or load > 8.0:
+        # (an instrumented library — tools/sanitize/run.sh — or a shared host under load: a pre-empted Python audio thread is one slow
+        # call with every counter of the engine clean; the wall clock is printed above and not asserted)
+        print(f"[{entry}] wall-clock criteria not asserted (load average {load:.1f}{', sanitizer run' if os.environ.get('SAN_RUN') else ''})")
     else:
-        _timing_criteria(rt, sets, ts, budget, over_max)
+        _wall_clock_criteria(ts, budget)
     assert np.isfinite(ys).all()
     y_ref = ref.run(xs, len(steady), 2048)
-    if rt["blocks_muted"] == 0:
-        for k, o in enumerate(steady):
-            assert rel_err(ys[o], y_ref[k]) < 1e-5, (o, rel_err(ys[o], y_ref[k]))
-    else:
-        # (a loaded host, _timing_criteria: ONE block was given up as silence — the whole-matrix form of the reference's muted pair.  Every
-        # sample outside a window of one block + the longest untouched IR behind the first difference is still the oracle's.)
-        d = np.abs(ys[steady[0]].astype(np.float64) - y_ref[0]) > 1e-5 * np.abs(y_ref[0]).max()
-        first = int(np.argmax(d))
-        keep = np.ones(ys.shape[1], bool)
-        keep[first: first + RB + L_fix] = False
-        for k, o in enumerate(steady):
-            assert rel_err(ys[o][keep], y_ref[k][keep]) < 1e-5, (o, first)
+    for k, o in enumerate(steady):
+        assert rel_err(ys[o], y_ref[k]) < 1e-5, (o, rel_err(ys[o], y_ref[k]))
     # afterwards: known IRs everywhere + reset -> the oracle's stream again (nothing stale survived the swaps and regrows)
     rows = [0, 9, 15]
     ref2 = oracle.Convolver(nin, len(rows), 0)

@@ -107,3 +107,25 @@ def test_reference_golden_vectors_through_the_cpp_headers(tmp_path):
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all golden vectors within tolerance" in out.stdout and out.stdout.count(" ok") >= 22
+
+
+CONTRACT_SRC = os.path.join(ROOT, "tests", "cpp", "audio_contract.cpp")
+CONTRACT_EXE = os.path.join(OUT_DIR, "audio_contract")
+
+
+def test_audio_contract_programme_compiles_and_links():
+    build(CONTRACT_SRC, CONTRACT_EXE)
+    assert subprocess.call([CONTRACT_EXE]) in (0, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block,calls", [(128, 1400), (32, 4200)])
+def test_audio_thread_contract_from_cpp(block, calls):
+    """tests/cpp/audio_contract.cpp: HISSTools::Convolver, a SCHED_FIFO audio thread (where permitted) making paced host-pointer calls,
+    a control thread looping set(resize) with growing 10 s impulse responses and stalled 300 us inside every control call's hand-over.
+    Engine-exact criteria at any load (no start collision, every section on the audio thread, the untouched rows unchanged); no call
+    over its budget and the slowest call inside it on a quiet host (MemorySwap.h:182-185, MonoConvolve.cpp:181-183)."""
+    build(CONTRACT_SRC, CONTRACT_EXE)
+    out = subprocess.run([CONTRACT_EXE, str(block), str(calls), "300"], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -89,3 +89,16 @@ def test_a_forward_stream_that_falls_blocks_behind_keeps_off_the_rings():
     # hcv_stage_stats.fused_stood_down — so the repetitions agree to rounding, not bit for bit)
     s = _run(16, 8, 96000, 40, "dev", extra_env={"HCV_NXM_TEST_DELAY_US": "300"})
     assert s["max_err"] < TOL, (s, r)
+
+
+def test_a_late_forward_launch_never_transforms_the_next_calls_upload():
+    """Host-pointer calls stage every block in ONE buffer, rewritten by the next call's upload.  With every wait forced out (the helping path
+    computes each block, the call returns) and the forward stream held back 0.3 ms, the forward launch of block k arrives while call k + 1 .. k + 3
+    is uploading: it must neither redo a task a helper has done (fwd_publish_kernel: the task's mark, `progress`) nor find its input rewritten
+    (Engine::input_behind_forward: the upload goes behind the pipe stream) — the oracle's stream, and the same bits as the undisturbed run
+    (ADVICE r5, high)."""
+    r = _run(16, 8, 96000, 28, "host")
+    assert r["max_err"] < TOL and r["tail_err"] < TOL and r["fused_launches"] >= 10, r
+    d = _run(16, 8, 96000, 28, "host", extra_env={"HCV_COOP_SPIN": "0", "HCV_NXM_TEST_DELAY_US": "300"})
+    assert d["max_err"] < TOL and d["tail_err"] < TOL and d["fused_launches"] >= 10, d
+    assert d["sha"] == r["sha"], (d, r)

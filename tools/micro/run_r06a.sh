@@ -1,0 +1,8 @@
+mkdir -p gpurun_out
+{
+echo "== C++ contract 128"; tests/cpp/build/audio_contract 128 1400 300
+echo "== C++ contract 32"; tests/cpp/build/audio_contract 32 4200 300
+echo "== C++ contract 32, control thread stalled 2 ms"; tests/cpp/build/audio_contract 32 4200 2000
+} 2>&1 | tee gpurun_out/contract_cpp.log
+timeout 1200 python -m pytest tests/test_audio_thread_contract_gpu.py -x -q -s 2>&1 | tail -30 | tee gpurun_out/contract_py.log
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/gpu_suite.log

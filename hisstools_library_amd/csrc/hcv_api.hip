@@ -1577,7 +1577,7 @@ extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
 extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
 {
     if (!out) return -1;
-    out->start_collisions = out->mailbox_runs = out->mailbox_ns_max = out->mailbox_ns_total = out->ctl_sections = 0;
+    out->start_collisions = out->mailbox_runs = out->mailbox_ns_max = out->mailbox_ns_total = out->ctl_sections = out->arena_misses = 0;
     auto add = [&](Engine &e)
     {
         const Engine::RtStats r = e.rt_stats();
@@ -1586,6 +1586,7 @@ extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
         out->mailbox_ns_max = std::max<uint64_t>(out->mailbox_ns_max, r.mailbox_ns_max);
         out->mailbox_ns_total += r.mailbox_ns_total;
         out->ctl_sections += r.ctl_sections;
+        out->arena_misses += r.arena_misses;
     };
     auto visit = [&](Matrix &m)
     {

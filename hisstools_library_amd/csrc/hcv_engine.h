@@ -147,9 +147,9 @@ namespace hcv
         // the one case left in which a process call cannot have the state: the FIRST call of a stream (no call for kStreamingWindowNs
         // before it) arriving while a control thread is inside a section it began during the pause — that call's block is silent, as every
         // pair under a set() is in the reference, and the call after it proceeds.
-        struct RtStats { uint64_t start_collisions, mailbox_runs, mailbox_ns_max, mailbox_ns_total, ctl_sections; };
-        RtStats rt_stats() const { return { mStartCollisions.load(), mMailboxRuns.load(), mMailboxNsMax.load(), mMailboxNsTotal.load(), mCtlSections.load() }; }
-        void clear_rt_stats() { mStartCollisions = 0; mMailboxRuns = 0; mMailboxNsMax = 0; mMailboxNsTotal = 0; mCtlSections = 0; }
+        struct RtStats { uint64_t start_collisions, mailbox_runs, mailbox_ns_max, mailbox_ns_total, ctl_sections, arena_misses; };
+        RtStats rt_stats() const { return { mStartCollisions.load(), mMailboxRuns.load(), mMailboxNsMax.load(), mMailboxNsTotal.load(), mCtlSections.load(), mArenaMisses.load() }; }
+        void clear_rt_stats() { mStartCollisions = 0; mMailboxRuns = 0; mMailboxNsMax = 0; mMailboxNsTotal = 0; mCtlSections = 0; mArenaMisses = 0; }
 
         void set_profiling(bool on);
         // HCV_REFERENCE_QUIRKS (hcv_api.hip): the next blocks leave the time-domain head out — what MonoConvolve::process does to it in a

@@ -246,8 +246,8 @@ int spread_streams(hipStream_t anchor, hipStream_t **roles, int n, int share)
     }
     if (std::getenv("HCV_VERBOSE"))
     {
-        std::fprintf(stderr, "[hcv] queue probe: %zu queues known, %d experiments%s, %d of %d busy streams placed, %d replaced; classes:", qm.reps.size(), experiments,
-                     may_probe ? "" : " (none allowed: the device is streaming)", served, n, replaced);
+        std::fprintf(stderr, "[hcv] queue probe: %zu queues known, %d experiments%s, main stream on queue %d, %d of %d busy streams placed, %d replaced; classes:",
+                     qm.reps.size(), experiments, may_probe ? "" : " (none allowed: the device is streaming)", anchor_cls, served, n, replaced);
         for (int r = 0; r < n; r++) std::fprintf(stderr, " %d", pick[r] >= 0 ? cands[pick[r]].cls : -1);
         std::fprintf(stderr, "\n");
     }

@@ -214,6 +214,8 @@ typedef struct hcv_rt_stats
     uint64_t mailbox_ns_max;    /* ... the longest of them, nanoseconds of the audio thread's time */
     uint64_t mailbox_ns_total;  /* ... and their sum */
     uint64_t ctl_sections;      /* swap sections control threads ran themselves (no stream running) */
+    uint64_t arena_misses;      /* control-path allocations the control arena could not serve: the driver mapped memory, and every stream of the
+                                 * process may have stalled for tens of milliseconds meanwhile (hcv_ctl_reserve) */
 } hcv_rt_stats;
 HCV_API int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out);
 

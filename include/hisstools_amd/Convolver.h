@@ -2,6 +2,7 @@
 // libhisstools_amd.so; the matrix then lives on the MI355X (IR spectra resident in HBM).
 #pragma once
 
+#include "MemorySwap.h"              // (Convolver.h:4 of the reference makes MemorySwap / thread_lock visible to its callers)
 #include "NToMonoConvolve.h"
 #include "ConvolveErrors.h"
 

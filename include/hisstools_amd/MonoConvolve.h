@@ -2,7 +2,10 @@
 #pragma once
 
 #include "../hisstools_amd.h"
+#include "PartitionedConvolve.h"
+#include "TimeDomainConvolve.h"
 #include "ConvolveErrors.h"
+#include "MemorySwap.h"
 
 #include <cstdint>
 #include <stdexcept>

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "../hisstools_amd.h"
+#include "HISSTools_FFT.h"           // (PartitionedConvolve.h:4 of the reference: its callers see the hisstools_* transforms)
 #include "ConvolveErrors.h"
 
 #include <cstdint>

@@ -78,7 +78,7 @@ int main(int argc, char **argv)
 
     // The objects are created for 1.25 s impulse responses and the control thread grows them to `ir_seconds`: a host that does that reserves
     // the control path's memory first, or the regrows have the driver map a gigabyte under the audio thread (hisstools_amd.h: hcv_ctl_reserve)
-    hcv_ctl_reserve(hcv_get_default_device() >= 0 ? hcv_get_default_device() : 0, (size_t) 3 << 30);
+    hcv_ctl_reserve(hcv_get_default_device() >= 0 ? hcv_get_default_device() : 0, (size_t) 4 << 30);
     // two convolvers with the same sixteen-by-sixteen matrix: `c` meets the control thread, `q` never does
     HISSTools::Convolver c(nin, nout, kLatencyZero), q(nin, nout, kLatencyZero);
     const size_t L_fix = 60000;
@@ -172,9 +172,10 @@ int main(int argc, char **argv)
                 fifo ? "SCHED_FIFO" : "SCHED_OTHER (SCHED_FIFO refused)", stall_us, load[0]);
     std::printf("  %d set(resize) calls beside them (worst %.1f ms each), %d errors\n", sets.load(), worst_set_ms, set_errors.load());
     std::printf("  calls: p50 %.4f  p99 %.4f  max %.4f ms, %zu over budget\n", sorted[ncalls / 2], sorted[(size_t) (0.99 * (double) ncalls)], sorted.back(), over);
-    std::printf("  engine: start_collisions %llu, sections run by the audio thread %llu (longest %.1f us, mean %.1f us), by control threads %llu\n",
+    std::printf("  engine: start_collisions %llu, sections run by the audio thread %llu (longest %.1f us, mean %.1f us), by control threads %llu; arena misses %llu\n",
                 (unsigned long long) rt.start_collisions, (unsigned long long) rt.mailbox_runs, (double) rt.mailbox_ns_max / 1e3,
-                rt.mailbox_runs ? (double) rt.mailbox_ns_total / 1e3 / (double) rt.mailbox_runs : 0.0, (unsigned long long) rt.ctl_sections);
+                rt.mailbox_runs ? (double) rt.mailbox_ns_total / 1e3 / (double) rt.mailbox_runs : 0.0, (unsigned long long) rt.ctl_sections,
+                (unsigned long long) rt.arena_misses);
 
     int failed = 0;
     auto criterion = [&](bool ok, bool asserted, const char *what)
@@ -186,6 +187,7 @@ int main(int argc, char **argv)
     criterion(set_errors.load() == 0, true, "every set() succeeded");
     criterion((int) rt.mailbox_runs >= sets_seen - 1, true, "every set()'s swap section ran on the audio thread, between two of its blocks");
     criterion(rt.ctl_sections == 0, true, "no control thread owned the engine while the stream ran");
+    criterion(rt.arena_misses == 0, true, "every regrow was served by the control arena reserved for it (no driver mapping under the stream)");
     // (a control thread stalled for milliseconds per call makes fewer of them)
     criterion(sets_seen >= (RB <= 32 ? (stall_us <= 500 ? 700 : 250) : 100) || ncalls < 1400, true, "enough set(resize) calls met the stream");
     criterion(over == 0, strict, "no call over its budget");

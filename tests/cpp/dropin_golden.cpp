@@ -94,11 +94,16 @@ namespace
 
     std::vector<float> run_mono(HISSTools::MonoConvolve &m, const std::vector<float> &x, Blocks blocks)
     {
-        std::vector<float> y(x.size(), 0.f), temp(x.size(), 0.f);
+        // (the scratch block a host of the reference keeps in a MemorySwap<float> — MemorySwap.h:19-290, visible through Convolver.h — grown
+        // on the control side, taken without waiting on the audio side: the drop-in header gives the same type)
+        static MemorySwap<float> scratch(0);
+        scratch.grow(x.size());
+        std::vector<float> y(x.size(), 0.f);
         for (size_t pos = 0; pos < x.size();)
         {
             const size_t n = blocks.next(x.size() - pos);
-            m.process(x.data() + pos, temp.data(), y.data() + pos, n);
+            MemorySwap<float>::Ptr temp = scratch.attempt();
+            if (temp.get() && temp.getSize() >= n) m.process(x.data() + pos, temp.get(), y.data() + pos, n);
             pos += n;
         }
         return y;

@@ -62,6 +62,7 @@ def _engine_criteria(rt, sets):
     """Exact counters of the engine: the same at any load"""
     assert rt["start_collisions"] == 0, rt
     assert rt["ctl_sections"] == 0, rt                                  # no control thread owned the engine while the stream ran
+    assert rt["arena_misses"] == 0, rt                                  # every regrow came out of the arena reserved for it
     assert rt["mailbox_runs"] >= sets["n"] - 2, (rt, sets["n"])         # every set()'s section (a regrow's two more) ran on the audio thread
 
 
@@ -85,7 +86,7 @@ def _scenario(H, oracle, entry, RB=128, ncalls=1400):
     # The object is created for 1.25 s impulse responses and the control thread grows them eightfold beside the running stream: a host
     # that does that reserves the control path's memory first (include/hisstools_amd.h: hcv_ctl_reserve), or the regrows have the driver
     # map a gigabyte under the audio thread — 19 - 49 ms in which every HIP call of the process stalls.
-    H.ctl_reserve(0, 3 << 30)
+    H.ctl_reserve(0, 4 << 30)
     try:
         _scenario_body(H, oracle, entry, RB, ncalls, torch, dev, nin, nout, fs, steady, L_fix, S, xs)
     finally:
@@ -155,7 +156,7 @@ def _scenario_body(H, oracle, entry, RB, ncalls, torch, dev, nin, nout, fs, stea
     print(f"[{entry}] {sets['n']} set(resize) calls (worst {sets['worst_ms']:.1f} ms each) beside {ncalls} paced calls: p50 {np.percentile(ts, 50):.3f} "
           f"p99 {np.percentile(ts, 99):.3f} max {ts.max():.3f} ms (budget {budget:.2f}); start collisions {rt['start_collisions']}, sections run by the "
           f"audio thread {rt['mailbox_runs']} (longest {rt['mailbox_ns_max'] / 1e3:.1f} us, mean "
-          f"{rt['mailbox_ns_total'] / 1e3 / max(1, rt['mailbox_runs']):.1f} us), by control threads {rt['ctl_sections']}")
+          f"{rt['mailbox_ns_total'] / 1e3 / max(1, rt['mailbox_runs']):.1f} us), by control threads {rt['ctl_sections']}; arena misses {rt['arena_misses']}")
     assert not sets["errors"] and sets["n"] >= 8                         # every length was loaded at least once: the stage regrew
     _engine_criteria(rt, sets)
     load = os.getloadavg()[0]

@@ -19,7 +19,7 @@ FFT_EXE = os.path.join(OUT_DIR, "fft_tester")
 def build(src=SRC, exe=EXE):
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", src, "-o", exe, f"-L{LIBDIR}", "-lhisstools_amd",
-           f"-Wl,-rpath,{LIBDIR}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+           f"-Wl,-rpath,{LIBDIR}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
     subprocess.check_call(cmd)
 
 
@@ -129,3 +129,17 @@ def test_audio_thread_contract_from_cpp(block, calls):
     out = subprocess.run([CONTRACT_EXE, str(block), str(calls), "300"], capture_output=True, text=True, timeout=600)
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+UTIL_SRC = os.path.join(ROOT, "tests", "cpp", "utility_types.cpp")
+UTIL_EXE = os.path.join(OUT_DIR, "utility_types")
+
+
+def test_utility_types_behave_like_the_references():
+    """MemorySwap<T> / Ptr, thread_lock, lock_hold (MemorySwap.h:19-290, ThreadLocks.hpp:51-120 — visible to every caller of the reference's
+    Convolver.h) and FloatVector / ALIGNED_MALLOC (ConvolveSIMD.h:62-107) through the drop-in headers: attempt() fails empty while another
+    thread holds a Ptr, grow / equal reallocate on > / !=, custom allocators are balanced, swap() never frees the caller's memory, moves,
+    mutual exclusion of thread_lock.  Host-only."""
+    build(UTIL_SRC, UTIL_EXE)
+    out = subprocess.run([UTIL_EXE], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "utility types ok" in out.stdout, out.stdout + out.stderr

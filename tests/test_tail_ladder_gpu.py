@@ -89,8 +89,9 @@ def test_the_pivot_on_the_n_x_m_block_when_asked_for():
 
 def test_busy_streams_are_placed_on_hardware_queues_at_creation():
     """hcv_queue_probe.hip: the pivot's two lanes and the first rung on hardware queues of their own, the last rung on the main
-    stream's (profiles/r05_queue_probe.txt) — found by experiment when the engine is made; the stream stays the oracle's.  A process
-    that has made other streams before (here: eleven of them, held) gets the same placement."""
+    stream's (profiles/r05_queue_probe.txt) — by what the experiment has found about the process's pooled streams (each stream is
+    classified once in its life, and never beside a running stream); the stream stays the oracle's.  A process that has made other
+    streams before (here: eleven of them, held) gets the same placement."""
     import re
     pre = ("import torch\n"
            "held = [torch.cuda.Stream() for _ in range(11)]\n"
@@ -106,12 +107,12 @@ def test_busy_streams_are_placed_on_hardware_queues_at_creation():
         assert r["err"] <= TOL, r
         probes = [l for l in out.stderr.splitlines() if "queue probe" in l]
         assert probes, out.stderr[-2000:]
-        m = re.search(r"(\d+) queues seen, (\d+) of (\d+) busy streams .* classes:((?: -?\d+)+)", probes[-1])
+        m = re.search(r"(\d+) queues known, .* main stream on queue (\d+), (\d+) of (\d+) busy streams .* classes:((?: -?\d+)+)", probes[-1])
         assert m, probes
-        queues, served, want = int(m.group(1)), int(m.group(2)), int(m.group(3))
-        classes = [int(c) for c in m.group(4).split()]
+        queues, main_q, served, want = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))
+        classes = [int(c) for c in m.group(5).split()]
         assert want == 4 and served == want, probes                # two lanes, two rungs
-        assert classes[-1] == 0 and len(set(classes)) == 4 and queues >= 4, probes
+        assert classes[-1] == main_q and len(set(classes)) == 4 and queues >= 4, probes
 
 
 def test_the_automatic_rule_on_the_baseline_shapes(H, oracle):

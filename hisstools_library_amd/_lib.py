@@ -45,6 +45,12 @@ class IRCall(C.Structure):           # hcv_ir_call
                 ("src_stride", usz), ("dst_stride", usz), ("value", C.c_double), ("zero_center", C.c_int)]
 
 
+class IRProductCall(C.Structure):    # hcv_ir_product_call
+    _fields_ = [("op", C.c_int), ("precision", C.c_int), ("size", usz), ("batch", usz),
+                ("a_re", vp), ("a_im", vp), ("b_re", vp), ("b_im", vp), ("dst_re", vp), ("dst_im", vp),
+                ("a_stride", usz), ("b_stride", usz), ("dst_stride", usz), ("b_broadcast", C.c_int), ("scale", C.c_double)]
+
+
 class AudioFileInfo(C.Structure):    # hcv_audiofile_info
     _fields_ = [("file_type", C.c_int), ("pcm_format", C.c_int), ("header_endianness", C.c_int), ("audio_endianness", C.c_int),
                 ("sampling_rate", C.c_double), ("channels", C.c_uint), ("frames", C.c_uint), ("bit_depth", C.c_uint),
@@ -140,6 +146,8 @@ SIGNATURES = {
     "hcv_fft_exec_dev": (C.c_int, [C.POINTER(FFTCall), vp, C.c_int]),
     "hcv_ir_exec": (C.c_int, [C.POINTER(IRCall)]),
     "hcv_ir_exec_dev": (C.c_int, [C.POINTER(IRCall), vp, C.c_int]),
+    "hcv_ir_product_exec": (C.c_int, [C.POINTER(IRProductCall)]),
+    "hcv_ir_product_exec_dev": (C.c_int, [C.POINTER(IRProductCall), vp, C.c_int]),
     "hcv_spectral_phase_size": (usz, [usz, C.c_double]),
     "hcv_spectral_change_phase_f32": (C.c_int, [f32p, usz, C.c_double, C.c_double, f32p]),
     "hcv_spectral_change_phase_f64": (C.c_int, [f64p, usz, C.c_double, C.c_double, f64p]),

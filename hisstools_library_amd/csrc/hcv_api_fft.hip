@@ -701,6 +701,91 @@ extern "C" int hcv_ir_exec(const hcv_ir_call *call)
     return ok ? 0 : -1;
 }
 
+// ---- the IR products (SpectralFunctions.hpp:415-436; kernel in hcv_irx.hip)
+namespace
+{
+    hcv::IrProduct to_irp(const hcv_ir_product_call &c)
+    {
+        hcv::IrProduct r;
+        r.op = c.op; r.precision = c.precision; r.batch = c.batch;
+        r.count = (c.op & 1) ? c.size >> 1 : c.size;
+        r.a_re = c.a_re; r.a_im = c.a_im; r.b_re = c.b_re; r.b_im = c.b_im; r.dst_re = c.dst_re; r.dst_im = c.dst_im;
+        r.a_stride = c.a_stride; r.b_stride = c.b_stride; r.dst_stride = c.dst_stride; r.b_broadcast = c.b_broadcast; r.scale = c.scale;
+        return r;
+    }
+}
+
+extern "C" int hcv_ir_product_exec_dev(const hcv_ir_product_call *call, void *stream, int sync)
+{
+    if (!call)
+    {
+        set_error("hcv_ir_product_exec_dev: null descriptor");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    std::string err;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hcv::irp_exec(to_irp(*call), st, &err);
+    if (e == hipSuccess && sync) e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+    {
+        set_error(err.empty() ? std::string("hcv_ir_product_exec_dev: ") + hipGetErrorString(e) : err);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int hcv_ir_product_exec(const hcv_ir_product_call *call)
+{
+    if (!call)
+    {
+        set_error("hcv_ir_product_exec: null descriptor");
+        return -1;
+    }
+    int dev = 0;
+    if (!use_default_device(dev)) return -1;
+    hcv::IrProduct c = to_irp(*call);
+    std::string err;
+    if (!hcv::irp_valid(c, &err))
+    {
+        set_error(err);
+        return -1;
+    }
+    if (!c.batch) return 0;
+    const size_t elem = c.precision == hcv::FX_F32 ? 4 : 8;
+    if (!c.a_stride) c.a_stride = c.count;
+    if (!c.b_stride) c.b_stride = c.count;
+    if (!c.dst_stride) c.dst_stride = c.count;
+    const size_t a_ext = (c.batch - 1) * c.a_stride + c.count, b_ext = c.b_broadcast ? c.count : (c.batch - 1) * c.b_stride + c.count;
+    const size_t d_ext = (c.batch - 1) * c.dst_stride + c.count;
+    DevBuf ar, ai, br, bi, dr, di;
+    bool ok = ar.alloc(a_ext * elem) && ai.alloc(a_ext * elem) && br.alloc(b_ext * elem) && bi.alloc(b_ext * elem) && dr.alloc(d_ext * elem) && di.alloc(d_ext * elem);
+    if (ok) HCV_API_TRY(hipMemcpy(ar.p, call->a_re, a_ext * elem, hipMemcpyHostToDevice));
+    if (ok) HCV_API_TRY(hipMemcpy(ai.p, call->a_im, a_ext * elem, hipMemcpyHostToDevice));
+    if (ok) HCV_API_TRY(hipMemcpy(br.p, call->b_re, b_ext * elem, hipMemcpyHostToDevice));
+    if (ok) HCV_API_TRY(hipMemcpy(bi.p, call->b_im, b_ext * elem, hipMemcpyHostToDevice));
+    const bool gaps = c.dst_stride != c.count && c.batch > 1;
+    if (ok && gaps) HCV_API_TRY(hipMemcpy(dr.p, call->dst_re, d_ext * elem, hipMemcpyHostToDevice));
+    if (ok && gaps) HCV_API_TRY(hipMemcpy(di.p, call->dst_im, d_ext * elem, hipMemcpyHostToDevice));
+    if (!ok)
+    {
+        if (tlsError.empty()) set_error("hcv_ir_product_exec: device allocation failed");
+        return -1;
+    }
+    c.a_re = ar.p; c.a_im = ai.p; c.b_re = br.p; c.b_im = bi.p; c.dst_re = dr.p; c.dst_im = di.p;
+    hipError_t e = hcv::irp_exec(c, nullptr, &err);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess)
+    {
+        set_error(err.empty() ? std::string("hcv_ir_product_exec: ") + hipGetErrorString(e) : err);
+        return -1;
+    }
+    HCV_API_TRY(hipMemcpy(call->dst_re, c.dst_re, d_ext * elem, hipMemcpyDeviceToHost));
+    if (ok) HCV_API_TRY(hipMemcpy(call->dst_im, c.dst_im, d_ext * elem, hipMemcpyDeviceToHost));
+    return ok ? 0 : -1;
+}
+
 // spectral_processor::calc_fft_size_log2 (SpectralProcessor.hpp:231-242) of round(size * time_multiplier)
 static unsigned phase_fft_log2(size_t size, double time_multiplier)
 {

@@ -28,6 +28,22 @@ namespace hcv
     hipError_t launch_scale(float *x, long long n, float scale, hipStream_t stream);
     hipError_t launch_scale(double *x, long long n, double scale, hipStream_t stream);
 
+    // The IR products (SpectralFunctions.hpp:415-436): dst = scale * a * b (convolve) or scale * a * conj(b) (correlate), batched.
+    // `count` = values per array: fft_size for the complex forms, fft_size / 2 for the real forms (bin 0 = (DC, Nyquist): two real products).
+    enum IrProductOp { IRP_CONVOLVE_COMPLEX = 0, IRP_CONVOLVE_REAL = 1, IRP_CORRELATE_COMPLEX = 2, IRP_CORRELATE_REAL = 3, IRP_NUM_OPS };
+    struct IrProduct
+    {
+        int op = IRP_CONVOLVE_COMPLEX, precision = 0;
+        size_t count = 0, batch = 1;
+        const void *a_re = nullptr, *a_im = nullptr, *b_re = nullptr, *b_im = nullptr;
+        void *dst_re = nullptr, *dst_im = nullptr;
+        size_t a_stride = 0, b_stride = 0, dst_stride = 0;      // elements between consecutive spectra, 0 = dense; b_stride may be given as
+        int b_broadcast = 0;                                    // ... one spectrum for the whole batch (b_broadcast != 0)
+        double scale = 1.0;
+    };
+    bool irp_valid(const IrProduct &call, std::string *err);
+    hipError_t irp_exec(const IrProduct &call, hipStream_t stream, std::string *err);
+
     bool irx_valid(const IrCall &call, std::string *err);
     hipError_t irx_exec(int device, const IrCall &call, hipStream_t stream, std::string *err);
 }

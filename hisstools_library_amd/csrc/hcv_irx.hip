@@ -496,6 +496,97 @@ hipError_t launch_scale(double *x, long long n, double scale, hipStream_t st)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ the IR products
+// ir_convolve_complex / ir_convolve_real / ir_correlate_complex / ir_correlate_real (SpectralFunctions.hpp:415-436 over
+// complex_operation :49-61 / real_operation :63-84 and the functors convolve :274-281, correlate :265-272).  Each product and each sum
+// is rounded on its own, then the scale — the reference's vector layer has no fused multiply-add, and neither has this kernel
+// (__fmul_rn / __fadd_rn and their double forms are never contracted): bit-identical results.
+namespace
+{
+    template <class T> struct IrP
+    {
+        const T *ar, *ai, *br, *bi;
+        T *dr, *di;
+        long long astride, bstride, dstride, count, batch;
+        int correlate, real_form;
+        T scale;
+    };
+    __device__ __forceinline__ float rn_mul(float a, float b) { return __fmul_rn(a, b); }
+    __device__ __forceinline__ double rn_mul(double a, double b) { return __dmul_rn(a, b); }
+    __device__ __forceinline__ float rn_add(float a, float b) { return __fadd_rn(a, b); }
+    __device__ __forceinline__ double rn_add(double a, double b) { return __dadd_rn(a, b); }
+
+    template <class T> __global__ __launch_bounds__(256) void ir_product_kernel(IrP<T> k)
+    {
+        for (long long row = blockIdx.y; row < k.batch; row += gridDim.y)
+        {
+            const T *ar = k.ar + row * k.astride, *ai = k.ai + row * k.astride, *br = k.br + row * k.bstride, *bi = k.bi + row * k.bstride;
+            T *dr = k.dr + row * k.dstride, *di = k.di + row * k.dstride;
+            for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < k.count; i += (long long) gridDim.x * blockDim.x)
+            {
+                const T a = ar[i], b = ai[i], c = br[i], d = bi[i];
+                T re, im;
+                if (k.real_form && i == 0)
+                {
+                    // bin 0 = (DC, Nyquist): op(dc, ., a, 0, c, 0) and op(nq, ., b, 0, d, 0): two real products (:73-83)
+                    re = rn_mul(k.scale, rn_add(rn_mul(a, c), k.correlate ? (T) 0 : -(T) 0));
+                    im = rn_mul(k.scale, rn_add(rn_mul(b, d), k.correlate ? (T) 0 : -(T) 0));
+                }
+                else if (k.correlate)
+                {
+                    re = rn_mul(k.scale, rn_add(rn_mul(a, c), rn_mul(b, d)));
+                    im = rn_mul(k.scale, rn_add(rn_mul(b, c), -rn_mul(a, d)));
+                }
+                else
+                {
+                    re = rn_mul(k.scale, rn_add(rn_mul(a, c), -rn_mul(b, d)));
+                    im = rn_mul(k.scale, rn_add(rn_mul(b, c), rn_mul(a, d)));
+                }
+                dr[i] = re;
+                di[i] = im;
+            }
+        }
+    }
+
+    template <class T> hipError_t run_product(const IrProduct &c, hipStream_t st)
+    {
+        IrP<T> k;
+        k.ar = static_cast<const T *>(c.a_re); k.ai = static_cast<const T *>(c.a_im);
+        k.br = static_cast<const T *>(c.b_re); k.bi = static_cast<const T *>(c.b_im);
+        k.dr = static_cast<T *>(c.dst_re); k.di = static_cast<T *>(c.dst_im);
+        k.count = (long long) c.count;
+        k.batch = (long long) c.batch;
+        k.astride = (long long) (c.a_stride ? c.a_stride : c.count);
+        k.bstride = c.b_broadcast ? 0 : (long long) (c.b_stride ? c.b_stride : c.count);
+        k.dstride = (long long) (c.dst_stride ? c.dst_stride : c.count);
+        k.correlate = c.op >= IRP_CORRELATE_COMPLEX;
+        k.real_form = c.op & 1;
+        k.scale = (T) c.scale;
+        const unsigned gx = (unsigned) std::max<long long>(1, std::min<long long>((k.count + 255) / 256, 1024));
+        hipLaunchKernelGGL(ir_product_kernel<T>, dim3(gx, (unsigned) std::min<long long>(k.batch, 4096)), dim3(256), 0, st, k);
+        return hipGetLastError();
+    }
+}
+
+bool irp_valid(const IrProduct &c, std::string *err)
+{
+    auto fail = [&](const char *m) { if (err) *err = m; return false; };
+    if (c.op < 0 || c.op >= IRP_NUM_OPS) return fail("hcv_ir_product: unknown operation");
+    if (c.precision != FX_F32 && c.precision != FX_F64) return fail("hcv_ir_product: precision must be float or double");
+    if (!c.count || (c.count & (c.count - 1))) return fail("hcv_ir_product: power-of-two sizes only (the reference's vector loops drop the remainder of any other)");
+    if (c.count > (size_t(1) << 28) || c.batch > 0x7fffffffull) return fail("hcv_ir_product: size out of range");
+    if (!c.batch) return true;
+    if (!c.a_re || !c.a_im || !c.b_re || !c.b_im || !c.dst_re || !c.dst_im) return fail("hcv_ir_product: null operand");
+    return true;
+}
+
+hipError_t irp_exec(const IrProduct &c, hipStream_t stream, std::string *err)
+{
+    if (!irp_valid(c, err)) return hipErrorInvalidValue;
+    if (!c.batch) return hipSuccess;
+    return c.precision == FX_F32 ? run_product<float>(c, stream) : run_product<double>(c, stream);
+}
+
 bool irx_valid(const IrCall &c, std::string *err)
 {
     auto fail = [&](const char *m) { if (err) *err = m; return false; };

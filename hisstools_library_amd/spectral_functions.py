@@ -1,4 +1,4 @@
-"""Python mirror of the reference's spectral IR functions (SpectralFunctions.hpp:365-413) over ``hcv_ir_exec``.
+"""Python mirror of the reference's spectral IR functions (SpectralFunctions.hpp:365-436) over ``hcv_ir_exec`` / ``hcv_ir_product_exec``.
 
 Spectra are packed half spectra as ``hisstools_rfft`` produces them: ``fft_size / 2`` values per array, bin 0 =
 (DC, Nyquist).  1-D arrays are one spectrum, 2-D arrays a batch (one spectrum per row, one launch).  The numpy dtype
@@ -82,6 +82,60 @@ def ir_time_reverse(realp, imagp, fft_size: int):
 def ir_phase(realp, imagp, fft_size: int, phase: float, zero_center: bool = False):
     """ir_phase(setup, out, in, fft_size, phase, zero_center) (:392-413): 0 minimum, 0.5 linear, 1 maximum phase."""
     return _run(IrOp.PHASE, realp, imagp, fft_size, phase, zero_center)
+
+
+class IrProductOp(IntEnum):        # hcv_ir_product_call.op
+    CONVOLVE_COMPLEX = 0
+    CONVOLVE_REAL = 1
+    CORRELATE_COMPLEX = 2
+    CORRELATE_REAL = 3
+
+
+def _product(op: IrProductOp, r1, i1, r2, i2, fft_size: int, scale: float):
+    if fft_size < 1 or fft_size & (fft_size - 1):
+        raise ValueError("fft_size must be a power of two")
+    n = fft_size >> 1 if int(op) & 1 else fft_size
+    a = np.ascontiguousarray(r1)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    dt = a.dtype
+    b = np.ascontiguousarray(i1, dtype=dt)
+    c, d = np.ascontiguousarray(r2, dtype=dt), np.ascontiguousarray(i2, dtype=dt)
+    one = a.ndim == 1
+    if one:
+        a, b = a.reshape(1, -1), b.reshape(1, -1)
+    broadcast = c.ndim == 1
+    if broadcast:
+        c, d = c.reshape(1, -1), d.reshape(1, -1)
+    if a.shape != b.shape or c.shape != d.shape or a.shape[1] < n or c.shape[1] < n or (not broadcast and c.shape[0] != a.shape[0]):
+        raise ValueError(f"{n} values per array expected; the second operand one spectrum or one per row")
+    out_re, out_im = np.zeros((a.shape[0], n), dt), np.zeros((a.shape[0], n), dt)
+    call = _lib.IRProductCall(op=int(op), precision=0 if dt == np.float32 else 1, size=fft_size, batch=a.shape[0], a_re=a.ctypes.data, a_im=b.ctypes.data,
+                              b_re=c.ctypes.data, b_im=d.ctypes.data, dst_re=out_re.ctypes.data, dst_im=out_im.ctypes.data, a_stride=a.shape[1],
+                              b_stride=c.shape[1], dst_stride=n, b_broadcast=int(broadcast and a.shape[0] > 1), scale=float(scale))
+    if _lib.load().hcv_ir_product_exec(C.byref(call)) != 0:
+        raise RuntimeError(f"ir_{op.name.lower()}: {_lib.last_error()}")
+    return (out_re[0], out_im[0]) if one else (out_re, out_im)
+
+
+def ir_convolve_complex(r1, i1, r2, i2, fft_size: int, scale: float = 1.0):
+    """ir_convolve_complex(out, in1, in2, fft_size, scale) (:414-418): scale * in1 * in2 on fft_size values per array."""
+    return _product(IrProductOp.CONVOLVE_COMPLEX, r1, i1, r2, i2, fft_size, scale)
+
+
+def ir_convolve_real(r1, i1, r2, i2, fft_size: int, scale: float = 1.0):
+    """ir_convolve_real (:420-424): the same on packed half spectra of fft_size real samples (bin 0 = (DC, Nyquist))."""
+    return _product(IrProductOp.CONVOLVE_REAL, r1, i1, r2, i2, fft_size, scale)
+
+
+def ir_correlate_complex(r1, i1, r2, i2, fft_size: int, scale: float = 1.0):
+    """ir_correlate_complex (:426-430): scale * in1 * conj(in2)."""
+    return _product(IrProductOp.CORRELATE_COMPLEX, r1, i1, r2, i2, fft_size, scale)
+
+
+def ir_correlate_real(r1, i1, r2, i2, fft_size: int, scale: float = 1.0):
+    """ir_correlate_real (:432-436)."""
+    return _product(IrProductOp.CORRELATE_REAL, r1, i1, r2, i2, fft_size, scale)
 
 
 def exec_dev(op: IrOp, precision: int, log2n: int, batch: int, src_re: int, src_im: int, dst_re: int, dst_im: int,

@@ -344,6 +344,29 @@ typedef struct hcv_ir_call
 } hcv_ir_call;
 HCV_API int hcv_ir_exec(const hcv_ir_call *call);
 HCV_API int hcv_ir_exec_dev(const hcv_ir_call *call, void *stream, int sync);
+/* The IR products, SpectralFunctions.hpp:415-436:
+ *
+ *   HCV_IR_CONVOLVE_COMPLEX   ir_convolve_complex   :414-418   dst = scale * a * b        on `size` values per array
+ *   HCV_IR_CONVOLVE_REAL      ir_convolve_real      :420-424   the same on packed half spectra of `size` real samples: size / 2 values
+ *   HCV_IR_CORRELATE_COMPLEX  ir_correlate_complex  :426-430   dst = scale * a * conj(b)    per array, bin 0 = (DC, Nyquist) gets its two
+ *   HCV_IR_CORRELATE_REAL     ir_correlate_real     :432-436                                real products
+ *
+ * `size` = the reference's fft_size argument, a power of two (its vector loops drop the remainder of any other size).  Every product and
+ * sum is rounded on its own, then the scale, as the reference's SIMD layer does: bit-identical results.  b_broadcast != 0: ONE b
+ * spectrum for the whole batch (a filter applied to many spectra).  dst may equal a or b.  Strides in elements, 0 = dense. */
+enum { HCV_IR_CONVOLVE_COMPLEX = 0, HCV_IR_CONVOLVE_REAL = 1, HCV_IR_CORRELATE_COMPLEX = 2, HCV_IR_CORRELATE_REAL = 3 };
+typedef struct hcv_ir_product_call
+{
+    int op, precision;
+    size_t size, batch;
+    const void *a_re, *a_im, *b_re, *b_im;
+    void *dst_re, *dst_im;
+    size_t a_stride, b_stride, dst_stride;
+    int b_broadcast;
+    double scale;
+} hcv_ir_product_call;
+HCV_API int hcv_ir_product_exec(const hcv_ir_product_call *call);                            /* host pointers */
+HCV_API int hcv_ir_product_exec_dev(const hcv_ir_product_call *call, void *stream, int sync);   /* device pointers + a hipStream_t */
 HCV_API size_t hcv_spectral_phase_size(size_t size, double time_multiplier);
 HCV_API int hcv_spectral_change_phase_f32(const float *in, size_t size, double phase, double time_multiplier, float *out);
 HCV_API int hcv_spectral_change_phase_f64(const double *in, size_t size, double phase, double time_multiplier, double *out);

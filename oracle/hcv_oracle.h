@@ -66,6 +66,8 @@ void hcvo_ir_spike_f32(float *ro, float *io, size_t fft_size, double position);
 void hcvo_ir_delay_f32(float *ro, float *io, const float *ri, const float *ii, size_t fft_size, double delay);
 void hcvo_ir_phase_f32(float *ro, float *io, const float *ri, const float *ii, size_t fft_size, double phase, int zero_center);
 size_t hcvo_change_phase_f32(const float *in, size_t size, double phase, double time_multiplier, float *out);
+void hcvo_ir_product_f32(int op, float *ro, float *io, const float *r1, const float *i1, const float *r2, const float *i2, size_t fft_size, double scale);
+void hcvo_ir_product_f64(int op, double *ro, double *io, const double *r1, const double *i1, const double *r2, const double *i2, size_t fft_size, double scale);
 void hcvo_ir_copy_f64(double *ro, double *io, const double *ri, const double *ii, size_t fft_size);
 void hcvo_ir_time_reverse_f64(double *ro, double *io, const double *ri, const double *ii, size_t fft_size);
 void hcvo_ir_spike_f64(double *ro, double *io, size_t fft_size, double position);

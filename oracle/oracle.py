@@ -660,6 +660,7 @@ def _ir_lib(backend):
             f["delay_" + sfx] = _decl(L, "hcvo_ir_delay_" + sfx, None, fp, fp, fp, fp, _sz, C.c_double)
             f["phase_" + sfx] = _decl(L, "hcvo_ir_phase_" + sfx, None, fp, fp, fp, fp, _sz, C.c_double, C.c_int)
             f["change_phase_" + sfx] = _decl(L, "hcvo_change_phase_" + sfx, _sz, fp, _sz, C.c_double, C.c_double, fp)
+            f["product_" + sfx] = _decl(L, "hcvo_ir_product_" + sfx, None, C.c_int, fp, fp, fp, fp, fp, fp, _sz, C.c_double)
     else:
         if not have_ref_spectral():
             raise FileNotFoundError(REF_SPECTRAL_PATH)
@@ -667,6 +668,7 @@ def _ir_lib(backend):
         for sfx, fp in (("f32", _f32p), ("f64", _f64p)):
             f["ir_" + sfx] = _decl(L, "ref_ir_" + sfx, None, C.c_int, fp, fp, fp, fp, _sz, C.c_double, C.c_int)
             f["change_phase_" + sfx] = _decl(L, "ref_change_phase_" + sfx, _sz, fp, _sz, C.c_double, C.c_double, fp)
+            f["product_" + sfx] = _decl(L, "ref_ir_product_" + sfx, None, C.c_int, fp, fp, fp, fp, fp, fp, _sz, C.c_double)
     _ir[backend] = f
     return f
 
@@ -699,6 +701,35 @@ def ir_op(op: str, realp, imagp, fft_size: int, value: float = 0.0, zero_center:
         f["phase_" + precision](ptr(ro), ptr(io), ptr(ri), ptr(ii), fft_size, value, int(zero_center))
     else:
         raise ValueError(op)
+    return ro, io
+
+
+IR_PRODUCTS = ("convolve_complex", "convolve_real", "correlate_complex", "correlate_real")
+
+
+def ir_product(op: str, r1, i1, r2, i2, fft_size: int, scale: float = 1.0, precision: str = "f32", backend: str = "port"):
+    """ir_convolve_complex / ir_convolve_real / ir_correlate_complex / ir_correlate_real (SpectralFunctions.hpp:415-436):
+    out = scale * in1 * in2 (or * conj(in2)); the complex forms on fft_size values per array, the real forms on fft_size / 2 packed
+    values with bin 0 = (DC, Nyquist).  Returns (realp, imagp)."""
+    f = _ir_lib(backend)
+    dt = np.float32 if precision == "f32" else np.float64
+    if fft_size < 1 or fft_size & (fft_size - 1):
+        raise ValueError("power-of-two sizes (the reference's vector loops drop the remainder of any other size, SpectralFunctions.hpp:44)")
+    n = fft_size if op.endswith("complex") else fft_size >> 1
+    ptr = (lambda v: v.ctypes.data_as(_f32p)) if dt == np.float32 else (lambda v: v.ctypes.data_as(_f64p))
+
+    def aligned(v=None):
+        # (the reference reads and writes whole SIMD vectors through reinterpret_cast: 32-byte aligned arrays, :32-41)
+        raw = np.zeros(n * np.dtype(dt).itemsize + 64, np.uint8)
+        off = (-raw.ctypes.data) % 64
+        out = raw[off:off + n * np.dtype(dt).itemsize].view(dt)
+        if v is not None:
+            out[:] = np.asarray(v, dt)[:n]
+        return out
+
+    a, b, c, d = (aligned(v) for v in (r1, i1, r2, i2))
+    ro, io = aligned(), aligned()
+    f["product_" + precision](IR_PRODUCTS.index(op), ptr(ro), ptr(io), ptr(a), ptr(b), ptr(c), ptr(d), fft_size, float(scale))
     return ro, io
 
 

@@ -105,4 +105,20 @@ extern "C"
     REF_IR(f32, float, FFT_SPLIT_COMPLEX_F, FFT_SETUP_F)
     REF_IR(f64, double, FFT_SPLIT_COMPLEX_D, FFT_SETUP_D)
 #undef REF_IR
+
+    // ---------------------------------------------------------------- the IR products (SpectralFunctions.hpp:415-436).  op: 0 convolve_complex,
+    // 1 convolve_real, 2 correlate_complex, 3 correlate_real; fft_size as the reference's argument (complex forms: that many values per
+    // array; real forms: fft_size / 2 values per array, bin 0 = (DC, Nyquist))
+#define REF_IRP(SFX, T, SPLIT)                                                                                                          \
+    void ref_ir_product_##SFX(int op, T *ro, T *io, const T *r1, const T *i1, const T *r2, const T *i2, uintptr_t fft_size, double scale) \
+    {                                                                                                                                   \
+        SPLIT out(ro, io), in1(const_cast<T *>(r1), const_cast<T *>(i1)), in2(const_cast<T *>(r2), const_cast<T *>(i2));                \
+        if (op == 0) ir_convolve_complex(&out, &in1, &in2, fft_size, (T) scale);                                                        \
+        else if (op == 1) ir_convolve_real(&out, &in1, &in2, fft_size, (T) scale);                                                      \
+        else if (op == 2) ir_correlate_complex(&out, &in1, &in2, fft_size, (T) scale);                                                  \
+        else ir_correlate_real(&out, &in1, &in2, fft_size, (T) scale);                                                                  \
+    }
+    REF_IRP(f32, float, FFT_SPLIT_COMPLEX_F)
+    REF_IRP(f64, double, FFT_SPLIT_COMPLEX_D)
+#undef REF_IRP
 }

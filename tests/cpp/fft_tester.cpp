@@ -211,6 +211,26 @@ namespace
         for (uintptr_t j = 0; j < half; j++) part = part && r3[j] == re[j] && i3[j] == im[j];
         if (!part) std::printf("ir_copy differs\n");
         ok = ok && part;
+        // the IR products (SpectralFunctions.hpp:415-436): convolving with the spectrum of a unit spike at sample 0 (all ones; the packed
+        // bin 0 = (1, 1)) changes nothing but the scale, exactly; correlating a spectrum with itself leaves no imaginary parts (bin 0's
+        // Nyquist slot aside, which is a real product)
+        ir_spike(&out, n, 0.0);
+        ir_convolve_real(&tmp, &spec, &out, n, (T) 0.5);
+        part = true;
+        for (uintptr_t j = 0; j < half; j++) part = part && r3[j] == (T) 0.5 * re[j] && i3[j] == (T) 0.5 * im[j];
+        if (!part) std::printf("ir_convolve_real with a unit spike is not the scaled input\n");
+        ok = ok && part;
+        ir_correlate_real(&tmp, &spec, &spec, n, (T) 1);
+        part = r3[0] == re[0] * re[0] && i3[0] == im[0] * im[0];
+        for (uintptr_t j = 1; j < half; j++) part = part && i3[j] == (T) 0 && r3[j] >= (T) 0;
+        if (!part) std::printf("ir_correlate_real of a spectrum with itself is not its power spectrum\n");
+        ok = ok && part;
+        ir_convolve_complex(&tmp, &spec, &out, half, (T) 1);
+        ir_correlate_complex(&out, &tmp, &out, half, (T) 1);
+        part = true;
+        for (uintptr_t j = 1; j < half; j++) part = part && r2[j] == re[j] && i2[j] == im[j];
+        if (!part) std::printf("the complex products with a unit spectrum changed the input\n");
+        ok = ok && part;
         // change_phase: the linear-phase version of x is symmetric about the centre of the frame
         spectral_processor<T> sp;
         std::vector<T> y(n);

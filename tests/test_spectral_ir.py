@@ -203,3 +203,98 @@ def test_gpu_bad_calls_fail_loudly():
         S.ir_copy(np.zeros(8, np.float32), np.zeros(8, np.float32), 24)
     with pytest.raises(RuntimeError):
         S.ir_phase(np.zeros(2, np.float32), np.zeros(2, np.float32), 4, 0.0)            # minimum phase needs >= 8 samples
+
+
+# ------------------------------------------------------------------------------------------------ the IR products (SpectralFunctions.hpp:415-436)
+# ir_convolve_complex / ir_convolve_real / ir_correlate_complex / ir_correlate_real: golden_ir2_v1.npz is made by the UNMODIFIED reference
+# (tests/golden/make_golden_ir2.py over oracle/ref_spectral_driver.cpp).  Products, sums and the scale are each rounded on their own in the
+# reference's vector layer, in the oracle and in the HIP kernel: BIT-identical, float and double.
+
+from make_golden_ir2 import COUNTS as P_COUNTS, SCALES as P_SCALES  # noqa: E402
+P_OPS = ("convolve_complex", "convolve_real", "correlate_complex", "correlate_real")
+
+
+@pytest.fixture(scope="module")
+def gold2():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_ir2_v1.npz"))
+
+
+def _product_cases(gold2):
+    for prec in ("f32", "f64"):
+        for n in P_COUNTS:
+            ops = [gold2[f"in_{prec}_{n}_{name}"] for name in "abcd"]
+            for op in P_OPS:
+                fs = n if op.endswith("complex") else 2 * n
+                for k, sc in enumerate(P_SCALES):
+                    yield prec, n, op, fs, sc, ops, (gold2[f"{op}_{prec}_{n}_{k}_re"], gold2[f"{op}_{prec}_{n}_{k}_im"])
+
+
+def test_oracle_ir_products_match_reference_vectors(oracle, gold2):
+    count = 0
+    for prec, n, op, fs, sc, ops, want in _product_cases(gold2):
+        got = oracle.ir_product(op, *ops, fs, sc, prec)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (prec, n, op, sc)
+        assert np.array_equal(np.signbit(got[0][:1]), np.signbit(want[0][:1]))         # (the signed zero through bin 0)
+        count += 1
+    assert count == 2 * len(P_COUNTS) * 4 * len(P_SCALES)
+
+
+def test_oracle_ir_products_first_principles(oracle):
+    rng = np.random.default_rng(3)
+    n = 64
+    a, b, c, d = (rng.uniform(-1, 1, n) for _ in range(4))
+    z1, z2 = a + 1j * b, c + 1j * d
+    re, im = oracle.ir_product("convolve_complex", a, b, c, d, n, 0.25, "f64")
+    assert np.allclose(re + 1j * im, 0.25 * z1 * z2, rtol=0, atol=1e-15)
+    re, im = oracle.ir_product("correlate_complex", a, b, c, d, n, 2.0, "f64")
+    assert np.allclose(re + 1j * im, 2.0 * z1 * np.conj(z2), rtol=0, atol=1e-14)
+    # the real forms: bin 0 carries (DC, Nyquist), each a real product; the other bins as the complex form
+    re, im = oracle.ir_product("convolve_real", a, b, c, d, 2 * n, 1.0, "f64")
+    assert re[0] == a[0] * c[0] and im[0] == b[0] * d[0]
+    assert np.allclose((re + 1j * im)[1:], (z1 * z2)[1:], rtol=0, atol=1e-15)
+    re, im = oracle.ir_product("correlate_real", a, b, c, d, 2 * n, 1.0, "f64")
+    assert re[0] == a[0] * c[0] and im[0] == b[0] * d[0]
+    assert np.allclose((re + 1j * im)[1:], (z1 * np.conj(z2))[1:], rtol=0, atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_gpu_ir_products_match_reference_vectors_bit_for_bit(gold2):
+    import hisstools_library_amd.spectral_functions as S
+    fns = {"convolve_complex": S.ir_convolve_complex, "convolve_real": S.ir_convolve_real, "correlate_complex": S.ir_correlate_complex,
+           "correlate_real": S.ir_correlate_real}
+    count = 0
+    for prec, n, op, fs, sc, ops, want in _product_cases(gold2):
+        got = fns[op](*ops, fs, sc)
+        assert got[0].dtype == want[0].dtype
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (prec, n, op, sc)
+        assert np.array_equal(np.signbit(got[0][:1]), np.signbit(want[0][:1]))
+        count += 1
+    assert count == 2 * len(P_COUNTS) * 4 * len(P_SCALES)
+
+
+@pytest.mark.gpu
+def test_gpu_ir_products_batched_and_one_filter_for_many(oracle):
+    """a batch of spectra against one spectrum each, and against ONE spectrum for all rows (a filter applied to many): row by row the oracle's"""
+    import hisstools_library_amd.spectral_functions as S
+    rng = np.random.default_rng(9)
+    rows, n = 7, 256
+    a, b = rng.uniform(-1, 1, (rows, n)).astype(np.float32), rng.uniform(-1, 1, (rows, n)).astype(np.float32)
+    c, d = rng.uniform(-1, 1, (rows, n)).astype(np.float32), rng.uniform(-1, 1, (rows, n)).astype(np.float32)
+    re, im = S.ir_convolve_real(a, b, c, d, 2 * n, 0.5)
+    for r in range(rows):
+        w = oracle.ir_product("convolve_real", a[r], b[r], c[r], d[r], 2 * n, 0.5, "f32")
+        assert np.array_equal(re[r], w[0]) and np.array_equal(im[r], w[1]), r
+    re, im = S.ir_correlate_complex(a, b, c[0], d[0], n, 1.0)
+    for r in range(rows):
+        w = oracle.ir_product("correlate_complex", a[r], b[r], c[0], d[0], n, 1.0, "f32")
+        assert np.array_equal(re[r], w[0]) and np.array_equal(im[r], w[1]), r
+
+
+@pytest.mark.gpu
+def test_gpu_ir_products_bad_calls_fail_loudly():
+    import hisstools_library_amd.spectral_functions as S
+    z = np.zeros(24, np.float32)
+    with pytest.raises(ValueError):
+        S.ir_convolve_complex(z, z, z, z, 24)                   # not a power of two
+    with pytest.raises(ValueError):
+        S.ir_convolve_real(z[:4], z[:4], z[:4], z[:4], 16)      # too few values

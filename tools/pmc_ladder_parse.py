@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per_step[c] = total * 1024.0 * factor / steps
     by = {}
     for r in rows[a + 1:b + 1]:
-        n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("hcv::", "")[:40]
+        n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("hcv::", "")[:40]
         by[n] = by.get(n, 0.0) + float(r["Counter_Value"]) * 1024.0 * factor / steps
     out[f"{c}_factor"] = round(factor, 4)
     out[f"{c}_bytes_per_step_by_kernel"] = {k: int(v) for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:8]}

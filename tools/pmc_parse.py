@@ -13,6 +13,7 @@ import sys
 w = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/pmc_{w}"
 batched = len(sys.argv) > 3 and sys.argv[3] == "batched"       # the hop-tiled launch of 65536-sample calls instead of the single-hop one
+offline = len(sys.argv) > 3 and sys.argv[3] == "offline"       # the matrix-core launch of 64-hop offline calls (hcv_mac_mfma.hip)
 GiB = 1 << 30
 
 
@@ -36,7 +37,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     run = load(f"{src}/{c}/run_counter_collection.csv")
     # the steady-state tail launch: the unpredicated single-hop spectral_mac (<OT, 1, false, NT>) moving the most bytes
     # (... or the n x m block's multiply-accumulate launch, hcv_fused_nxm.hip, where the engine takes that block: c4s8, c4g)
-    cand = {k: v for k, v in run.items() if ("spectral_mac_tiled_kernel" in k[0] if batched else (("spectral_mac_kernel" in k[0] and ", 1, false," in k[0]) or "mac_meet_kernel" in k[0]))}
+    cand = {k: v for k, v in run.items() if ("spectral_mac_mfma_kernel" in k[0] if offline else "spectral_mac_tiled_kernel" in k[0] if batched else (("spectral_mac_kernel" in k[0] and ", 1, false," in k[0]) or "mac_meet_kernel" in k[0]))}
     # the head partition's MAC of whole-hop mode can share the tail's template variant and grid: the tail launches are the
     # ones near the largest value of the (name, grid) group that holds it
     key = max(cand, key=lambda k: max(cand[k]))
@@ -61,5 +62,5 @@ out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out["hbm_write_
 import datetime, os
 out["commit"] = os.environ.get("PMC_COMMIT", "unknown")
 out["date"] = datetime.date.today().isoformat()
-json.dump(out, open(f"profiles/traffic_{w}{'_batched' if batched else ''}.json", "w"), indent=1)
+json.dump(out, open(f"profiles/traffic_{w}{'_batched' if batched else '_offline' if offline else ''}.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -15,7 +15,8 @@ last_k = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 agg = defaultdict(list)
 starts = defaultdict(list)
 for r in csv.DictReader(open(path)):
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("hcv::", "")
+    # (kernels of an anonymous namespace demangle as hcv::(anonymous namespace)::name<...>(...): that parenthesis is not the argument list)
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("hcv::", "")
     grid = (r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Grid_Size_Z", "?"))
     wg = r.get("Workgroup_Size_X", "?")
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3

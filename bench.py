@@ -1150,6 +1150,18 @@ def bench_line(args, ctx):
                                                      "is almost read-only traffic with nontemporal loads and out-runs a copy; `frac` stays achieved / 8 TB/s")
             except Exception as e:          # (context, never the measurement)
                 line["roofline"]["box_copy_GBps"] = f"error: {e}"
+        if args.tail_ratio:
+            # the extended ladder as the headline workload (--tail-ratio): no single kernel dominates its step — the last rung's launch turns over
+            # once in 64 steps and may not run at all inside the timed region — so the roofline object is the WHOLE step against SURVEY 8d's bytes
+            # for the ladder's own stage list (what config.extended_layout.roofline_step carries when the ladder runs beside the headline)
+            l_sum_p, l_ns = sum(s_["partitions"] for s_ in stats), len(stats)
+            l_bytes = (8.0 * nin * (nout + 1) * l_sum_p + 12.0 * nin * l_ns + 4.0 * nout * l_ns) * B
+            l_gbs = l_bytes / (elapsed / args.steps) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": f"whole step of the ladder (stages {[(s_['fft_size'], s_['partitions']) for s_ in stats]}): no single kernel dominates it",
+                                "achieved": round(l_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(l_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                "alg_bytes_per_step": int(l_bytes), "sum_partitions": int(l_sum_p),
+                                "all_stage_mac_ms": {str(s_["fft_size"]): round(s_["mac_ms"], 3) for s_ in stats},
+                                "note": "bytes = SURVEY 8d's per-sample-time figure summed over the ladder's stages x the step's samples; traffic: profiles/traffic_<workload>_ladder.json"}
         if roofline_batched is not None:
             line["roofline_batched"] = roofline_batched
         if cpu is not None:

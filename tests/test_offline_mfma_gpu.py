@@ -133,3 +133,22 @@ def test_offline_calls_equal_hop_calls(H, torch, nin, nout, call_hops):
     st = convs[1].stage_stats()[-1]
     assert st["hop_tile"] == call_hops and st["out_tile"] == 16, st
     assert st["mac_steady_launches"] >= 2, st
+
+
+def test_matrix_core_kernel_against_the_register_tiles_over_random_shapes():
+    """tools/micro/mac_mfma_fuzz.cpp, launch level: 300 random shapes the engine can hand the kernel — 16 .. 2048 bins, 1 .. 20 inputs, 2 .. 40
+    outputs (ragged output tiles), 1 .. 60 partitions (k-slices ending inside an input, chunks of fewer than 16 partitions), 32 .. 150 hops
+    (ragged hop tiles), random ring lengths and first hops — each against the register-tiled kernels of the same library on the same
+    operands: within 2e-6 of the peak (two f32 summation orders)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "tests", "cpp", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "mac_mfma_fuzz")
+    lib = os.path.join(root, "hisstools_library_amd")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(lib, "csrc"), os.path.join(root, "tools", "micro", "mac_mfma_fuzz.cpp"),
+                           "-L", lib, "-lhisstools_amd", f"-Wl,-rpath,{lib}", "-o", exe])
+    out = subprocess.run([exe, "300", "11"], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout + out.stderr

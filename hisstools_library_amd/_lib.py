@@ -25,7 +25,7 @@ u32 = C.c_uint32
 class StageStats(C.Structure):
     _fields_ = [("fft_size", u32), ("partitions", u32), ("num_ins", u32), ("num_outs", u32),
                 ("mac_launches", C.c_uint64), ("mac_hops", C.c_uint64), ("mac_ms", C.c_double),
-                ("ksplit", u32), ("out_tile", u32), ("mac_steady_launches", C.c_uint64), ("hop_tile", u32), ("launch_partitions", u32), ("fused_launches", C.c_uint64), ("fused_stood_down", C.c_uint64)]
+                ("ksplit", u32), ("out_tile", u32), ("mac_steady_launches", C.c_uint64), ("hop_tile", u32), ("launch_partitions", u32), ("fused_launches", C.c_uint64), ("fused_stood_down", C.c_uint64), ("host_pre_launches", C.c_uint64)]
 
 
 class RtStats(C.Structure):          # hcv_rt_stats

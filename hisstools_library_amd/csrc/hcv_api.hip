@@ -1675,6 +1675,7 @@ extern "C" int hcv_convolver_stage_stats(hcv_convolver *h, int stage, hcv_stage_
     out->launch_partitions = s.launch_partitions;
     out->fused_launches = s.fused_launches;
     out->fused_stood_down = s.fused_stood_down;
+    out->host_pre_launches = s.host_pre_launches;
     return 0;
 }
 

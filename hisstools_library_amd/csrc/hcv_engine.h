@@ -86,6 +86,7 @@ namespace hcv
         uint32_t hop_tile, launch_partitions;
         uint64_t fused_launches;        // of mac_launches: whole blocks run as ONE launch (hcv_fft_split.hip: fused_block_*_kernel)
         uint64_t fused_stood_down;      // times the n x m block was stood down for 4096 blocks (its forward launches kept arriving late)
+        uint64_t host_pre_launches;     // hop-sized host-pointer blocks whose partitions >= 1 went out ahead of the upload (host_pre_mac)
     };
 
     class Engine
@@ -176,6 +177,13 @@ namespace hcv
         bool fence_chains(bool keep_forward = false);
         bool join_forward_stream();
         bool input_behind_forward();
+        // Host-pointer calls of one whole hop on a streamed engine (c4, ns64, c5): the part of the hop's multiply-accumulate that needs
+        // nothing of the new block — partitions >= 1, over spectra the ring holds already: all but 1 / (P + 1) of the launch — is enqueued
+        // BEFORE the caller's samples are staged and uploaded, so that the staging copy and the PCIe transfer run beside it instead of in
+        // front of it (hcv_engine_block.hip: host_pre_mac).  What it left for the block's own enqueue:
+        struct PreMac { bool valid = false; uint64_t block = 0; int ksplit = 0; long long h_mac = 0; uint32_t nin = 0, nout = 0; };
+        PreMac mPre;
+        bool host_pre_mac(uint32_t nin_act, uint32_t nout_act, uint32_t B);
         bool ensure_staging(Stage &st, uint32_t parts);
         // control-path device memory: stream-ordered allocation on the control stream (hipMallocAsync / hipFreeAsync).  The
         // synchronous calls take runtime-wide locks and, for hipFree, wait for the whole device: an audio thread's launches

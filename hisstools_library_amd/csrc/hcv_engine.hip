@@ -352,6 +352,12 @@ bool Engine::init(const EngineCfg &cfg)
         }
         else if (pv.nxm_helped)
             roles.push_back(&mPipeStream);
+        // (round 6: a streamed tail — a GB-class store of spectra — whose hop-sized HOST-pointer calls start the old partitions' multiply-accumulate
+        // ahead of the upload, host_pre_mac: the upload is enqueued on the main stream, and in a hardware queue shared with the stage's stream
+        // it would sit behind that launch instead of beside it)
+        if (roles.empty() && pv.lead && mCfg.nout > 1 && !mCfg.diag &&
+            sizeof(float2) * (double) mCfg.nout * mNinAlloc * pv.Pcap * pv.M >= 512.0 * 1048576.0)
+            roles.push_back(&pv.stream);
         if (!roles.empty()) mStreamsSpread = spread_streams(mStream, roles.data(), (int) roles.size(), share);
     }
     if (order_mode() > 0)
@@ -1546,6 +1552,7 @@ bool Engine::stage_stats(size_t s, StageStats *out)
         out->launch_partitions = st.last_parts;
         out->fused_launches = st.fused_launches;
         out->fused_stood_down = st.nxm_stood_down;
+        out->host_pre_launches = st.host_pre_launches;
         return true;
     }, 1);
 }
@@ -1556,7 +1563,7 @@ void Engine::clear_stats()
     {
         for (Stage *st : mStages)
         {
-            st->launches = st->hops = st->steady_launches = st->fused_launches = 0;
+            st->launches = st->hops = st->steady_launches = st->fused_launches = st->host_pre_launches = 0;
             st->ms = 0.0;
         }
         return true;

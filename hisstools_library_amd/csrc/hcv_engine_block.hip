@@ -8,6 +8,12 @@
 namespace hcv
 {
 
+// (the lead slot's nin terms are a short reduction per output: up to six k-slices fill the chip — measured on 64 x 64, 2 s IRs, staged /
+// registered host calls in ms: 2 slices 0.697 / 0.649, 3: 0.704 / 0.658, 6: 0.668 / 0.625, 8: 0.667 / 0.622, the split off: 0.736 / 0.662; the
+// old partitions keep the k-slices of the whole launch, and the reduction in front of the inverse takes all of them)
+constexpr int kPreNewSlices = 6;
+
+
 // How many launches the deferred accumulation of a hop is spread over: one per partition up to kBgSlices for real-time calls (short
 // launches, evenly through the hop: no call waits long behind one); for hop-sized calls of a long stage — throughput callers, the
 // extended ladder's rungs under 8192-sample blocks — no more than half as many as the hop has calls, so that every slice carries
@@ -366,10 +372,30 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
         sw.steady = (!wcheck && !st.gh_count) ? 1 : 0;      // (offline calls of 32 hops or more: the matrix cores, hcv_mac_mfma.hip)
         MacPlan pw;
-        mac_plan(sw, pw);
-        if (!begin_event()) return false;
-        if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM)) return false;
-        if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
+        // A host-pointer call whose partitions >= 1 went out ahead of the upload (host_pre_mac): slices [0, ks) of Y hold them; what is
+        // left is the lead slot's nin terms over the NEW spectra, into the slices behind.
+        const bool pre = mPre.valid && mPre.block == mBlockCount && !serial && !wcheck && T == 1 && mPre.h_mac == h_mac && mPre.nin == nin_act &&
+                         mPre.nout == nout_act && sM == st.stream && !mProfiling;
+        mPre.valid = false;
+        if (pre)
+        {
+            MacShape sn = mac_shape(st, /* P */ 1, /* Pcap */ st.hparts(), /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ 0,
+                                    /* T */ 1, /* max_ksplit */ kPreNewSlices);
+            MacPlan pn;
+            mac_plan(sn, pn);
+            if (!mac(st, sn, pn, st.Hs, st.Y + (size_t) mPre.ksplit * nout_act * st.M, h_mac, false, sM)) return false;
+            pw = pn;
+            pw.ksplit = mPre.ksplit + pn.ksplit;            // (the inverse — or the reduction in front of it — takes all of them)
+            pw.nt = 1;
+            st.host_pre_launches++;
+        }
+        else
+        {
+            mac_plan(sw, pw);
+            if (!begin_event()) return false;
+            if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM)) return false;
+            if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
+        }
         st.launches++;
         st.hops += (uint64_t) T;
         st.last_ksplit = (uint32_t) pw.ksplit;
@@ -981,6 +1007,50 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     return true;
 }
 
+// Host-pointer calls, one whole hop of a streamed engine (see PreMac in hcv_engine.h).  The block about to be enqueued is classified by the
+// same rules enqueue_chunk and enqueue_stage apply (the engine is owned: nothing changes in between; should the two ever disagree, the
+// block's own enqueue computes the whole sum again and this launch was wasted, not wrong).  It qualifies when it is a steady-state whole-hop
+// block of the full matrix on a lead-slot stage with a GB or more of live spectra, one hop long, with nothing pending that the
+// multiply-accumulate would have to be ordered behind.  Then  Y[0 .. ks) = sum over p >= 1  X[h - p] H[p]  goes out on the stage's stream now.
+bool Engine::host_pre_mac(uint32_t nin_act, uint32_t nout_act, uint32_t B)
+{
+    mPre.valid = false;
+    static const bool allow = !(std::getenv("HCV_HOST_PRE_MAC") && std::atoi(std::getenv("HCV_HOST_PRE_MAC")) == 0);
+    static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
+    if (!allow || mStages.empty() || !mTailHead || !mLeadSlot || mOneStream || mProfiling || mCfg.diag) return true;
+    if (mCtlDirty || mExtDirty || mFwdPending || mDropHead.load(std::memory_order_relaxed)) return true;
+    Stage &st = *mStages[mPivot];
+    const bool rungs = mPivot + 1 < mStages.size();
+    const long long n0 = mN;
+    if (rungs || !st.lead || B != st.M || (n0 % st.M) != 0 || !mTailHeadPrev) return true;                  // one whole hop, not the mode's first block
+    if (mTdMaxValid > 0 && (n0 - (long long) mTdLpad < mTdMaxValid)) return true;                             // (td_check)
+    if (st.max_hv > n0 / st.M) return true;
+    if (nout_act != mCfg.nout || nin_act != mCfg.nin) return true;                                           // the full matrix
+    if ((double) st.live_parts * st.M * sizeof(float2) < 1024.0 * 1048576.0 || serial_env == 1) return true; // streamed engines only
+    for (Stage *o : mStages)
+        if (o->chain_pending >= 0 || o->bg_pending) return true;
+    const int Pw = (int) (st.P + st.lead);
+    const long long h_mac = n0 / st.M;
+    if (Pw < 4 || st.gh_count || (h_mac - st.max_hv) < (long long) Pw - 1 || h_mac + 1 < Pw) return true;     // steady state: every partition live
+    const int q = (int) (mBlockCount & 1);
+    const size_t ks_cap = std::max<size_t>(1, st.y_elems / ((size_t) nout_act * st.M));
+    if (ks_cap < kPreNewSlices + 2) return true;
+    MacShape so = mac_shape(st, /* P */ Pw - 1, /* Pcap */ st.hparts(), /* nin */ (int) nin_act, /* nin_alloc */ (int) mNinAlloc, /* nout */ (int) nout_act, /* diag */ 0,
+                            /* T */ 1, /* max_ksplit */ (int) (ks_cap - kPreNewSlices));
+    MacPlan po;
+    mac_plan(so, po);
+    if (po.mfma || po.inwg) return true;
+    xcd_pin_hint(false);
+    if (!mac(st, so, po, st.Hs + st.M, st.Yq[q], h_mac - 1, /* check */ false, st.stream)) return false;
+    mPre.valid = true;
+    mPre.block = mBlockCount;
+    mPre.ksplit = po.ksplit;
+    mPre.h_mac = h_mac;
+    mPre.nin = nin_act;
+    mPre.nout = nout_act;
+    return true;
+}
+
 // The staging buffer of the host paths (mDevIn) is ONE buffer, rewritten by every call's upload.  The forward launches of n x m blocks read it
 // from the pipe stream with no event towards the main stream (hcv_fused_nxm.hip): one that arrives late — its block finished by the helping
 // path, the call returned — would otherwise still be reading while the next call's upload lands (the launch itself also stands
@@ -1005,7 +1075,6 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
     if (!nout_act || !B) return true;
     if (B > mMaxBlock) { mErr = "process_begin: block longer than max_block"; return false; }
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
-    for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i], sizeof(float) * B);
     if (!audio_enter())
     {
         mHostMuted = true;              // (a stream-start collision, hcv_engine.h: this block is silent, nothing of the engine's state is touched)
@@ -1015,6 +1084,9 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
     if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
     static const int zc_limit = std::getenv("HCV_ZERO_COPY") ? std::atoi(std::getenv("HCV_ZERO_COPY")) : 2048;
     const bool zero_copy = mPinInDev && mPinOutDev && (int) B <= zc_limit;
+    // (a hop-sized block of a streamed engine: what needs nothing of the caller's samples starts now, beside the staging copy and the upload)
+    if (!zero_copy && !host_pre_mac(nin_act, nout_act, B)) return false;
+    for (uint32_t i = 0; i < rows_in; i++) std::memcpy(mPinIn + (size_t) i * B, ins[i], sizeof(float) * B);
     if (zero_copy)
     {
         mCallWaits = true;
@@ -1111,6 +1183,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
         }
         OwnerGuard own(this);
         if (!fence_chains(/* keep_forward */ true) || !update_active_matrix(rows_in, nout_act) || !apply_pending_resets()) return false;
+        if (!host_pre_mac(nin_act, nout_act, B)) return false;
         if (rows_in)
         {
             if (!input_behind_forward()) return false;

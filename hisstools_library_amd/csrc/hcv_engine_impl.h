@@ -140,7 +140,7 @@ struct Engine::Stage
     uint64_t launches = 0, hops = 0;
     double ms = 0.0;
     uint32_t last_ksplit = 0, last_ot = 0, last_tt = 0, last_parts = 0;
-    uint64_t steady_launches = 0, fused_launches = 0;
+    uint64_t steady_launches = 0, fused_launches = 0, host_pre_launches = 0;
 };
 
 struct Engine::GhostEvent

@@ -237,6 +237,7 @@ typedef struct hcv_stage_stats
     /* times the stage stood its n x m block down for 4096 blocks: three launches within 64 blocks found their forward launch missing
      * (stuck behind another stream's work in a shared hardware queue) and did the transforms themselves */
     uint64_t fused_stood_down;
+    uint64_t host_pre_launches;     /* hop-sized host-pointer calls whose partitions >= 1 were multiplied ahead of the upload (streamed engines) */
 } hcv_stage_stats;
 HCV_API void hcv_convolver_set_profiling(hcv_convolver *h, int on);
 HCV_API int hcv_convolver_num_stages(hcv_convolver *h);

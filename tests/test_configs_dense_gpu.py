@@ -75,3 +75,48 @@ def test_config4_dense_rows_vs_oracle(H, oracle):
     tail = c.stage_stats()[-1]
     assert tail["partitions"] == 11 and tail["out_tile"] == 8 and (tail["ksplit"] > 1 or tail["fused_launches"] > 0) and tail["hop_tile"] == 1
     assert tail["mac_steady_launches"] >= 3, tail
+
+
+def test_hop_sized_host_pointer_calls_on_a_streamed_engine_vs_oracle(H, oracle):
+    """hcv_convolver_process_f32 (host pointers: what HISSTools::Convolver::process calls) in 8192-sample calls on an engine with more than a
+    GB of live tail spectra (16 x 16, 70 partitions): from the steady state on, the part of each hop's multiply-accumulate that needs nothing of
+    the new block — partitions >= 1 — is enqueued ahead of the staging copy and the upload (Engine::host_pre_mac; Convolver.cpp:138-154 over
+    PartitionedConvolve.cpp:352-377), the lead slot's terms behind them.  Dense decaying-noise IRs on every pair (inputs 0..3 carry audio), rows
+    0, 7, 8, 15 against oracle.Convolver(4, 4) over the whole stream: ramp-up (whole launches) and steady state (split launches) alike."""
+    import torch
+    dev = torch.device("cuda:0")
+    nin = nout = 16
+    B = 8192
+    L = B + 70 * B - 999
+    hops = 96
+    S = hops * B
+    rows, cols = [0, 7, 8, 15], [0, 1, 2, 3]
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
+    ref = oracle.Convolver(len(cols), len(rows), 0)
+    ref.setResetOffset(0)
+    spare = []
+    for o in rows:
+        for i in cols:
+            h = oracle.synth_ir(i, o, L - 555 * (i % 3))
+            assert c.set(i, o, h, True) == 0 and ref.set(i, rows.index(o), h, True) == 0
+            if len(spare) < 4:
+                spare.append(torch.from_numpy(np.ascontiguousarray(h)).to(dev))
+    k = 0
+    for o in range(nout):
+        for i in range(nin):
+            if not (o in rows and i in cols):
+                torch.cuda.synchronize()
+                assert c.set_dev(i, o, spare[k % len(spare)].data_ptr(), spare[k % len(spare)].numel(), True) == 0
+                k += 1
+    xs = np.zeros((nin, S), np.float32)
+    for i in cols:
+        xs[i] = oracle.synth_audio(i, S)
+    c.clear_stats()
+    y = c.run(xs, nout, B)                                  # host pointers, 8192 samples per call
+    y_ref, _ = ref.stream_timed(xs[cols], len(rows), 2048)
+    for k, o in enumerate(rows):
+        assert rel_err(y[o], y_ref[k]) < 1e-5, (o, rel_err(y[o], y_ref[k]))
+        assert rel_err(y[o][-8 * B:], y_ref[k][-8 * B:]) < 1e-5, (o, "steady span")
+    tail = c.stage_stats()[-1]
+    assert tail["partitions"] == 70 and tail["mac_launches"] == hops, tail
+    assert tail["host_pre_launches"] >= hops - 75, tail      # every steady-state hop took the split form

@@ -351,6 +351,10 @@ namespace
         // the block of an empty object is silence either way)
         std::atomic<int> users { 0 };
         std::atomic<bool> swapping { false };
+        // (a shard of a sharded object: the engine a process call uses is read ONCE per call, first_use, and an engine replaced before the
+        // shard's first call is kept until the object goes — a call that raced the replacement holds either one, both empty, and never waits)
+        std::atomic<Engine *> live { nullptr };
+        std::vector<std::unique_ptr<Engine>> retired;
         std::vector<uint64_t> mLength, part4Size;
         std::vector<uint8_t> part4Alloc;
         intptr_t resetOffset = -1;
@@ -369,6 +373,7 @@ namespace
             laidFor = maxLength;
             engine.reset(make_engine(layout, maxLength));
             if (!engine) return false;
+            live.store(engine.get(), std::memory_order_release);
             const size_t pairs = (size_t) nout * (diag ? 1 : nin);
             mLength.assign(pairs, 0);
             part4Size.assign(pairs, maxLength);                          // part4.equal(..., maxLength), :254
@@ -428,8 +433,8 @@ namespace
             swapping.store(true, std::memory_order_seq_cst);
             // A shard's engine pointer is held by the shard pool's jobs across a block, without a count in `users`: its first process
             // call and this swap settle it between them (Dekker: each side writes its flag, then reads the other's, both seq_cst — at
-            // least one of them sees the other).  The call raises everProcessed and, finding `swapping`, waits the few microseconds
-            // of the pointer swap out (first_use: once in the object's life); this side, finding everProcessed, leaves the engine be.
+            // least one of them sees the other).  The call raises everProcessed and takes the engine that is live (first_use: the replaced
+            // one is kept alive); this side, finding everProcessed, leaves the engine be.
             if (pristineOnly && everProcessed.load(std::memory_order_seq_cst))
             {
                 swapping.store(false, std::memory_order_release);
@@ -438,16 +443,20 @@ namespace
             while (users.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
             engine.swap(fresh);
             layout = nl;
+            live.store(engine.get(), std::memory_order_seq_cst);
             swapping.store(false, std::memory_order_release);
-            // (`fresh` now holds the old engine: destroyed here, after whatever it still had in flight)
+            // (`fresh` now holds the old engine: destroyed here, after whatever it still had in flight — but a shard's is KEPT: its first
+            // process call may have read the pointer a moment ago, first_use)
+            if (pristineOnly) retired.push_back(std::move(fresh));
         }
 
-        // a shard's first process call (see relayout_for): from here on the shard keeps its stage list
-        void first_use()
+        // a shard's process call: the engine this call runs on.  The first call raises everProcessed — from here on the shard keeps its stage
+        // list — and takes whichever engine is live at that moment; it never waits for a replacement in progress (round 5 polled `swapping`
+        // here): the replaced engine stays alive and is as empty as its successor.
+        Engine *first_use()
         {
-            if (everProcessed.load(std::memory_order_relaxed)) return;
-            everProcessed.store(true, std::memory_order_seq_cst);
-            while (swapping.load(std::memory_order_seq_cst)) hcv::cpu_relax();
+            if (!everProcessed.load(std::memory_order_relaxed)) everProcessed.store(true, std::memory_order_seq_cst);
+            return live.load(std::memory_order_seq_cst);
         }
 
         Engine *make_engine(const Layout &l, uint64_t maxLength)
@@ -612,6 +621,7 @@ struct hcv_shard
     float *part[2] = { nullptr, nullptr };
     hipEvent_t evPart = nullptr;        // ... of the current block is complete
     hipEvent_t evDone[2] = { nullptr, nullptr };    // row root: the sum of the last block of that parity has read every partial block of the row group
+    Engine *cur = nullptr;              // the engine the process call in progress (or the last one) runs on (Matrix::first_use)
 };
 
 struct hcv_shards
@@ -1139,8 +1149,8 @@ namespace
         const float **rows = ip;
         if (a_ni > 64) { big.resize(a_ni); rows = big.data(); }
         for (uint32_t i = 0; i < a_ni; i++) rows[i] = j.ins[x.in_lo + i] + j.pos;
-        if (x.m->engine->process_begin(rows, a_ni, a_no, j.B)) return true;
-        if (k < 64) j.err[k] = x.m->engine->last_error();
+        if (x.cur->process_begin(rows, a_ni, a_no, j.B)) return true;
+        if (k < 64) j.err[k] = x.cur->last_error();
         return false;
     }
 
@@ -1161,9 +1171,9 @@ namespace
             float **rows = op;
             if (a_no > 64) { big.resize(a_no); rows = big.data(); }
             for (uint32_t o = 0; o < a_no; o++) rows[o] = j.outs[x.out_lo + o] + j.pos;
-            if (!x.m->engine->process_end(rows, a_no, j.B, /* accumulate */ x.col > 0))
+            if (!x.cur->process_end(rows, a_no, j.B, /* accumulate */ x.col > 0))
             {
-                if (k < 64) j.err[k] = x.m->engine->last_error();
+                if (k < 64) j.err[k] = x.cur->last_error();
                 return false;
             }
         }
@@ -1187,7 +1197,7 @@ namespace
 static int sharded_process_host(hcv_convolver *h, const float *const *ins, float *const *outs, size_t numIns, size_t numOuts, size_t numSamples)
 {
     hcv_shards &sh = *h->sh;
-    for (hcv_shard &x : sh.s) x.m->first_use();         // (from here on the shards keep their stage lists)
+    for (hcv_shard &x : sh.s) x.cur = x.m->first_use();         // (from here on the shards keep their stage lists)
     HostJob j;
     j.sh = &sh;
     j.ins = ins;
@@ -1386,7 +1396,7 @@ namespace
         uint32_t a_ni, a_no;
         shard_active(sh, x, j.ni, j.no, a_ni, a_no);
         if (!a_no) return true;
-        Engine &e = *x.m->engine;
+        Engine &e = *x.cur;
         const float *src = j.ins + (size_t) x.in_lo * j.in_stride + j.pos;
         if (sh.gi == 1)
             return e.process_dev(src, (int64_t) j.in_stride, j.outs + (size_t) x.out_lo * j.out_stride + j.pos, (int64_t) j.out_stride, a_ni, a_no, j.B, false);
@@ -1411,7 +1421,7 @@ namespace
         uint32_t a_ni, a_no;
         shard_active(sh, root, j.ni, j.no, a_ni, a_no);
         if (!a_no) return true;
-        hipStream_t rs = root.m->engine->main_stream();
+        hipStream_t rs = root.cur->main_stream();
         int prev = -1;
         (void) hipGetDevice(&prev);
         bool ok = prev == root.device || hipSetDevice(root.device) == hipSuccess;
@@ -1443,7 +1453,7 @@ static int sharded_process_dev(hcv_convolver *h, const float *ins_dev, size_t in
         set_error("sharded Convolver: no peer access between the devices; use the host-pointer entry point (hcv_convolver_process_f32)");
         return -1;
     }
-    for (hcv_shard &x : sh.s) x.m->first_use();
+    for (hcv_shard &x : sh.s) x.cur = x.m->first_use();
     DevJob j;
     j.sh = &sh;
     j.ins = ins_dev;
@@ -1513,11 +1523,15 @@ extern "C" int hcv_convolver_synchronize(hcv_convolver *h)
     if (h->sh)
     {
         for (hcv_shard &x : h->sh->s)
-            if (!x.m->engine->synchronize())
+        {
+            // (what the last process call ran on; an object that has not processed yet: its live engine)
+            Engine *e = x.cur ? x.cur : x.m->live.load(std::memory_order_acquire);
+            if (e && !e->synchronize())
             {
-                set_error(x.m->engine->last_error());
+                set_error(e->last_error());
                 return -1;
             }
+        }
         return 0;
     }
     EngineUse use(*h->m);

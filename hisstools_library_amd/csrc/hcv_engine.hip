@@ -8,6 +8,8 @@
 #include <map>
 #include <thread>
 
+#include <dlfcn.h>
+
 namespace hcv
 {
 
@@ -140,6 +142,24 @@ void stream_give(int device, hipStream_t s)
     }
     std::lock_guard<std::mutex> g(gStreamPoolMutex);
     gStreamPool[device].push_back(s);
+}
+
+const RoctxApi *roctx_api()
+{
+    static const RoctxApi *api = []() -> const RoctxApi *
+    {
+        if (!(std::getenv("HCV_ROCTX") && std::atoi(std::getenv("HCV_ROCTX")))) return nullptr;
+        static RoctxApi a;
+        for (const char *lib : { "librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4" })
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))
+            {
+                a.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                a.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (a.push && a.pop) return &a;
+            }
+        return nullptr;
+    }();
+    return api;
 }
 
 long long order_violations() { return order_mode() > 0 ? order_registry().violations.load() : -1; }
@@ -726,6 +746,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     if (s >= mStages.size()) return false;
     DeviceGuard dg(mDevice);
     Stage &st = *mStages[s];
+    RoctxRange range("hcv:resize");
     uint32_t newP = (uint32_t) std::max<uint64_t>(1, (capacity + st.M - 1) / st.M);
     if (newP <= st.Pcap) return true;
     // grow by at least half: obtaining NEW device memory from the driver stalls every HIP call of the process while it maps
@@ -1204,6 +1225,7 @@ bool Engine::ensure_staging(Stage &st, uint32_t parts)
 bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bool device_ptr)
 {
     if (out >= mCfg.nout || (!mCfg.diag && in >= mCfg.nin)) return false;
+    RoctxRange range("hcv:set");
     std::lock_guard<std::mutex> gs(mSetMutex);
     DeviceGuard dg(mDevice);
     if (!ir) len = 0;

@@ -599,6 +599,7 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
 // cleared what block k's hops are added into).
 bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int64_t out_stride, uint32_t nin_act, uint32_t nout_act, uint32_t B)
 {
+    RoctxRange range("hcv:block");                                  // (HCV_ROCTX=1; otherwise one load of a flag)
     const long long n0 = mN;
     const long long hmask = mHistLen - 1;
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;

@@ -32,6 +32,24 @@ void stream_give(int device, hipStream_t s);
         if (e_ != hipSuccess) return fail(#expr, e_);                                                                  \
     } while (0)
 
+// HCV_ROCTX=1 (the reference has no tracing; rocprofv3 --marker-trace shows these): ranges `hcv:block` around every block's
+// enqueue and `hcv:set` / `hcv:resize` around the control calls.  The marker library (rocprofiler-sdk's, else roctracer's) is opened at run time
+// on first use — the product has no link dependency on it — and with the variable unset a range costs one load of a static flag.
+struct RoctxApi
+{
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi *roctx_api();                 // hcv_engine.hip; nullptr: off, or no marker library to be had
+struct RoctxRange
+{
+    const RoctxApi *api;
+    explicit RoctxRange(const char *name) : api(roctx_api()) { if (api) (void) api->push(name); }
+    ~RoctxRange() { if (api) (void) api->pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 inline long long pow2ceil(long long v)
 {
     long long p = 1;

@@ -86,3 +86,15 @@ def test_the_check_is_off_by_default_and_sees_a_missing_wait():
         if v:
             assert "order check:" in err
     assert found > 0
+
+
+def test_roctx_ranges_on_request():
+    """HCV_ROCTX=1: `hcv:block` / `hcv:set` / `hcv:resize` marker ranges through the marker library opened at run
+    time; the smoke stream — live IR swap included — still equals the oracle's, with and without a profiler attached to read them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HCV_ROCTX="1"))
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]

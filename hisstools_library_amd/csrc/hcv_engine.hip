@@ -1506,6 +1506,7 @@ bool Engine::global_reset()
         HCV_TRY(hipMemsetAsync(st->timeline, 0, sizeof(float) * mCfg.nout * st->tl_len, mStream));
         HCV_TRY(hipMemsetAsync(st->hv, 0, sizeof(long long) * pairs, mStream));
         st->max_hv = 0;
+        st->hv_zero = true;
     }
     if (mTdValid) HCV_TRY(hipMemsetAsync(mTdValid, 0, sizeof(long long) * pairs, mStream));
     mTdMaxValid = 0;

@@ -371,6 +371,14 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
                                 /* T */ T, /* max_ksplit */ (int) ks_cap);
         const bool wcheck = (h_mac - st.max_hv) < (long long) Pw - 1;
         sw.steady = (!wcheck && !st.gh_count) ? 1 : 0;      // (offline calls of 32 hops or more: the matrix cores, hcv_mac_mfma.hip)
+        // (... and their ramp-up after a global reset: one bound for every pair, hop 0 — the kernel stages earlier hops as silence)
+        bool uniform = false;
+        if (wcheck && !st.gh_count && st.hv_zero && T >= 32)
+        {
+            sw.steady = 1;
+            sw.hop_min = 0;
+            uniform = true;
+        }
         MacPlan pw;
         // A host-pointer call whose partitions >= 1 went out ahead of the upload (host_pre_mac): slices [0, ks) of Y hold them; what is
         // left is the lead slot's nin terms over the NEW spectra, into the slices behind.
@@ -392,8 +400,15 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
         else
         {
             mac_plan(sw, pw);
+            if (uniform && !pw.mfma)
+            {
+                // (not a shape the matrix-core kernel takes: the checked register tiles, as ever)
+                uniform = false;
+                sw.steady = 0;
+                mac_plan(sw, pw);
+            }
             if (!begin_event()) return false;
-            if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck, sM)) return false;
+            if (!mac(st, sw, pw, st.Hs, st.Y, h_mac, wcheck && !uniform, sM)) return false;
             if (ev) HCV_TRY(hipEventRecord(ev->b, sM));
         }
         st.launches++;

@@ -134,6 +134,7 @@ struct Engine::Stage
     hipEvent_t done[2] = { nullptr, nullptr };   // by block parity
     long long *hv = nullptr;
     long long max_hv = 0;
+    bool hv_zero = true;                // every pair's first hop is 0 (nothing but global resets since the stage was made): the ramp-up's bound is uniform
     unsigned *coop_bar = nullptr;       // fused blocks: the two monotonic hand-over counters (one-output engines only)
     unsigned long long *coop_flags = nullptr;   // fused blocks: per-task completion marks (hcv_kernels.h: kFusedMacTasks + kFusedFwdTasks), one-output engines only
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived

@@ -362,6 +362,7 @@ bool Engine::apply_pending_resets()
                 const long long hvv = mN / st->M;
                 if (!fence(st->hv + p, hvv)) return false;
                 st->max_hv = std::max(st->max_hv, hvv);
+                if (hvv != 0) st->hv_zero = false;
             }
             if (mTdValid)
             {

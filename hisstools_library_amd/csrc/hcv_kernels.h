@@ -128,6 +128,8 @@ namespace hcv
         int target_blocks;  // 0 = default; > 0 = aim for this many workgroups (background work keeps a small footprint)
         int ot_cap;         // 0 = none; > 0 = at most this many outputs per thread (more, smaller workgroups for launches without k-slices)
         int steady = 0;     // the launch will run unchecked (every pair sees all P partitions): the offline shapes may take the matrix cores
+        long long hop_min = -(1LL << 62);   // matrix-core launches only: input hops before this one count as silence (the ramp-up after a global
+                                            // reset: every pair's first hop is 0, and what the ring holds from before the reset must not be seen)
     };
     struct MacPlan
     {

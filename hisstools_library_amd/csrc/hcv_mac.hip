@@ -382,6 +382,7 @@ hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float
     a.kper = pl.kper;
     a.binblocks = pl.binblocks;
     a.ks_stride4 = (long long) s.T * s.nout * (s.M / 2);
+    a.hop_min = s.hop_min;
     if (pl.mfma)
     {
         if (check) return hipErrorInvalidValue;             // (planned for a steady launch only: MacShape::steady)

@@ -27,6 +27,9 @@
 // and every wave then issues, per partition, 1 + MT LDS reads of 16 bytes and 4 MT matrix instructions.  The next chunk's global loads
 // are in flight (in registers) under the current chunk's arithmetic.  Bin 0 carries (DC, Nyquist) — two real products — through a
 // B operand of its own in the one wave that owns it: B[k][2 o + c] = (c == k) ? H.c : 0.
+// The RAMP-UP of a stream (the hops after a global reset, while partitions still reach back before the stream's first hop) runs here too:
+// every pair's bound is the same then, hop 0, so the staged input hops before `hop_min` are simply zeros — no per-pair checks in the loop.
+// (An offline convolution of a file shorter than the impulse response is ramp-up from its first sample to its last.)
 //
 // Row strides of 20 floats keep every 16-byte LDS access of 8 consecutive lanes on 8 different 4-bank groups.
 
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void spectral_mac_mfma_kernel(MacParams a)
                     slot %= a.R;
                     if (slot < 0) slot += a.R;
                     xreg = xrow[(unsigned) slot * (unsigned) a.M2 + xq];
+                    if (h0 - pc - xr < a.hop_min) xreg = make_float4(0.f, 0.f, 0.f, 0.f);     // (before the stream's first hop: silence, whatever the ring holds)
                 }
             };
             auto store_chunk = [&](int pc)
@@ -161,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void spectral_mac_mfma_kernel(MacParams a)
                 const int uc = min(u, max(live_t - 1, 0));
                 int slot = (hmod - pa + uc) % a.R;
                 if (slot < 0) slot += a.R;
-                const float4 v = xrow[(unsigned) slot * (unsigned) a.M2 + q];
+                float4 v = xrow[(unsigned) slot * (unsigned) a.M2 + q];
+                if (h0 - pa + uc < a.hop_min) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int s = (h0w - pa + u) & (W - 1);
                 float *d = Xs + s * kBS + 2 * q;
                 *reinterpret_cast<float2 *>(d) = make_float2(v.x, v.z);

@@ -23,6 +23,7 @@ struct MacParams
     int binblocks;
     long long ks_stride4;   // float4 stride between k-slices of Y
     int pin;                // >= 0: grid.x is 8 x the workgroups and only blockIdx.x % 8 == pin work (hcv_kernels.h: xcd_pin_for)
+    long long hop_min;      // (hcv_mac_mfma.hip) input hops before this one are staged as zeros
 };
 
 // the software-pipelined hop-tiled kernel (hcv_mac_tiled.hip): (OT, TT) in {1, 4} x {2, 4, 8}

@@ -1,9 +1,10 @@
 // Randomised comparison of the offline multiply-accumulate on the matrix cores (hcv_mac_mfma.hip) with the register-tiled kernels of the same
 // library over shapes the engine can hand it: bins 16 .. 2048, 1 .. 20 inputs, 2 .. 40 outputs (ragged output tiles), 1 .. 60 partitions
-// (k-slices that end inside an input, chunks of fewer than 16 partitions), 32 .. 150 hops (ragged hop tiles), ring lengths and first hops at random.
+// (k-slices that end inside an input, chunks of fewer than 16 partitions), 32 .. 150 hops (ragged hop tiles), ring lengths and first hops at random;
+// one case in three is a ramp-up (a uniform first hop inside the partitions' reach: MacShape::hop_min against the checked register tiles).
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I hisstools_library_amd/csrc tools/micro/mac_mfma_fuzz.cpp -L hisstools_library_amd -lhisstools_amd \
 //         -Wl,-rpath,$PWD/hisstools_library_amd -o tools/micro/build/mac_mfma_fuzz
-//   mac_mfma_fuzz [cases] [seed]        exit 0 = every case within 2e-6 of the peak
+//   mac_mfma_fuzz [cases] [seed]        exit 0 = every case within 1e-5 of the peak (two f32 evaluation orders; the checked register tiles round a product differently)
 #include "hcv_kernels.h"
 
 #include <algorithm>
@@ -74,7 +75,18 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL(fill_random, dim3(1024), dim3(256), 0, st, (float *) X, xs * 2, (unsigned) g());
         CK(hipMemsetAsync(Ym, 0xff, ym * sizeof(float2), st));
         const long long h_first = 1000 + pick(0, 100000);
-        CK(hcv::launch_spectral_mac(s, pr, X, H, Yr, hv, h_first, false, st));
+        // one case in three: a ramp-up — every pair's first hop is hv_val, somewhere inside the reach of the launch's partitions; the register
+        // tiles apply it as per-pair bounds (check = true), the matrix-core kernel stages earlier hops as zeros (hop_min)
+        const bool ramp = pick(0, 2) == 0;
+        const long long hv_val = ramp ? h_first + s.T - 1 - pick(0, s.P + s.T) : 0;
+        if (ramp)
+        {
+            std::vector<long long> hh(4096, hv_val);
+            CK(hipMemcpyAsync(hv, hh.data(), sizeof(long long) * 4096, hipMemcpyHostToDevice, st));
+            CK(hipStreamSynchronize(st));
+            sm.hop_min = hv_val;
+        }
+        CK(hcv::launch_spectral_mac(s, pr, X, H, Yr, hv, h_first, ramp, st));
         CK(hcv::launch_spectral_mac(sm, pm, X, H, Ym, hv, h_first, false, st));
         CK(hipStreamSynchronize(st));
         r.resize(yr * 2);
@@ -88,12 +100,13 @@ int main(int argc, char **argv)
             for (int k = 0; k < pr.ksplit; k++) vr += r[(size_t) k * per * 2 + e];
             for (int k = 0; k < pm.ksplit; k++) vm += m[(size_t) k * per * 2 + e];
             peak = std::max(peak, std::fabs(vr));
+            if (e == 0 && peak == 0) peak = 1e-30;
             if (!(std::fabs(vr - vm) <= err)) err = std::fabs(vr - vm);
         }
         const double rel = err / peak;
         done++;
         worst = std::max(worst, rel);
-        if (!(rel < 2e-6))
+        if (!(rel < 1e-5))         // (SURVEY 8c's bound; a missing or misplaced term would show at 1e-2: these sums have ~1000 terms of unit size)
         {
             bad++;
             std::printf("MISMATCH case %d: M %d nin %d(+%d) nout %d P %d(cap %d) T %d R %d ksplit %d/%d mt %d: %.3e of peak\n", c, s.M, s.nin, s.nin_alloc - s.nin, s.nout,

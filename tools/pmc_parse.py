@@ -41,7 +41,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     # the head partition's MAC of whole-hop mode can share the tail's template variant and grid: the tail launches are the
     # ones near the largest value of the (name, grid) group that holds it
     key = max(cand, key=lambda k: max(cand[k]))
-    top = [v for v in cand[key] if v >= 0.5 * max(cand[key])]
+    # (offline: the ramp-up's launches run the same kernel over fewer partitions — only the launches with every partition live count)
+    top = [v for v in cand[key] if v >= (0.97 if offline else 0.5) * max(cand[key])]
     tail[c] = sum(top) / len(top)
     if "mac_meet_kernel" in key[0]:
         # the n x m block: every launch of the group is the same steady-state block, but a launch whose forward launch came late does

@@ -293,7 +293,6 @@ namespace hcv
         // work, synchronize) first puts the main stream behind them by an event (join_forward_stream, from fence_chains)
         bool mFwdPending = false;           // forward launches on the pipe stream the main stream has not been put behind yet
         bool mPrevNxm = false;              // the previous block was such a block
-        bool mPrevNxmSplit = false;         // ... with its multiply-accumulate on the stage's own stream and its inverse on the main one (enqueue_stage)
         uint64_t mNxmRun = 0;               // such blocks since the pipe stream was last lined up behind the main stream
         uint32_t mNxmEvery = 3;             // ... every how many of them record their end (from the rings' depth, enqueue_chunk)
         hipEvent_t mEvNxmEnd[4] = { nullptr, nullptr, nullptr, nullptr };    // ends of every mNxmEvery-th such block (back-pressure on the pipe stream, enqueue_chunk)

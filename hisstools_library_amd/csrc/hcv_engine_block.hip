@@ -207,37 +207,10 @@ bool Engine::enqueue_stage(Block &blk, size_t si, size_t sj)
             }
             pe->stage = si;
         }
-        // Round 6: an asynchronous caller's serial blocks put the multiply-accumulate on the stage's OWN stream (idle in a serial engine) and keep the
-        // inverse on the main stream — which thereby still ends every block, as its contract says — so that block k + 1's launch follows block k's
-        // directly and block k's inverse (9 - 11 us of an 85 us step) runs beside it:
-        //   stage:  wait done[q] (= inverse(k - 2): the partial spectra's buffer) -> mac_meet(k) -> rec mac[q]
-        //   main:   wait mac[q] -> rifft_split_emit(k) -> rec done[q]
-        // A call that waits for its result gains nothing by it and keeps the one stream.  (HCV_NXM_SPLIT = 0: one stream for all.)
-        static const bool split_allowed = !(std::getenv("HCV_NXM_SPLIT") && std::atoi(std::getenv("HCV_NXM_SPLIT")) == 0);
-        const bool split = split_allowed && serial && blk.direct_out && !mCallWaits && !mProfiling && st.stream != nullptr && st.stream != mStream;
-        const hipStream_t sMac = split ? st.stream : sS;
-        if (split)
-        {
-            if (!mPrevNxmSplit)
-            {
-                // (the stage's stream starts behind everything the main stream holds: earlier blocks of other kinds, control work)
-                HCV_TRY(hipEventRecord(mEvSerial, mStream));
-                HCV_TRY(hipStreamWaitEvent(st.stream, mEvSerial, 0));
-            }
-            HCV_TRY(hipStreamWaitEvent(st.stream, st.done[q], 0));
-        }
-        hipError_t fe = launch_fused_block_nxm(blk.nxm_plan, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, (int) mNinAlloc,
-                                               (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, (blk.direct_out && !split) ? blk.dout : nullptr, blk.out_stride,
-                                               st.tw, st.coop_bar, st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sMac, /* chained */ mNxmRun > 0,
-                                               pe ? pe->a : nullptr, pe ? pe->b : nullptr, st.nxm_helped_dev, /* inverse_elsewhere */ split);
-        if (split && fe == hipSuccess)
-        {
-            HCV_TRY(hipEventRecord(st.mac_done[q], st.stream));
-            HCV_TRY(hipStreamWaitEvent(mStream, st.mac_done[q], 0));
-            fe = launch_fused_nxm_inverse(blk.nxm_plan, st.Y, (int) nout_act, blk.dout, blk.out_stride, st.tw, st.coop_flags, st.coop_seq, mStream);
-            if (fe == hipSuccess) HCV_TRY(hipEventRecord(st.done[q], mStream));
-        }
-        mPrevNxmSplit = split && fe == hipSuccess;
+        const hipError_t fe = launch_fused_block_nxm(blk.nxm_plan, mHist, mHistLen, hmask, blk.din, blk.in_stride, n0, h_first, (int) rows_in, (int) mNinAlloc,
+                                                     (int) nout_act, st.X, (int) st.R, st.Hs, st.hparts(), Pw, st.Y, blk.direct_out ? blk.dout : nullptr, blk.out_stride,
+                                                     st.tw, st.coop_bar, st.coop_flags, st.coop_arrived_nxm, &st.coop_seq, mPipeStream, sS, /* chained */ mNxmRun > 0,
+                                                     pe ? pe->a : nullptr, pe ? pe->b : nullptr, st.nxm_helped_dev);
         if (pe && fe == hipSuccess) pe->live = true;
         if (fe == hipSuccess && !blk.direct_out)
         {
@@ -803,7 +776,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
             HCV_TRY(hipEventRecord(mEvSerial, mStream));
             HCV_TRY(hipStreamWaitEvent(mPipeStream, mEvSerial, 0));
             mNxmRun = 0;
-            mPrevNxmSplit = false;              // (the stage's stream lines up behind the main stream again too: enqueue_stage)
         }
         // Back-pressure.  Nothing else holds the forward launches back — an asynchronous caller's whole burst of them would run at once —
         // and the launch of block k overwrites the ring slot of hop h - R, which the multiply-accumulate of block k - (R - P - lead) - 1

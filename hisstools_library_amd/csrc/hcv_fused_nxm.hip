@@ -363,8 +363,7 @@ bool fused_block_nxm_plan(int log2n, int nin, int nout, int P, size_t y_elems, F
 hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long hist_stride, long long hist_mask, const float *in, long long in_stride, long long n0,
                                   long long h, int nin, int nin_alloc, int nout, float2 *X, int Rring, const float2 *H, int hparts, int P, float2 *Y, float *out,
                                   long long out_stride, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived, unsigned long long *seq,
-                                  hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin, hipEvent_t ev_end, unsigned *helped,
-                                  bool inverse_elsewhere)
+                                  hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin, hipEvent_t ev_end, unsigned *helped)
 {
     constexpr int LOG2N = kNxmLog2N, M = 1 << (LOG2N - 1);
     constexpr size_t lds_fwd = sizeof(float2) * (size_t) lds_padded(M);                  // the whole-frame transform (the helping path runs it too)
@@ -401,7 +400,7 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     // (a forward launch is normally through tens of microseconds before it is needed: a shorter wait than the one-output blocks' — ~0.1 ms —
     // before the multiply-accumulate's workgroups do the transforms themselves)
     a.sy.spin = std::min(a.sy.spin, 256);
-    a.hint_wait = (chained && (out || inverse_elsewhere)) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
+    a.hint_wait = (chained && out) ? std::min(kNxmHints, nout * 8) : 0;     // (marks to look at; `chained`: the previous launch on these counters was the block before this one)
     static const int test_delay_us = std::getenv("HCV_NXM_TEST_DELAY_US") ? std::atoi(std::getenv("HCV_NXM_TEST_DELAY_US")) : 0;
     if (test_delay_us > 0) hipLaunchKernelGGL(nxm_delay_kernel, dim3(1), dim3(64), 0, fwd_stream, (unsigned long long) test_delay_us * 100ull);
     hipLaunchKernelGGL((fwd_publish_kernel<LOG2N>), dim3(pl.nfwd), dim3(64 * kNxmWaves), lds_fwd, fwd_stream, a);
@@ -416,17 +415,8 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev_end && (e = hipEventRecord(ev_end, st)) != hipSuccess) return e;
-    if (!out) return hipSuccess;                             // (the caller adds the hop to the stage's timeline itself — the extended ladder's pivot
-                                                             // stage — or launches the inverse on another stream: launch_fused_nxm_inverse)
+    if (!out) return hipSuccess;                             // (the caller adds the hop to the stage's timeline itself: the extended ladder's pivot stage)
     return launch_rifft_emit_split(LOG2N, Y, pl.ms, (long long) nout * M, 1, nout, out, out_stride, tw, st, a.hint, std::min(kNxmHints, nout * 8), a.sy.seq);
-}
-
-hipError_t launch_fused_nxm_inverse(const FusedNxmPlan &pl, const float2 *Y, int nout, float *out, long long out_stride, const float2 *tw,
-                                    unsigned long long *flags, unsigned long long seq, hipStream_t st)
-{
-    constexpr int LOG2N = kNxmLog2N, M = 1 << (LOG2N - 1);
-    ORD_ACCESS(st, Y, 0, 1, 0, false, "partial spectra (n x m inverse)");
-    return launch_rifft_emit_split(LOG2N, Y, pl.ms, (long long) nout * M, 1, nout, out, out_stride, tw, st, flags + kNxmHintBase, std::min(kNxmHints, nout * 8), seq);
 }
 
 } // namespace hcv

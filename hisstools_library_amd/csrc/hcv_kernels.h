@@ -102,11 +102,7 @@ namespace hcv
                                       long long n0, long long h, int nin, int nin_alloc, int nout, float2 *X, int Rring, const float2 *H, int hparts, int P,
                                       float2 *Y, float *out, long long out_stride, const float2 *tw, unsigned *bar, unsigned long long *flags, unsigned *arrived,
                                       unsigned long long *seq, hipStream_t fwd_stream, hipStream_t st, bool chained, hipEvent_t ev_begin = nullptr,
-                                      hipEvent_t ev_end = nullptr, unsigned *helped = nullptr, bool inverse_elsewhere = false);
-    // ... and its inverse as a launch of its own (inverse_elsewhere: the caller puts it on another stream, behind an event of `st`): the
-    // partial spectra added up as they are loaded, the caller's block written, the marks the NEXT block's forward launch looks for set
-    hipError_t launch_fused_nxm_inverse(const FusedNxmPlan &pl, const float2 *Y, int nout, float *out, long long out_stride, const float2 *tw,
-                                        unsigned long long *flags, unsigned long long seq, hipStream_t st);
+                                      hipEvent_t ev_end = nullptr, unsigned *helped = nullptr);
     const float2 *fft_split_sub_table(int log2s);          // the (2 S)-th roots of the residue-split transforms' sub-transform, current device
 
     hipError_t big_rfft_frames(int log2n, const float *hist, long long hist_stride, long long hist_mask, long long h_first, int T, int nin, float2 *X,

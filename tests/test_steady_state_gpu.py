@@ -172,17 +172,19 @@ def test_dense_irs_16x16_steady_state_vs_oracle(H, oracle, torch):
     assert tail["mac_steady_launches"] >= hops - 41, tail
 
 
-def test_config5_depth_dense_irs_vs_oracle(H, oracle, torch):
+@pytest.mark.parametrize("rows,cols", [([0, 7, 8, 15], [0, 1, 2, 3]), ([13], list(range(16)))], ids=["4rows_x_4inputs", "1row_x_all16inputs"])
+def test_config5_depth_dense_irs_vs_oracle(H, oracle, torch, rows, cols):
     """Dense-IR parity with the reference ARITHMETIC at config 5's own depth (what bench.py's self-check does after its timed region, here
     in the suite): 16x16, L = 5 760 000 (P = 703 tail partitions), dense decaying-noise IRs on EVERY pair, inputs 0..3 carrying audio and
     the others silent, streamed in 8192-sample hops PAST the whole IR (712 hops: ramp-up with partition bounds, then the unchecked
     split-K instantiation with all 703 partitions live).  Rows 0, 7, 8, 15 — first and last row of both output tiles — against
-    oracle.Convolver(4, 4) holding the same sixteen IRs (PartitionedConvolve.cpp:321-348 scheduling, :387-426 the multiply-accumulate)."""
+    oracle.Convolver(4, 4) holding the same sixteen IRs; and row 13 fed by all sixteen inputs against oracle.Convolver(16, 1) (PartitionedConvolve.cpp:321-348 scheduling, :387-426 the multiply-accumulate)."""
     dev = torch.device("cuda:0")
     nin = nout = 16
     L, B, hops = 5760000, 8192, 712
     S = hops * B
-    rows, cols = [0, 7, 8, 15], [0, 1, 2, 3]
+    # (second case, round 6: ONE output row fed by ALL sixteen inputs carrying audio — every input's ring and forward transform in the sum, where
+    # the first case leaves twelve inputs silent; the same sixteen pairs of oracle work)
     c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
     ref = oracle.Convolver(len(cols), len(rows), 0)
     ref.setResetOffset(0)

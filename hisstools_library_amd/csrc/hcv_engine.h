@@ -85,7 +85,7 @@ namespace hcv
         uint64_t mac_steady_launches;   // of mac_launches: the unchecked instantiation with nontemporal IR loads
         uint32_t hop_tile, launch_partitions;
         uint64_t fused_launches;        // of mac_launches: whole blocks run as ONE launch (hcv_fft_split.hip: fused_block_*_kernel)
-        uint64_t fused_stood_down;      // times the n x m block was stood down for 4096 blocks (its forward launches kept arriving late)
+        uint64_t fused_stood_down;      // times the n x m block was stood down (64 .. 4096 blocks: its forward launches kept arriving late)
         uint64_t host_pre_launches;     // hop-sized host-pointer blocks whose partitions >= 1 went out ahead of the upload (host_pre_mac)
     };
 

@@ -745,7 +745,7 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
         const int Pw = (int) (tl.P + tl.lead);
         const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
         // (launches whose wait for the forward transforms ran out report it, hcv_fused_nxm.hip: three of them within 64 blocks and the stage
-        // takes the separate kernels for the next 4096 blocks — the forward stream is stuck behind another stream in a hardware queue they
+        // takes the separate kernels for the next 64 .. 4096 blocks — the forward stream is stuck behind another stream in a hardware queue they
         // share, e.g. a second engine of the process: c5 on the ladder as the bench's second engine ran 0.80 ms per step that way, 0.125 without)
         Stage &tw_ = *mStages[last];
         if (tw_.nxm_helped)
@@ -758,7 +758,12 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
                 tw_.nxm_strike_block = mBlockCount;
                 if (tw_.nxm_strikes >= 3)
                 {
-                    tw_.nxm_off_until = mBlockCount + 4096;
+                    // (round 6: the stand-down backs off — 64 blocks the first time, four times longer each time it recurs within 1024 blocks of
+                    // coming back, 4096 at most — instead of 4096 blocks for any three late launches: a co-tenant's burst costs half a second of
+                    // the separate kernels, not 34)
+                    if (mBlockCount - tw_.nxm_off_until > 1024) tw_.nxm_backoff = 64;
+                    tw_.nxm_off_until = mBlockCount + tw_.nxm_backoff;
+                    tw_.nxm_backoff = std::min<uint64_t>(4096, tw_.nxm_backoff * 4);
                     tw_.nxm_stood_down++;
                     tw_.nxm_strikes = 0;
                 }

@@ -140,6 +140,7 @@ struct Engine::Stage
     unsigned coop_arrived[2] = { 0, 0 };    // fused blocks: what the two hand-over counters read once everything launched so far has arrived
     unsigned *nxm_helped = nullptr, *nxm_helped_dev = nullptr;     // host-mapped: n x m launches that had to do their forward transforms themselves
     unsigned nxm_helped_seen = 0, nxm_strikes = 0;
+    uint64_t nxm_backoff = 64;          // blocks the next stand-down lasts (enqueue_chunk)
     uint64_t nxm_strike_block = 0, nxm_off_until = 0, nxm_stood_down = 0;               // (engine block counts) the last strike; separate kernels until this block
     unsigned coop_arrived_nxm[kFusedShards] = {};       // ... of the n x m block's sharded counter (hcv_fused_sync.h), per shard
     unsigned long long coop_seq = 0;        // fused blocks launched so far

@@ -234,7 +234,7 @@ typedef struct hcv_stage_stats
     /* of mac_launches: whole blocks of a one-output engine that ran as ONE launch (transforms, multiply-accumulate and inverse
      * with in-launch hand-overs) */
     uint64_t fused_launches;
-    /* times the stage stood its n x m block down for 4096 blocks: three launches within 64 blocks found their forward launch missing
+    /* times the stage stood its n x m block down (64 blocks, longer — up to 4096 — when it recurs): three launches within 64 blocks found their forward launch missing
      * (stuck behind another stream's work in a shared hardware queue) and did the transforms themselves */
     uint64_t fused_stood_down;
     uint64_t host_pre_launches;     /* hop-sized host-pointer calls whose partitions >= 1 were multiplied ahead of the upload (streamed engines) */

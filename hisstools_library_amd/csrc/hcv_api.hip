@@ -530,6 +530,11 @@ namespace
         {
             std::lock_guard<std::mutex> g(stateMutex);
             const size_t p = pair(in, out);
+            // HCV_REFERENCE_QUIRKS=1: the reference holds the pair's memory through the whole of set() — upload, transforms — so the pair is
+            // SILENT for the blocks processed meanwhile and what it still had to deliver is dropped (MonoConvolve.cpp:118-140, 181-183).  By
+            // default the pair plays its previous IR until the new one is swapped in; on request it is cleared first, as there.
+            static const bool mute_during_set = std::getenv("HCV_REFERENCE_QUIRKS") && std::atoi(std::getenv("HCV_REFERENCE_QUIRKS")) != 0;
+            if (mute_during_set && mLength[p]) (void) engine->set_ir(in, out, nullptr, 0, false);
             mLength[p] = 0;
             if (requestResize)
             {

@@ -827,3 +827,66 @@ def test_registered_host_memory_runs_in_place(H, oracle):
         H.host_unregister(xr)
         H.host_unregister(yr)
     assert H.load().hcv_host_unregister(xr.ctypes.data) == -1             # not registered any more
+
+
+_MUTE_SCRIPT = r"""
+import sys, threading, time, json
+import numpy as np
+sys.path.insert(0, ".")
+import hisstools_library_amd as H
+from oracle import oracle as O
+B, fs, L = 128, 48000, 20000
+c = H.Convolver(2, 2, 0)
+ha, hb = O.synth_ir(0, 0, L), O.synth_ir(3, 1, L)
+for o in range(2):
+    for i in range(2):
+        assert c.set(i, o, ha, True) == 0
+n_blocks = 300
+x = np.zeros((2, n_blocks * B), np.float32)
+x[0] = O.synth_audio(0, n_blocks * B)            # input 1 silent: output row 0 is pair (0, 0) alone
+y = np.zeros((2, n_blocks * B), np.float32)
+t_set = {}
+def control():
+    time.sleep(0.15)
+    t_set["t0"] = time.perf_counter()
+    assert c.set(0, 0, hb, True) == 0
+    t_set["t1"] = time.perf_counter()
+th = threading.Thread(target=control); th.start()
+t_start = time.perf_counter(); stamps = []
+for k in range(n_blocks):
+    while time.perf_counter() < t_start + k * B / fs: pass
+    stamps.append(time.perf_counter())
+    c.process(x[:, k * B:(k + 1) * B], y[:, k * B:(k + 1) * B])
+th.join()
+peak = float(np.abs(y[0]).max())
+quiet = [bool(np.abs(y[0, k * B:(k + 1) * B]).max() < 1e-5 * peak) for k in range(n_blocks)]
+run = best = 0
+for k in range(20, n_blocks):                    # (the stream's first blocks are quiet by themselves)
+    run = run + 1 if quiet[k] else 0
+    best = max(best, run)
+print(json.dumps({"longest_quiet_run": best, "set_ms": 1e3 * (t_set["t1"] - t_set["t0"]), "peak": peak}))
+"""
+
+
+def test_reference_quirks_mode_mutes_the_pair_while_set_is_in_progress():
+    """HCV_REFERENCE_QUIRKS=1, second quirk (round 6): the reference holds a pair's memory through the whole of set(), so the pair is SILENT for
+    the blocks processed meanwhile and its pending output is dropped (MonoConvolve.cpp:118-140, 181-183); by default the pair here plays its
+    previous IR until the swap.  A control thread replaces pair (0, 0) beside paced 128-sample calls with its hand-overs stalled 60 ms each
+    (HCV_TEST_CTL_STALL_US): with the quirk the row fed by that pair alone goes exactly quiet for tens of blocks, without it it never does."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for quirks in ("1", "0"):
+        env = dict(os.environ, HCV_TEST_CTL_STALL_US="60000")
+        env.pop("HCV_REFERENCE_QUIRKS", None)
+        if quirks == "1":
+            env["HCV_REFERENCE_QUIRKS"] = "1"
+        out = subprocess.run([sys.executable, "-c", _MUTE_SCRIPT], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2000:]
+        res[quirks] = json.loads(out.stdout.strip().splitlines()[-1])
+    print(res)
+    assert res["1"]["longest_quiet_run"] >= 15, res          # >= 40 ms of silence on the replaced pair (the stall alone is 60 ms)
+    assert res["0"]["longest_quiet_run"] <= 2, res           # ... and by default it keeps playing right through the set()

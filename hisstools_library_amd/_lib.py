@@ -30,7 +30,7 @@ class StageStats(C.Structure):
 
 class RtStats(C.Structure):          # hcv_rt_stats
     _fields_ = [("start_collisions", C.c_uint64), ("mailbox_runs", C.c_uint64), ("mailbox_ns_max", C.c_uint64), ("mailbox_ns_total", C.c_uint64),
-                ("ctl_sections", C.c_uint64), ("arena_misses", C.c_uint64)]
+                ("ctl_sections", C.c_uint64), ("start_waits", C.c_uint64), ("arena_misses", C.c_uint64)]
 
 
 class FFTCall(C.Structure):          # hcv_fft_call

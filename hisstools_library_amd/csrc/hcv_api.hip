@@ -1596,7 +1596,7 @@ extern "C" void hcv_convolver_clear_stats(hcv_convolver *h)
 extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
 {
     if (!out) return -1;
-    out->start_collisions = out->mailbox_runs = out->mailbox_ns_max = out->mailbox_ns_total = out->ctl_sections = out->arena_misses = 0;
+    out->start_collisions = out->mailbox_runs = out->mailbox_ns_max = out->mailbox_ns_total = out->ctl_sections = out->start_waits = out->arena_misses = 0;
     auto add = [&](Engine &e)
     {
         const Engine::RtStats r = e.rt_stats();
@@ -1606,6 +1606,7 @@ extern "C" int hcv_convolver_rt_stats(hcv_convolver *h, hcv_rt_stats *out)
         out->mailbox_ns_total += r.mailbox_ns_total;
         out->ctl_sections += r.ctl_sections;
         out->arena_misses += r.arena_misses;
+        out->start_waits += r.start_waits;
     };
     auto visit = [&](Matrix &m)
     {

@@ -147,10 +147,11 @@ namespace hcv
         // runs it between two of its blocks (mailbox_runs; what that cost it: mailbox_ns_max / mailbox_ns_total).  start_collisions counts
         // the one case left in which a process call cannot have the state: the FIRST call of a stream (no call for kStreamingWindowNs
         // before it) arriving while a control thread is inside a section it began during the pause — that call's block is silent, as every
-        // pair under a set() is in the reference, and the call after it proceeds.
-        struct RtStats { uint64_t start_collisions, mailbox_runs, mailbox_ns_max, mailbox_ns_total, ctl_sections, arena_misses; };
-        RtStats rt_stats() const { return { mStartCollisions.load(), mMailboxRuns.load(), mMailboxNsMax.load(), mMailboxNsTotal.load(), mCtlSections.load(), mArenaMisses.load() }; }
-        void clear_rt_stats() { mStartCollisions = 0; mMailboxRuns = 0; mMailboxNsMax = 0; mMailboxNsTotal = 0; mCtlSections = 0; mArenaMisses = 0; }
+        // pair under a set() is in the reference, and the call after it proceeds.  (A call of 2048 samples or more — an offline loop, not an
+        // audio callback — waits the section out instead: start_waits.)
+        struct RtStats { uint64_t start_collisions, mailbox_runs, mailbox_ns_max, mailbox_ns_total, ctl_sections, arena_misses, start_waits; };
+        RtStats rt_stats() const { return { mStartCollisions.load(), mMailboxRuns.load(), mMailboxNsMax.load(), mMailboxNsTotal.load(), mCtlSections.load(), mArenaMisses.load(), mStartWaits.load() }; }
+        void clear_rt_stats() { mStartCollisions = 0; mMailboxRuns = 0; mMailboxNsMax = 0; mMailboxNsTotal = 0; mCtlSections = 0; mArenaMisses = 0; mStartWaits = 0; }
 
         void set_profiling(bool on);
         // HCV_REFERENCE_QUIRKS (hcv_api.hip): the next blocks leave the time-domain head out — what MonoConvolve::process does to it in a
@@ -208,7 +209,7 @@ namespace hcv
             bool ok = false;
         };
         bool run_exclusive(std::function<bool()> fn, int slot = 0);        // control threads
-        bool audio_enter();                                 // audio thread: stamp, take the ownership (false: a stream-start collision), run posted sections
+        bool audio_enter(uint64_t samples);                 // audio thread: stamp, take the ownership (false: a stream-start collision), run posted sections
         void audio_leave();                                 // audio thread: posted sections once more, stamp, ownership back
         void run_mailbox();
         // the ownership of a process call, given back on every way out of it (an error return included)
@@ -228,6 +229,7 @@ namespace hcv
         std::atomic<uint64_t> mMailboxNsMax { 0 }, mMailboxNsTotal { 0 };   // ... and what they took of its calls
         std::atomic<uint64_t> mCtlSections { 0 };           // sections control threads ran themselves (no stream running)
         std::atomic<uint64_t> mStartCollisions { 0 };
+        std::atomic<uint64_t> mStartWaits { 0 };            // calls of kOfflineCallSamples or more that waited a control section out instead (audio_enter)
         bool apply_pending_resets();
         std::atomic<uint32_t> mResetAllGen { 0 };           // reset_all() calls so far
         uint32_t mResetAllSeen = 0;                         // ... applied so far (audio side)

@@ -1450,8 +1450,14 @@ void Engine::run_mailbox()
     }
 }
 
-// audio thread, first thing in a process call: ONE attempt at the ownership, no loop, no lock, no device call
-bool Engine::audio_enter()
+// audio thread, first thing in a process call: ONE attempt at the ownership, no loop, no lock, no device call — for the calls of a
+// real-time host.  `samples` = the length of the call: a call of kOfflineCallSamples or more is no audio callback (2048 samples are 21 ms at
+// 96 kHz), and for such a call — an offline loop that pauses between its chunks while another thread loads impulse responses — a silent
+// block of that size would be the wrong trade: it waits out the control thread's short section instead (sleeping, 100 ms at most; counted in
+// start_waits).  Nothing changes for the calls the contract is about.
+constexpr uint64_t kOfflineCallSamples = 2048;
+
+bool Engine::audio_enter(uint64_t samples)
 {
     const long long now = steady_ns();
     note_device_streaming(mDevice, now);
@@ -1460,8 +1466,22 @@ bool Engine::audio_enter()
     uint32_t expect = kOwnerFree;
     if (!mOwner.compare_exchange_strong(expect, kOwnerAudio, std::memory_order_seq_cst))
     {
-        mStartCollisions.fetch_add(1, std::memory_order_relaxed);
-        return false;
+        bool got = false;
+        if (samples >= kOfflineCallSamples)
+        {
+            for (int k = 0; k < 5000 && !got; k++)
+            {
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                expect = kOwnerFree;
+                got = mOwner.compare_exchange_strong(expect, kOwnerAudio, std::memory_order_seq_cst);
+            }
+            if (got) mStartWaits.fetch_add(1, std::memory_order_relaxed);
+        }
+        if (!got)
+        {
+            mStartCollisions.fetch_add(1, std::memory_order_relaxed);
+            return false;
+        }
     }
     run_mailbox();
     return true;

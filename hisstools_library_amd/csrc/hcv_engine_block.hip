@@ -1096,7 +1096,7 @@ bool Engine::process_begin(const float *const *ins, uint32_t nin_act, uint32_t n
     if (!nout_act || !B) return true;
     if (B > mMaxBlock) { mErr = "process_begin: block longer than max_block"; return false; }
     const uint32_t rows_in = mCfg.diag ? nout_act : nin_act;
-    if (!audio_enter())
+    if (!audio_enter(B))
     {
         mHostMuted = true;              // (a stream-start collision, hcv_engine.h: this block is silent, nothing of the engine's state is touched)
         return true;
@@ -1197,7 +1197,7 @@ bool Engine::process_pinned(const float *ins_host, const float *ins_map, int64_t
     for (uint64_t pos = 0; pos < n; pos += mMaxBlock)
     {
         const uint32_t B = (uint32_t) std::min<uint64_t>(mMaxBlock, n - pos);
-        if (!audio_enter())
+        if (!audio_enter(n))
         {
             for (uint32_t o = 0; o < nout_act; o++) std::memset(outs_host + (size_t) o * out_stride + pos, 0, sizeof(float) * B);
             continue;
@@ -1239,7 +1239,7 @@ bool Engine::process_dev(const float *ins, int64_t in_stride, float *outs, int64
     nin_act = std::min(nin_act, mCfg.nin);
     if (!nout_act || !n) return true;
     {
-        if (!audio_enter())
+        if (!audio_enter(n))
         {
             // a stream-start collision (hcv_engine.h): silence for this call; nothing of the engine's state is touched
             HCV_TRY(hipMemset2DAsync(outs, sizeof(float) * (size_t) out_stride, 0, sizeof(float) * n, nout_act, mStream));

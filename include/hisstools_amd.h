@@ -209,11 +209,13 @@ HCV_API int hcv_host_unregister(void *ptr);
 typedef struct hcv_rt_stats
 {
     uint64_t start_collisions;  /* process calls that found a control thread inside a section: only the FIRST call of a stream (after a pause of
-                                 * 0.4 s or more) can; that call's block is silent — no wait, no retry — and the next call proceeds */
+                                 * 0.4 s or more) can; that call's block is silent — no wait, no retry — and the next call proceeds (calls of 2048 samples or more: start_waits) */
     uint64_t mailbox_runs;      /* swap sections of control calls that the audio thread ran between two of its blocks */
     uint64_t mailbox_ns_max;    /* ... the longest of them, nanoseconds of the audio thread's time */
     uint64_t mailbox_ns_total;  /* ... and their sum */
     uint64_t ctl_sections;      /* swap sections control threads ran themselves (no stream running) */
+    uint64_t start_waits;       /* calls of 2048 samples or more (an offline loop, not an audio callback) that met such a section and waited it out —
+                                 * sleeping, 100 ms at most — instead of delivering a silent block of that size */
     uint64_t arena_misses;      /* control-path allocations the control arena could not serve: the driver mapped memory, and every stream of the
                                  * process may have stalled for tens of milliseconds meanwhile (hcv_ctl_reserve) */
 } hcv_rt_stats;

@@ -185,3 +185,61 @@ def _scenario_body(H, oracle, entry, RB, ncalls, torch, dev, nin, nout, fs, stea
     y2_ref = ref2.run(xs[:, :40000], len(rows), 2048)
     for k, o in enumerate(rows):
         assert rel_err(y2[o], y2_ref[k]) < 1e-5
+
+
+_COLLISION_SCRIPT = r"""
+import sys, threading, time, json
+import numpy as np
+sys.path.insert(0, ".")
+import hisstools_library_amd as H
+from oracle import oracle as O
+c = H.Convolver(2, 2, 0)
+ha, hb = O.synth_ir(0, 0, 9000), O.synth_ir(1, 1, 9000)
+for o in range(2):
+    for i in range(2):
+        assert c.set(i, o, ha, True) == 0
+x = np.stack([O.synth_audio(i, 8192) for i in range(2)])
+res = {}
+# no stream is running: a control thread serves itself, and is held inside its section for 150 ms (HCV_TEST_CTL_STALL_US).  The FIRST call of a
+# stream arrives meanwhile: 128 samples — an audio callback: silence at once, no wait; then (another pause, another section) 4096 samples — an
+# offline loop's chunk: it waits the section out and delivers
+for name, n in (("callback", 128), ("chunk", 4096)):
+    time.sleep(0.55)
+    c.clear_stats()
+    th = threading.Thread(target=lambda: c.set(0, 0, hb if name == "callback" else ha, True))
+    th.start()
+    time.sleep(0.04)
+    y = np.full((2, n), 7.0, np.float32)
+    t0 = time.perf_counter()
+    c.process(x[:, :n], y)
+    dt = 1e3 * (time.perf_counter() - t0)
+    th.join()
+    rt = c.rt_stats()
+    res[name] = {"ms": dt, "peak": float(np.abs(y).max()), "start_collisions": rt["start_collisions"], "start_waits": rt["start_waits"], "ctl_sections": rt["ctl_sections"]}
+# and the call after a collision proceeds
+y = np.zeros((2, 128), np.float32)
+c.process(x[:, :128], y)
+res["after"] = {"peak": float(np.abs(y).max())}
+print(json.dumps(res))
+"""
+
+
+def test_the_first_call_of_a_stream_meeting_a_control_section():
+    """The one case in which a process call cannot have the engine (hcv_engine.h: start_collisions): no stream running, a control thread inside a
+    section — held there 150 ms by HCV_TEST_CTL_STALL_US — and the stream's first call arrives.  A 128-sample call (an audio callback) returns at
+    once with a silent block, waits for nothing, and the next call plays; a 4096-sample call (an offline loop's chunk, not a callback) waits the
+    section out instead of delivering 4096 samples of silence (start_waits)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _COLLISION_SCRIPT], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, HCV_TEST_CTL_STALL_US="150000"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    print(r)
+    assert r["callback"]["start_collisions"] == 1 and r["callback"]["start_waits"] == 0 and r["callback"]["peak"] == 0.0, r
+    assert r["callback"]["ms"] < 20.0, r                           # it did not wait for the 150 ms section
+    assert r["chunk"]["start_collisions"] == 0 and r["chunk"]["start_waits"] == 1 and r["chunk"]["peak"] > 0.0, r
+    assert 50.0 < r["chunk"]["ms"] < 400.0, r                      # it waited the section out
+    assert r["after"]["peak"] > 0.0, r

@@ -273,7 +273,7 @@ bool Engine::init(const EngineCfg &cfg)
 
     HCV_TRY(hipMalloc(&mHist, sizeof(float) * mCfg.nin * mHistLen));
     HCV_TRY(hipMemset(mHist, 0, sizeof(float) * mCfg.nin * mHistLen));
-    // (retire_pair's frame, allocated here so that no swap section under the engine lock ever allocates)
+    // (retire_pair's frame, allocated here so that no swap section in an owner section ever allocates)
     if (nmax) HCV_TRY(hipMalloc(&mRetireTmp, sizeof(float) * nmax));
     HCV_TRY(hipMalloc(&mDevIn, sizeof(float) * mCfg.nin * mMaxBlock));
     HCV_TRY(hipMalloc(&mDevOut, sizeof(float) * mCfg.nout * mMaxBlock));
@@ -739,7 +739,7 @@ bool Engine::fence_background(bool keep_plan)
 //
 // The MemorySwap idea (MemorySwap.h:187-229) applied to the whole stage: the new buffers are allocated and filled on the
 // control stream while the audio thread keeps processing on the old ones; only the pointer swap — plus a catch-up copy of
-// the few ring slots written meanwhile — happens under the engine lock.
+// the few ring slots written meanwhile — happens in an owner section.
 bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
 {
     std::lock_guard<std::mutex> gs(mSetMutex);
@@ -753,7 +753,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
     // (one 19 ms `process` call observed beside a regrow to 0.5 GB) — the pool keeps what it has, so make such growth rare
     newP = std::max<uint32_t>(newP, st.Pcap + st.Pcap / 2);
 
-    // ---- outside the engine lock: allocate, clear, re-stride what exists
+    // ---- outside any owner section: allocate, clear, re-stride what exists
     const size_t pairs = (size_t) mCfg.nout * mNinAlloc;
     const uint32_t newR = newP + 2 * st.Tmax + st.ring_extra;
     float2 *nHs = nullptr, *nX = nullptr;
@@ -799,7 +799,7 @@ bool Engine::ensure_stage_capacity(size_t s, uint64_t capacity)
         return false;
     }
 
-    // ---- under the engine lock: the hops that arrived since the snapshot, then the pointer swap (no allocation, no wait)
+    // ---- in an owner section: the hops that arrived since the snapshot, then the pointer swap (no allocation, no wait)
     float2 *oHs = nullptr, *oX = nullptr;
     const bool old_ctl = st.hs_ctl;
     (void) run_exclusive([&]()
@@ -1216,10 +1216,10 @@ bool Engine::ensure_staging(Stage &st, uint32_t parts)
 
 // Load / clear one pair's IR (Convolver::set -> ... -> PartitionedConvolve::set, PartitionedConvolve.cpp:173-225).
 //
-// Phase A, no engine lock: the IR is uploaded and transformed into STAGING buffers on the control stream — the pageable host
+// Phase A, no owner section: the IR is uploaded and transformed into STAGING buffers on the control stream — the pageable host
 // copy, the FFTs of every partition and the wait for them happen while the audio thread keeps processing with the pair's
 // previous spectra (the reference mutes the pair for those blocks instead, MonoConvolve.cpp:118-140,181-183).
-// Phase B, under the engine lock: the pair's pending output is retired, the staged spectra are copied into place on the main
+// Phase B, in an owner section: the pair's pending output is retired, the staged spectra are copied into place on the main
 // stream (device-to-device, asynchronous) and the bookkeeping is swapped — a short, host-only section with no allocation, no
 // host copy and no device wait, which is all the audio thread can ever wait for.
 bool Engine::set_ir(uint32_t in, uint32_t out, const float *ir, uint64_t len, bool device_ptr)

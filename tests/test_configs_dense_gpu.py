@@ -118,5 +118,9 @@ def test_hop_sized_host_pointer_calls_on_a_streamed_engine_vs_oracle(H, oracle):
         assert rel_err(y[o], y_ref[k]) < 1e-5, (o, rel_err(y[o], y_ref[k]))
         assert rel_err(y[o][-8 * B:], y_ref[k][-8 * B:]) < 1e-5, (o, "steady span")
     tail = c.stage_stats()[-1]
-    assert tail["partitions"] == 70 and tail["mac_launches"] == hops, tail
-    assert tail["host_pre_launches"] >= hops - 75, tail      # every steady-state hop took the split form
+    assert tail["partitions"] == 70, tail
+    import os
+    off = os.environ.get("HCV_HOST_PRE_MAC") == "0" or os.environ.get("HCV_SERIAL") == "1" or os.environ.get("HCV_TAIL_HEAD") == "0"
+    if not off:                                              # (tools/knob_matrix.sh: the result above holds under every knob, the schedule not)
+        assert tail["mac_launches"] == hops, tail
+        assert tail["host_pre_launches"] >= hops - 75, tail  # every steady-state hop took the split form

@@ -87,6 +87,7 @@ elif mode == "dev":
     res["all_same"] = len(set(shas)) == 1
     res["sha"] = shas[0]
     res["fused_launches"] = int(c.stage_stats()[-1]["fused_launches"])
+    res["stood_down"] = int(c.stage_stats()[-1]["fused_stood_down"])
     res["ms_per_block"] = t_blk * 1e3
 elif mode == "mixed":
     c = make()
@@ -128,7 +129,7 @@ else:
             y = yd.cpu().numpy()
             shas.append(hashlib.sha256(y.tobytes()).hexdigest())
             errs.append(max(rel_err(y[o], y_ref[o]) for o in range(nout)))
-        result[k] = (shas, max(errs), int(c.stage_stats()[-1]["fused_launches"]))
+        result[k] = (shas, max(errs), int(c.stage_stats()[-1]["fused_launches"]), int(c.stage_stats()[-1]["fused_stood_down"]))
 
     ts = [threading.Thread(target=drive, args=(k,)) for k in range(K)]
     for t in ts:
@@ -139,4 +140,5 @@ else:
     res["all_same"] = len({s for r in result for s in r[0]}) == 1
     res["sha"] = result[0][0][0]
     res["fused_launches"] = min(r[2] for r in result)
+    res["stood_down"] = sum(r[3] for r in result)
 print(json.dumps(res))

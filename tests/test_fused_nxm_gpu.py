@@ -69,10 +69,19 @@ def test_mode_changes_and_a_live_swap():
 
 
 def test_four_engines_at_once():
+    """Four engines, a host thread each, eight busy streams over the device's four hardware queues: forward launches DO arrive late here
+    now and then (behind another engine's packets).  A late launch costs time, not bits (the helping path) — but three of them within 64
+    blocks and the stage takes the separate kernels for a while (fused_stood_down), whose sums agree to rounding only.  So: every stream
+    within tolerance of the oracle always; the same bits from every engine and repetition wherever no stage stood down, and always
+    with every wait forced out (no stand-down then: nothing is reported as late) — the bits of one undisturbed engine."""
+    one = _run(16, 8, 48000, 16, "dev")
+    assert one["max_err"] < TOL and one["all_same"] and one["stood_down"] == 0, one
     r = _run(16, 8, 48000, 16, "many", engines=4)
-    assert r["max_err"] < TOL and r["all_same"] and r["fused_launches"] >= 3, r
+    assert r["max_err"] < TOL and r["fused_launches"] >= 3, r
+    if r["stood_down"] == 0:
+        assert r["all_same"] and r["sha"] == one["sha"], (r, one)
     h = _run(16, 8, 48000, 16, "many", engines=4, extra_env={"HCV_COOP_SPIN": "0"})
-    assert h["max_err"] < TOL and h["all_same"] and h["sha"] == r["sha"], (h, r)
+    assert h["max_err"] < TOL and h["all_same"] and h["stood_down"] == 0 and h["sha"] == one["sha"], (h, one)
 
 
 def test_a_forward_stream_that_falls_blocks_behind_keeps_off_the_rings():

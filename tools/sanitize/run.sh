@@ -2,13 +2,13 @@
 # The host layer under ThreadSanitizer and AddressSanitizer on the GPU box.
 #   here (no GPU):   make -C hisstools_library_amd/csrc tsan asan      -> tools/sanitize/lib/libhisstools_amd_{tsan,asan}.so
 #   on the box:      bash tools/sanitize/run.sh [tsan|asan|both] [pytest args]   -> gpurun_out/sanitize/{tsan,asan}.txt + summary
-# The tests are the ones that exercise the host-side concurrency: the audio-thread contract (process beside set / resize / regrow: engine lock,
-# mailbox, control turns, arena), the sharded object (shard pool, per-shard engines), the fused blocks under contention (several engines and
+# The tests are the ones that exercise the host-side concurrency: the audio-thread contract (process beside set / resize / regrow: ownership word,
+# mailbox, control sections, arena), the sharded object (shard pool, per-shard engines), the fused blocks under contention (several engines and
 # host threads) and the per-pair restarts.  The sanitizer runtime is preloaded into the Python process; only libhisstools_amd is instrumented.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 WHICH=${1:-both}; shift || true
-TESTS=${SAN_TESTS:-"tests/test_audio_thread_contract_gpu.py tests/test_sharded_object_gpu.py::test_sharded_object_matches_unsharded_and_oracle tests/test_sharded_object_gpu.py::test_sharded_object_device_pointers tests/test_sharded_object_gpu.py::test_sharded_object_enqueue_threads tests/test_fused_block_contention_gpu.py::test_eight_concurrent_engines tests/test_fused_nxm_gpu.py::test_four_engines_at_once tests/test_pair_restart_gpu.py"}
+TESTS=${SAN_TESTS:-"tests/test_audio_thread_contract_gpu.py tests/test_sharded_object_gpu.py::test_sharded_object_matches_unsharded_and_oracle tests/test_sharded_object_gpu.py::test_sharded_object_device_pointers tests/test_sharded_object_gpu.py::test_sharded_object_enqueue_threads tests/test_fused_block_contention_gpu.py::test_eight_concurrent_engines tests/test_fused_nxm_gpu.py::test_four_engines_at_once tests/test_pair_restart_gpu.py tests/test_gpu_parity.py::test_reference_quirks_mode_mutes_the_pair_while_set_is_in_progress"}
 RTDIR=/opt/rocm/lib/llvm/lib/clang/22/lib/linux
 OUT=gpurun_out/sanitize; mkdir -p $OUT
 # (the sanitizers intercept dlopen, and a library opened through the interceptor is no longer looked up along its caller's RPATH: PyTorch's lazily

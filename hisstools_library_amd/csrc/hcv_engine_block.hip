@@ -647,15 +647,81 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // Serial blocks: everything on the main stream, in program order, with no events at all.  A dependency on a pending event
     // of another stream costs the host ~10 us (a kernel launch 2.6, an event record 1.7 — tools/micro/api_cost.hip), so a
     // small engine running one stage per block (whole-hop mode: 26 calls, five such dependencies, 111 us of host time for
-    // 60 us of kernels on the 8x1 workload) is bound by its own enqueue; big engines keep the overlap.  HCV_SERIAL = 0 / 1
+    // 60 us of kernels on the 8x1 workload) is bound by its own enqueue; big engines keep their streams (but see below).  HCV_SERIAL = 0 / 1
     // forces the choice for whole-hop blocks; single-stream engines are always serial.
     static const int serial_env = std::getenv("HCV_SERIAL") ? std::atoi(std::getenv("HCV_SERIAL")) : -1;
     constexpr double kSerialMB = 1024.0;
     const bool small_tail = whole_hops && (double) mStages[last]->live_parts * mStages[last]->M * sizeof(float2) < kSerialMB * 1048576.0;
     // (an extended ladder keeps its streams: the rungs' deferred slices run beside the pivot stage's latency-bound chain — c5 on the ladder
     // 0.147 ms per 8192-sample block on one stream, 0.135 on the stages' own)
-    const bool serial = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : (small_tail && !rungs)));
+    const bool serial_small = mOneStream || (whole_hops && (serial_env >= 0 ? serial_env != 0 : (small_tail && !rungs)));
+    // ... and big engines keep it for the blocks that do not take the n x m fused block (below): a steady-state one-hop block of a streamed
+    // engine through device pointers does take it, on the main stream like a small engine's (round 6, one box, streamed -> this: c5 1.954 ->
+    // 1.909 ms per step, ns64 2.470 -> 2.403, c4 0.524 -> 0.504 — the forward transforms run under the previous block's inverse and the
+    // partial spectra meet in LDS; in round 5 the block gained nothing there).  Not where a host-pointer call has put the old partitions'
+    // multiply-accumulate on the stage's stream already (host_pre_mac).
+    const bool pre_pending = mPre.valid && mPre.block == mBlockCount;
+    const bool big_candidate = whole_hops && serial_env < 0 && !serial_small && !rungs && !pre_pending;
+    const bool full_matrix_c = nout_act == mCfg.nout && nin_act == (mCfg.diag ? mCfg.nout : mCfg.nin);
+    // (direct input / output of whole-hop blocks: see below where the block's fields are set)
+    const bool direct_in_c = rows_in > 0 && whole_hops && !is_big_fft(mStages[last]->log2n) && ((uintptr_t) din % 8) == 0 && (in_stride % 2) == 0 && !entering;
+    const bool direct_out_c = whole_hops && !entering && !rungs && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
+    bool nxm_take = false;
+    FusedNxmPlan nxm_plan_c;
+    // The n x m fused block (hcv_fused_nxm.hip): a steady-state one-hop block of a serial engine with several outputs whose last stage
+    // is the reference's 16384-point tail with a lead slot — one rank's share of a strong-scaled matrix (64 x 8 of config 4 over 8 GPUs)
+    // is the shape it was built for.  Forward transforms on the pipe stream, ONE multiply-accumulate + inverse launch on the main
+    // stream, no event between them (HCV_COOP = 0: the separate kernels).
+    // Streamed engines (a GB and more of tail spectra) take it too since round 6 (`big_candidate` above; in round 5, before the forward launch
+    // was placed under the previous block's inverse, 64 x 64 gained nothing with 2 s IRs — 0.553 -> 0.551 ms per step — and lost 3 % with 10 s).
+    // The pivot stage of an extended ladder can take it (HCV_NXM_LADDER = 1; its hop then goes into the stage's timeline, which emit adds to
+    // the rungs') but does not by default.  Measured, c5 on the ladder, ms per step: ONE lane 0.147 / 0.153 with it against 0.137 / 0.140
+    // without (one workgroup per CU with most of its registers crowds the rungs' slices out while it runs); TWO lanes (enqueue_stage) as the
+    // process's only engine 0.121 - 0.129 with it against 0.125 - 0.131 without — inside the boxes' spread — and as the process's SECOND engine
+    // (bench.py's extended leg) 0.80 with it: its forward launches sat behind the first engine's streams in a hardware queue they share, every
+    // multiply-accumulate waited its full bound and then did the transforms itself.  The stand-down below brings that to 0.148; the two
+    // lanes alone run 0.118 - 0.125 there (0.60 - 0.64 of HBM for the ladder's 601 MB per step), so that is the default.
+    static const int nxm_ladder_env = std::getenv("HCV_NXM_LADDER") ? std::atoi(std::getenv("HCV_NXM_LADDER")) : 0;
+    const bool nxm_ladder = nxm_ladder_env != 0;
+    if ((serial_small || big_candidate || (rungs && nxm_ladder)) && whole_hops && direct_in_c && (direct_out_c || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
+        full_matrix_c && mPipeStream && B == mStages[last]->M)
+    {
+        const Stage &tl = *mStages[last];
+        const long long h = n0 / (long long) tl.M;
+        const int Pw = (int) (tl.P + tl.lead);
+        const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
+        // (launches whose wait for the forward transforms ran out report it, hcv_fused_nxm.hip: three of them within 64 blocks and the stage
+        // takes the separate kernels for the next 64 .. 4096 blocks — the forward stream is stuck behind another stream in a hardware queue they
+        // share, e.g. a second engine of the process: c5 on the ladder as the bench's second engine ran 0.80 ms per step that way, 0.125 without)
+        Stage &tw_ = *mStages[last];
+        if (tw_.nxm_helped)
+        {
+            const unsigned now = *reinterpret_cast<volatile unsigned *>(tw_.nxm_helped);
+            if (now != tw_.nxm_helped_seen)
+            {
+                tw_.nxm_helped_seen = now;
+                tw_.nxm_strikes = (mBlockCount - tw_.nxm_strike_block <= 64) ? tw_.nxm_strikes + 1 : 1;
+                tw_.nxm_strike_block = mBlockCount;
+                if (tw_.nxm_strikes >= 3)
+                {
+                    // (round 6: the stand-down backs off — 64 blocks the first time, four times longer each time it recurs within 1024 blocks of
+                    // coming back, 4096 at most — instead of 4096 blocks for any three late launches: a co-tenant's burst costs half a second of
+                    // the separate kernels, not 34)
+                    if (mBlockCount - tw_.nxm_off_until > 1024) tw_.nxm_backoff = 64;
+                    tw_.nxm_off_until = mBlockCount + tw_.nxm_backoff;
+                    tw_.nxm_backoff = std::min<uint64_t>(4096, tw_.nxm_backoff * 4);
+                    tw_.nxm_stood_down++;
+                    tw_.nxm_strikes = 0;
+                }
+            }
+        }
+        if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw && mBlockCount >= tl.nxm_off_until)
+            nxm_take = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &nxm_plan_c);
+    }
+    const bool serial = serial_small || (big_candidate && nxm_take);
     Block blk;
+    blk.nxm = nxm_take && (serial || rungs);
+    blk.nxm_plan = nxm_plan_c;
     blk.din = din; blk.dout = dout; blk.in_stride = in_stride; blk.out_stride = out_stride;
     blk.nin_act = nin_act; blk.nout_act = nout_act; blk.rows_in = rows_in; blk.B = B;
     blk.n0 = n0; blk.hmask = hmask; blk.q = q; blk.last = last;
@@ -719,60 +785,6 @@ bool Engine::enqueue_chunk(const float *din, int64_t in_stride, float *dout, int
     // zero-latency transform per output and hop, so the inverse's last pass writes the caller's block (launch_rifft_emit) and the
     // emit launch — with its wait for the stage's stream — goes too.  Needs 8-byte aligned output rows.
     blk.direct_out = whole_hops && !entering && !rungs && ((uintptr_t) dout % 8) == 0 && (out_stride % 2) == 0;
-    // The n x m fused block (hcv_fused_nxm.hip): a steady-state one-hop block of a serial engine with several outputs whose last stage
-    // is the reference's 16384-point tail with a lead slot — one rank's share of a strong-scaled matrix (64 x 8 of config 4 over 8 GPUs)
-    // is the shape it was built for.  Forward transforms on the pipe stream, ONE multiply-accumulate + inverse launch on the main
-    // stream, no event between them (HCV_COOP = 0: the separate kernels).
-    blk.nxm = false;
-    // Streamed engines (a GB and more of tail spectra) keep the separate kernels: measured with the block forced on, one box, 64 x 64 (512
-    // workgroups in two rounds) gains nothing with 2 s IRs (0.553 -> 0.551 ms per step) and loses 3 % with 10 s; c5's 16 x 16 / 703 partitions
-    // (one round) ran 1.82 against 1.99 ms in one pair of runs and 1.94 / 1.95 against 1.92 / 1.99 in the next — both kernels stream at
-    // 0.93 - 0.95 of what the box reads at all, and the difference is the box's own spread.
-    // The pivot stage of an extended ladder can take it (HCV_NXM_LADDER = 1; its hop then goes into the stage's timeline, which emit adds to
-    // the rungs') but does not by default.  Measured, c5 on the ladder, ms per step: ONE lane 0.147 / 0.153 with it against 0.137 / 0.140
-    // without (one workgroup per CU with most of its registers crowds the rungs' slices out while it runs); TWO lanes (enqueue_stage) as the
-    // process's only engine 0.121 - 0.129 with it against 0.125 - 0.131 without — inside the boxes' spread — and as the process's SECOND engine
-    // (bench.py's extended leg) 0.80 with it: its forward launches sat behind the first engine's streams in a hardware queue they share, every
-    // multiply-accumulate waited its full bound and then did the transforms itself.  The stand-down below brings that to 0.148; the two
-    // lanes alone run 0.118 - 0.125 there (0.60 - 0.64 of HBM for the ladder's 601 MB per step), so that is the default.
-    static const int nxm_ladder_env = std::getenv("HCV_NXM_LADDER") ? std::atoi(std::getenv("HCV_NXM_LADDER")) : 0;
-    const bool nxm_ladder = nxm_ladder_env != 0;
-    if ((serial || (rungs && nxm_ladder)) && whole_hops && direct_in && (blk.direct_out || (rungs && !entering)) && !mCfg.diag && mCfg.nout > 1 &&
-        blk.full_matrix && mPipeStream && B == mStages[last]->M)
-    {
-        const Stage &tl = *mStages[last];
-        const long long h = n0 / (long long) tl.M;
-        const int Pw = (int) (tl.P + tl.lead);
-        const bool wcheck = (h - tl.max_hv) < (long long) Pw - 1;           // (right after a reset the partitions have bounds: the checked kernels)
-        // (launches whose wait for the forward transforms ran out report it, hcv_fused_nxm.hip: three of them within 64 blocks and the stage
-        // takes the separate kernels for the next 64 .. 4096 blocks — the forward stream is stuck behind another stream in a hardware queue they
-        // share, e.g. a second engine of the process: c5 on the ladder as the bench's second engine ran 0.80 ms per step that way, 0.125 without)
-        Stage &tw_ = *mStages[last];
-        if (tw_.nxm_helped)
-        {
-            const unsigned now = *reinterpret_cast<volatile unsigned *>(tw_.nxm_helped);
-            if (now != tw_.nxm_helped_seen)
-            {
-                tw_.nxm_helped_seen = now;
-                tw_.nxm_strikes = (mBlockCount - tw_.nxm_strike_block <= 64) ? tw_.nxm_strikes + 1 : 1;
-                tw_.nxm_strike_block = mBlockCount;
-                if (tw_.nxm_strikes >= 3)
-                {
-                    // (round 6: the stand-down backs off — 64 blocks the first time, four times longer each time it recurs within 1024 blocks of
-                    // coming back, 4096 at most — instead of 4096 blocks for any three late launches: a co-tenant's burst costs half a second of
-                    // the separate kernels, not 34)
-                    if (mBlockCount - tw_.nxm_off_until > 1024) tw_.nxm_backoff = 64;
-                    tw_.nxm_off_until = mBlockCount + tw_.nxm_backoff;
-                    tw_.nxm_backoff = std::min<uint64_t>(4096, tw_.nxm_backoff * 4);
-                    tw_.nxm_stood_down++;
-                    tw_.nxm_strikes = 0;
-                }
-            }
-        }
-        if (tl.lead && tl.coop_flags && !tl.coop_off && !tl.gh_count && !wcheck && h + 1 >= Pw && mBlockCount >= tl.nxm_off_until)
-            blk.nxm = fused_block_nxm_plan(tl.log2n, (int) rows_in, (int) nout_act, Pw, tl.y_elems, &blk.nxm_plan) &&
-                      (serial || rungs);
-    }
     if (blk.nxm)
     {
         if (!mPrevNxm || ctl_was_dirty)

@@ -1,12 +1,19 @@
-"""Full-depth, steady-state parity of the kernel instantiation the headline roofline is quoted on:
-spectral_mac_kernel<OT = 8, TT = 1, CHECK = false, NT = true> with split-K (hcv_mac.hip), i.e. the tail stage of a matrix
-with >= 8 outputs once EVERY partition of every pair is live (PartitionedConvolve.cpp:321-348 scheduling all P partitions,
-:387-426 the multiply-accumulate).  The ramp-up after a reset runs the CHECK = true, non-NT variant, so each test here streams
-past the whole IR length, puts energy into every region of the IR (every partition index, every k-slice, the ring wrap at
-R = Pcap + 2 Tmax), and asserts through the stage statistics that the steady-state instantiation actually ran.
+"""Full-depth, steady-state parity of the launches the headline roofline is quoted on — the tail stage of a matrix with >= 8 outputs once
+EVERY partition of every pair is live (PartitionedConvolve.cpp:321-348 scheduling all P partitions, :387-426 the multiply-accumulate):
+  * device-pointer one-hop blocks (what bench.py times; from round 6 on streamed engines too): the n x m fused block, mac_meet_kernel
+    (hcv_fused_nxm.hip) — the same unchecked, nontemporal sum with its k-slices meeting in LDS;
+  * the stage's own stream (host-pointer calls, a stage that stood down, HCV_SERIAL=0): spectral_mac_kernel<OT = 8, TT = 1, CHECK = false,
+    NT = true> with split-K (hcv_mac.hip).
+The ramp-up after a reset runs the CHECK = true, non-NT variant, so each test here streams past the whole IR length, puts energy into every
+region of the IR (every partition index, every k-slice, the ring wrap at R = Pcap + 2 Tmax), and asserts through the stage statistics that
+the steady-state launch actually ran — and which one.
 
 Tolerance: max|y - y_ref| <= 1e-5 * max|y_ref| per channel for the long-IR / many-input shapes.
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -96,6 +103,23 @@ def test_config5_full_depth_steady_state(H, torch):
     assert tail["mac_launches"] == hops
     # every hop from the 703rd on runs the unchecked instantiation with nontemporal loads
     assert tail["mac_steady_launches"] >= hops - 704, tail
+    # ... and which launch that is: the fused block by default, the split-K kernel on the stage's stream where a knob says so
+    if os.environ.get("HCV_SERIAL") == "0" or os.environ.get("HCV_COOP") == "0" or os.environ.get("HCV_TAIL_HEAD") == "0":
+        assert tail["fused_launches"] == 0 and tail["ksplit"] > 1, tail
+    elif os.environ.get("HCV_SERIAL") is None:
+        assert tail["fused_launches"] >= hops - 704 - 64 * tail["fused_stood_down"] and tail["fused_launches"] > 0, tail
+
+
+def test_config5_full_depth_on_the_stage_stream():
+    """The same case with the whole-hop blocks kept on the stage's own stream (HCV_SERIAL=0, read once per process: a child process) —
+    spectral_mac_kernel<8, 1, false, true> with its 24 k-slices through memory, reduce / inverse behind it: what host-pointer calls, a
+    stage that stood down and every round before the sixth run at this depth."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HCV_SERIAL="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_steady_state_gpu.py") + "::test_config5_full_depth_steady_state",
+                          "-q", "-m", "gpu", "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "1 passed" in out.stdout, out.stdout[-1000:]
 
 
 def test_config5_extended_ladder_full_depth(H, torch):

@@ -32,9 +32,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"{k[0]:48s} {'x'.join(k[1]):>22s} {k[2]:>4s} {k[3]:>5s} {k[4]:>5s} {len(v):6d} {t/len(v):10.2f} {min(v):10.2f} {t/1e3:10.3f} {100*t/tot:6.2f}")
 
 if last_k:
-    # The tail stage's steady-state spectral_mac: look at the window holding the final 4K spectral_mac launches of the run
+    # The tail stage's steady-state multiply-accumulate (spectral_mac_*, or the n x m block's mac_meet_kernel): the window holding the final 4K such launches of the run
     # (K steps x up to four stages), and take the variant whose launches inside it are the longest on average.
-    macs = sorted((t, k, i) for k, v in starts.items() if "spectral_mac" in k[0] for i, t in enumerate(v))
+    macs = sorted((t, k, i) for k, v in starts.items() if ("spectral_mac" in k[0] or "mac_meet_kernel" in k[0]) for i, t in enumerate(v))
     if macs:
         window_start = macs[max(0, len(macs) - 4 * last_k)][0]
         best = None

@@ -32,16 +32,12 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"{k[0]:48s} {'x'.join(k[1]):>22s} {k[2]:>4s} {k[3]:>5s} {k[4]:>5s} {len(v):6d} {t/len(v):10.2f} {min(v):10.2f} {t/1e3:10.3f} {100*t/tot:6.2f}")
 
 if last_k:
-    # The tail stage's steady-state multiply-accumulate (spectral_mac_*, or the n x m block's mac_meet_kernel): the window holding the final 4K such launches of the run
-    # (K steps x up to four stages), and take the variant whose launches inside it are the longest on average.
+    # The tail stage's steady-state multiply-accumulate (spectral_mac_*, or the n x m block's mac_meet_kernel)
     macs = sorted((t, k, i) for k, v in starts.items() if ("spectral_mac" in k[0] or "mac_meet_kernel" in k[0]) for i, t in enumerate(v))
     if macs:
-        window_start = macs[max(0, len(macs) - 4 * last_k)][0]
-        best = None
-        for k in {m[1] for m in macs}:
-            sel = [agg[k][i] for i, t in enumerate(starts[k]) if t >= window_start][-last_k:]
-            if len(sel) >= last_k // 2 and (best is None or sum(sel) / len(sel) > sum(best[1]) / len(best[1])):
-                best = (k, sel)
-        if best:
-            top, sel = best
-            print(f"\ntimed region: last {len(sel)} launches of {top[0]} grid {'x'.join(top[1])}: avg {sum(sel)/len(sel):.2f} us, min {min(sel):.2f} us, max {max(sel):.2f} us")
+        # the kernel that owns most of the run's final K such launches (the timed steps are the last thing the bench does; a ramp-up's
+        # checked launches — longer each — come before them), and its last K launches
+        from collections import Counter
+        top = Counter(m[1] for m in macs[-last_k:]).most_common(1)[0][0]
+        sel = [d for _, d in sorted(zip(starts[top], agg[top]))][-last_k:]
+        print(f"\ntimed region: last {len(sel)} launches of {top[0]} grid {'x'.join(top[1])}: avg {sum(sel)/len(sel):.2f} us, min {min(sel):.2f} us, max {max(sel):.2f} us")

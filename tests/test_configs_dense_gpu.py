@@ -124,3 +124,63 @@ def test_hop_sized_host_pointer_calls_on_a_streamed_engine_vs_oracle(H, oracle):
     if not off:                                              # (tools/knob_matrix.sh: the result above holds under every knob, the schedule not)
         assert tail["mac_launches"] == hops, tail
         assert tail["host_pre_launches"] >= hops - 75, tail  # every steady-state hop took the split form
+
+
+def test_live_swap_on_a_streamed_engine_between_fused_blocks_vs_oracle(H, oracle):
+    """A streamed engine (16 x 16, 71 partitions: 1.2 GB of live tail spectra) driven through DEVICE pointers one hop per call: its
+    steady-state blocks are the n x m fused block on the main stream (round 6), its ramp-up blocks the checked kernels on the stage's stream.
+    One pair's impulse response is replaced in mid-stream (Convolver::set beside process, MonoConvolve.cpp:118-140): the engine leaves the
+    fused block for the pair's ramp-up (partition bounds: the checked kernels, back on the stage's stream) and returns to it — forward
+    stream joined and lined up again both ways.  Rows 0, 7, 8, 15 against the oracle driven through the same calls, over the whole stream."""
+    import os
+    import torch
+    dev = torch.device("cuda:0")
+    nin = nout = 16
+    B = 8192
+    L = B + 70 * B - 999
+    hops_a, hops_b = 80, 82
+    S = (hops_a + hops_b) * B
+    rows, cols = [0, 7, 8, 15], [0, 1, 2, 3]
+    c = H.Convolver(nin, nout, 0, custom=(L, True, 256, 1024, 4096, 16384), maxBlock=B)
+    ref = oracle.Convolver(len(cols), len(rows), 0)
+    ref.setResetOffset(0)
+    spare = []
+    for o in rows:
+        for i in cols:
+            h = oracle.synth_ir(i, o, L - 555 * (i % 3))
+            assert c.set(i, o, h, True) == 0 and ref.set(i, rows.index(o), h, True) == 0
+            if len(spare) < 4:
+                spare.append(torch.from_numpy(np.ascontiguousarray(h)).to(dev))
+    k = 0
+    for o in range(nout):
+        for i in range(nin):
+            if not (o in rows and i in cols):
+                torch.cuda.synchronize()
+                assert c.set_dev(i, o, spare[k % len(spare)].data_ptr(), spare[k % len(spare)].numel(), True) == 0
+                k += 1
+    xs = np.zeros((nin, S), np.float32)
+    for i in cols:
+        xs[i] = oracle.synth_audio(i, S)
+    xd = torch.from_numpy(xs).to(dev)
+    yd = torch.zeros((nout, S), device=dev)
+    torch.cuda.synchronize()
+    c.clear_stats()
+    new_ir = oracle.synth_ir(41, 42, L - 123)
+    y_ref = []
+    for seg, (h0, h1) in enumerate(((0, hops_a), (hops_a, hops_a + hops_b))):
+        if seg == 1:
+            assert c.set(1, 7, new_ir, True) == 0 and ref.set(1, rows.index(7), new_ir, True) == 0
+        for hop in range(h0, h1):
+            c.process_dev(xd.data_ptr() + 4 * hop * B, S, yd.data_ptr() + 4 * hop * B, S, nin, nout, B, sync=False)
+        c.synchronize()
+        y_ref.append(ref.run(xs[cols][:, h0 * B:h1 * B], len(rows), 2048))
+    y = yd.cpu().numpy()
+    y_ref = np.concatenate(y_ref, axis=1)
+    for k, o in enumerate(rows):
+        assert rel_err(y[o], y_ref[k]) < TOL_SUM, (o, rel_err(y[o], y_ref[k]))
+        assert rel_err(y[o][hops_a * B:], y_ref[k][hops_a * B:]) < TOL_SUM, (o, "after the swap")
+    tail = c.stage_stats()[-1]
+    assert tail["partitions"] == 70 and tail["mac_launches"] == hops_a + hops_b, tail
+    if all(os.environ.get(v) is None for v in ("HCV_SERIAL", "HCV_COOP", "HCV_TAIL_HEAD", "HCV_EXACT_RESTART")):
+        # both steady stretches took the fused block (9 + 11 blocks), the two ramp-ups did not
+        assert 12 <= tail["fused_launches"] <= 24, tail

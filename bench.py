@@ -5,8 +5,9 @@
 
 One "step" = one Convolver::process call of B samples (default 8192 = one hop of the 16384-point tail stage) over
 the whole channel matrix, audio and IR spectra resident in HBM.  Metric (BASELINE.json): output-channel
-Msamples/s for the node, next to the achieved-vs-peak HBM bandwidth of the dominant kernel (spectral_mac of the
-tail stage).
+Msamples/s for the node, next to the achieved-vs-peak HBM bandwidth of the dominant kernel (the tail stage's spectral
+multiply-accumulate launch: mac_meet_kernel of the n x m block, or spectral_mac_kernel where that block does not apply —
+`roofline.kernel` names it).
 
 Workloads (BASELINE.json configs; default c5 = the config the metric's HBM clause is quoted on):
     c5    Convolver 16x16, 60 s @ 96 kHz IRs (L = 5,760,000), zero latency      11.8 GB of tail spectra

@@ -357,4 +357,13 @@ hipError_t big_rifft_rows(int log2n, const float2 *src, int batch, float *dst, c
     return hipGetLastError();
 }
 
+// (Engine::init, once per device: HIP loads a translation unit's code object at the first launch of one of its kernels — 0.3 - 0.8 ms on the
+// calling thread, which for the kernels of a control section or a restart is the audio thread in mid-stream; asking for a kernel's attributes loads it now)
+void preload_bigfft()
+{
+    hipFuncAttributes fa;
+    (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(big_load_kernel));
+    (void) hipGetLastError();
+}
+
 } // namespace hcv

@@ -212,6 +212,21 @@ bool Engine::init(const EngineCfg &cfg)
         return false;
     }
     DeviceGuard dg(mDevice);
+    {
+        // every kernel the engine may launch from the audio thread is resident on this device before the first block (hcv_kernels.h: preload_*)
+        static std::atomic<bool> loaded[64];
+        if (mDevice < 64 && !loaded[mDevice].exchange(true, std::memory_order_acq_rel))
+        {
+            preload_kernels();
+            preload_mac();
+            preload_mac_tiled();
+            preload_mac_mfma();
+            preload_ghost();
+            preload_bigfft();
+            preload_fft_split();
+            preload_fused_nxm();
+        }
+    }
 
     mMaxBlock = cfg.max_block;
     if (!mMaxBlock)

@@ -737,4 +737,13 @@ hipError_t launch_fused_block_hops(int log2n, float *hist, long long hist_mask, 
     return fused_launched(arrived, seq, nfwd, MACW);
 }
 
+// (Engine::init, once per device: HIP loads a translation unit's code object at the first launch of one of its kernels — 0.3 - 0.8 ms on the
+// calling thread, which for the kernels of a control section or a restart is the audio thread in mid-stream; asking for a kernel's attributes loads it now)
+void preload_fft_split()
+{
+    hipFuncAttributes fa;
+    (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>((rifft_split_emit_kernel<14, 4, 256>)));
+    (void) hipGetLastError();
+}
+
 } // namespace hcv

@@ -419,4 +419,13 @@ hipError_t launch_fused_block_nxm(const FusedNxmPlan &pl, float *hist, long long
     return launch_rifft_emit_split(LOG2N, Y, pl.ms, (long long) nout * M, 1, nout, out, out_stride, tw, st, a.hint, std::min(kNxmHints, nout * 8), a.sy.seq);
 }
 
+// (Engine::init, once per device: HIP loads a translation unit's code object at the first launch of one of its kernels — 0.3 - 0.8 ms on the
+// calling thread, which for the kernels of a control section or a restart is the audio thread in mid-stream; asking for a kernel's attributes loads it now)
+void preload_fused_nxm()
+{
+    hipFuncAttributes fa;
+    (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>((mac_meet_kernel<kNxmLog2N>)));
+    (void) hipGetLastError();
+}
+
 } // namespace hcv

@@ -228,4 +228,14 @@ namespace hcv
     hipError_t launch_swap_in(const SwapPlan &pl, hipStream_t st);
     hipError_t launch_regrow_spectra(const float2 *src, float2 *dst, long long pairs, int Pold, int Pnew, int M, hipStream_t st);
     hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold, int Rnew, int M, long long h_last, int live, hipStream_t st);
+
+    // each translation unit's code object loaded on the current device now, not at the first launch of one of its kernels (see hcv_kernels.hip)
+    void preload_kernels();
+    void preload_mac();
+    void preload_mac_tiled();
+    void preload_mac_mfma();
+    void preload_ghost();
+    void preload_bigfft();
+    void preload_fft_split();
+    void preload_fused_nxm();
 }

@@ -1195,4 +1195,13 @@ hipError_t launch_regrow_ring(const float2 *src, float2 *dst, int nin, int Rold,
     return hipGetLastError();
 }
 
+// (Engine::init, once per device: HIP loads a translation unit's code object at the first launch of one of its kernels — 0.3 - 0.8 ms on the
+// calling thread, which for the kernels of a control section or a restart is the audio thread in mid-stream; asking for a kernel's attributes loads it now)
+void preload_kernels()
+{
+    hipFuncAttributes fa;
+    (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(swap_in_kernel));
+    (void) hipGetLastError();
+}
+
 } // namespace hcv

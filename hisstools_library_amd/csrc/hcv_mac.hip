@@ -407,4 +407,13 @@ hipError_t launch_spectral_mac(const MacShape &s, const MacPlan &pl, const float
     }
 }
 
+// (Engine::init, once per device: HIP loads a translation unit's code object at the first launch of one of its kernels — 0.3 - 0.8 ms on the
+// calling thread, which for the kernels of a control section or a restart is the audio thread in mid-stream; asking for a kernel's attributes loads it now)
+void preload_mac()
+{
+    hipFuncAttributes fa;
+    (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>((spectral_mac_kernel<8, 1, false, true, false>)));
+    (void) hipGetLastError();
+}
+
 } // namespace hcv

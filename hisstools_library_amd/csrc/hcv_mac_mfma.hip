@@ -284,4 +284,13 @@ hipError_t launch_mac_mfma(const MacPlan &pl, const MacParams &a, hipStream_t st
     return hipGetLastError();
 }
 
+// (Engine::init, once per device: HIP loads a translation unit's code object at the first launch of one of its kernels — 0.3 - 0.8 ms on the
+// calling thread, which for the kernels of a control section or a restart is the audio thread in mid-stream; asking for a kernel's attributes loads it now)
+void preload_mac_mfma()
+{
+    hipFuncAttributes fa;
+    (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>((spectral_mac_mfma_kernel<2, true>)));
+    (void) hipGetLastError();
+}
+
 } // namespace hcv

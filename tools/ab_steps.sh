@@ -1,3 +1,5 @@
+#!/bin/bash
+# The driver's short run (20 steps after 5) against longer ones and longer warm-ups, new default against HCV_SERIAL=0, one box, two rounds (c5).
 for rep in 1 2; do
 for cfg in "X=0 20 5" "HCV_SERIAL=0 20 5" "X=0 45 5" "X=0 20 30" "HCV_SERIAL=0 20 30"; do
   set -- $cfg

@@ -161,7 +161,10 @@ HCV_API hcv_convolver *hcv_convolver_create_extended(uint32_t numIns, uint32_t n
 /* IR already in HBM on the object's device */
 HCV_API int hcv_convolver_set_f32_dev(hcv_convolver *h, uint32_t inChan, uint32_t outChan, const float *input_dev, uintptr_t length, int resize);
 /* ins_dev: [numIns][in_stride] floats, outs_dev: [numOuts][out_stride] floats, both in HBM.  Asynchronous on the object's
- * stream unless sync != 0.  Returns 0 ok, -1 failure. */
+ * streams unless sync != 0: the input rows must hold their samples when the call is made (what produced them has finished, or was
+ * synchronised with), and both buffers are the object's until hcv_convolver_synchronize — or a call with sync != 0 — returns: the
+ * block's launches read and write them on streams of the object's own (one block's transforms may run beside the previous block's
+ * inverse).  Returns 0 ok, -1 failure. */
 HCV_API int hcv_convolver_process_f32_dev(hcv_convolver *h, const float *ins_dev, size_t in_stride, float *outs_dev, size_t out_stride,
                                           size_t numIns, size_t numOuts, size_t numSamples, int sync);
 HCV_API int hcv_convolver_synchronize(hcv_convolver *h);
